@@ -1,0 +1,8 @@
+"""megapath_nano_amd -- MI355X-native alignment + read-reassignment hot path of MegaPath-Nano.
+
+Only what the path needs lives here: csrc/ (HIP kernels + the C-ABI in libmpn.so), _ffi.py (ctypes
+loader, no CPU fallback), and host-side mirrors of the reference's stage interfaces:
+  pyssw.py        <- /root/reference/bin/realignment/pyssw.py       (SSW class)
+  aligner.py      <- /root/reference/bin/lib/aligner.py             (Align)
+  reassignment.py <- /root/reference/bin/lib/reassignment.py        (Reassign)
+"""

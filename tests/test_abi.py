@@ -1,0 +1,45 @@
+"""CPU tests: libmpn.so builds, loads, and exports every symbol include/*.h declares (no compute)."""
+import ctypes as ct
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = set()
+    for h in glob.glob(os.path.join(ROOT, 'include', '*.h')):
+        text = open(h).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        text = re.sub(r'//[^\n]*', '', text)
+        for m in re.finditer(r'\b([A-Za-z_][A-Za-z0-9_]*)\s*\(', text):
+            name = m.group(1)
+            if name.startswith(('mpn_', 'ssw_')) or name in ('init_destroy', 'align_destroy'):
+                syms.add(name)
+    return syms
+
+
+def test_headers_declare_something():
+    syms = declared_symbols()
+    assert {'ssw_init', 'ssw_align', 'init_destroy', 'align_destroy', 'mpn_ssw_align_batch',
+            'mpn_last_error'} <= syms
+
+
+def test_library_exports_all_declared_symbols(libmpn):
+    for s in sorted(declared_symbols()):
+        assert hasattr(libmpn, s), f'libmpn.so does not export {s}'
+
+
+def test_s_align_layout_matches_reference_struct():
+    # ssw.h:47-57 / pyssw.py:7-16: 2xu16, 5xi32, pointer, i32  -> 40 bytes on LP64
+    from megapath_nano_amd.pyssw import CAlignRes
+    assert ct.sizeof(CAlignRes) == 40
+    assert CAlignRes.sCigar.offset == 24 and CAlignRes.nCigarLen.offset == 32
+
+
+def test_product_does_not_import_oracle():
+    for path in glob.glob(os.path.join(ROOT, 'megapath_nano_amd', '**', '*'), recursive=True):
+        if path.endswith(('.py', '.hip', '.h', '.cpp')):
+            text = open(path).read()
+            assert 'oracle' not in text.replace('oracle/ssw_oracle.c for the', ''), f'{path} mentions the oracle'
