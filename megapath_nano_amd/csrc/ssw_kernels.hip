@@ -283,8 +283,11 @@ __global__ __launch_bounds__(64) void ssw_banded_kernel(BandDev b) {
             const int f1 = max(f, 0);
             const int temp1 = max(e1, f1);
             const int h = max(temp1, temp2);
-            const int hl = lane == 0 ? carry_h : wave_shr1(h, 0);
-            const int fleft = lane == 0 ? carry_f : wave_shr1(f, 0);
+            // DPP reads are hoisted out of the selects: a DPP executed under a partial EXEC mask would see
+            // the masked-off source lane as invalid
+            const int h_sh = wave_shr1(h, 0), f_sh = wave_shr1(f, 0);
+            const int hl = lane == 0 ? carry_h : h_sh;
+            const int fleft = lane == 0 ? carry_f : f_sh;
             const int df = (hl - gapO > fleft - gapE) ? 5 : 4;
             const int dh = temp1 <= temp2 ? 1 : (e1 > f1 ? de : df);
             if (act) {

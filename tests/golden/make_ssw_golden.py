@@ -41,3 +41,47 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def pyssw_golden():
+    """(score, cigar string, ref_begin) from the reference's own Python wrapper
+    (/root/reference/bin/realignment/pyssw.py SSW.align) driving the compiled reference ssw.c."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location('ref_pyssw', '/root/reference/bin/realignment/pyssw.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    so = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'oracle', '_ref', 'libssw.so')
+    rng = np.random.default_rng(77)
+    out = []
+    for t in range(6):
+        ref = ''.join('ACGTN'[x] for x in rng.choice(5, size=int(rng.integers(120, 500)), p=[.245, .245, .245, .245, .02]))
+        s = mod.SSW(lib_path=so)
+        s.set_reference_sequence(ref)
+        qs = []
+        for k in range(8):
+            lo = int(rng.integers(0, len(ref) - 40))
+            hi = int(rng.integers(lo + 20, min(len(ref), lo + 200)))
+            q = list(ref[lo:hi])
+            for _ in range(int(rng.integers(0, 6))):
+                p = int(rng.integers(0, len(q)))
+                r = rng.random()
+                if r < 0.4:
+                    q[p] = 'ACGT'[int(rng.integers(0, 4))]
+                elif r < 0.7:
+                    q.insert(p, 'acgtn'[int(rng.integers(0, 5))])
+                else:
+                    del q[p]
+            if k == 7:
+                q = list('TTAGGC') + q + list('x')  # soft clips + an unknown letter
+            q = ''.join(q)
+            score, cigar, beg = s.align(q)
+            qs.append(dict(query=q, score=int(score), cigar=cigar, ref_begin=int(beg)))
+        out.append(dict(reference=ref, queries=qs))
+    with open(os.path.join(HERE, 'pyssw_golden.json'), 'w') as f:
+        json.dump(dict(source='reference pyssw.SSW.align via oracle/_ref/libssw.so', sets=out), f, separators=(',', ':'))
+    print('wrote pyssw golden', sum(len(x['queries']) for x in out))
+
+
+if __name__ == '__main__':
+    pyssw_golden()

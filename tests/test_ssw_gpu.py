@@ -70,19 +70,20 @@ def test_reference_abi_single_calls(libmpn, oracle_built):
         assert sb.ssw_abi_align(lib, **kw) == sb.oracle_align(**kw)
 
 
-def test_pyssw_mirror_matches_reference_examples(libmpn):
-    """Values recorded in SURVEY.md section 8c from the reference's pyssw.SSW + compiled ssw.c."""
+def test_pyssw_mirror_matches_reference_wrapper_golden(libmpn):
+    """tests/golden/pyssw_golden.json: outputs of the reference's pyssw.SSW.align (score, cigar string with
+    `=`/soft clips, ref_begin) on the reference's compiled ssw.c."""
+    import json
+    import os
     from megapath_nano_amd.pyssw import SSW
-    rng = np.random.default_rng(5)
-    ref = ''.join('ACGT'[x] for x in rng.integers(0, 4, size=300))
-    s = SSW()
-    s.set_reference_sequence(ref)
-    q = ref[10:60]
-    assert s.align(q) == (200, '50=', 10)
-    q2 = ref[20:45] + 'GT' + ref[45:80]
-    score, cigar, beg = s.align(q2)
-    assert (score, beg) == (220, 20) and cigar in ('25=2I35=',)
-    assert s.align_batch([q, q2]) == [(200, '50=', 10), (score, cigar, beg)]
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pyssw_golden.json')) as f:
+        sets = json.load(f)['sets']
+    for st in sets:
+        s = SSW()
+        s.set_reference_sequence(st['reference'])
+        want = [(q['score'], q['cigar'], q['ref_begin']) for q in st['queries']]
+        assert [s.align(q['query']) for q in st['queries'][:3]] == want[:3]
+        assert s.align_batch([q['query'] for q in st['queries']]) == want
 
 
 def test_edge_cases(libmpn, oracle_built):
