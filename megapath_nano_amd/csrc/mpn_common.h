@@ -18,6 +18,38 @@ void set_error(const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// ---- device buffer with RAII (host-side plumbing) --------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        MPN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        return 0;
+    }
+    int zero(hipStream_t st) {
+        if (n) MPN_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), st));
+        return 0;
+    }
+    int upload(const T *h, size_t count, hipStream_t st) {
+        if (alloc(count)) return -1;
+        if (count) MPN_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    int download(T *h, size_t count, hipStream_t st) const {
+        if (count) MPN_HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, st));
+        return 0;
+    }
+};
+
 // ---- wave64 cross-lane primitives (DPP; no LDS traffic) ---------------------------------
 constexpr int NEG_INF = -(1 << 28);
 

@@ -17,23 +17,12 @@
 #include "mpn_common.h"
 #include "../../include/mpn_ssw.h"
 
-#include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include <algorithm>
 
 namespace mpn {
-
-static thread_local std::string g_err;
-void set_error(const char *fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_err = buf;
-}
 
 struct SswDev {
     const int8_t *reads, *refs;
@@ -343,28 +332,6 @@ __global__ __launch_bounds__(64) void ssw_banded_kernel(BandDev b) {
 
 // ---------------------------------------------------------------------------------------------
 // host side
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t count) {
-        n = count;
-        if (count == 0) count = 1;
-        MPN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
-        return 0;
-    }
-    int upload(const T *h, size_t count, hipStream_t st) {
-        if (alloc(count)) return -1;
-        if (count) MPN_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
-        return 0;
-    }
-    int download(T *h, size_t count, hipStream_t st) {
-        if (count) MPN_HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, st));
-        return 0;
-    }
-};
-
 template <int R>
 static int launch_score(const SswDev &d, const int32_t *order_dev, int count, hipStream_t st) {
     if (count == 0) return 0;
@@ -551,8 +518,6 @@ struct _profile {  // opaque to callers (pyssw.py only passes the pointer back)
 };
 
 extern "C" {
-
-const char *mpn_last_error(void) { return mpn::g_err.c_str(); }
 
 int mpn_ssw_align_batch(int32_t n_pairs, const int8_t *reads, const int64_t *read_off, const int32_t *read_len,
                         const int8_t *refs, const int64_t *ref_off, const int32_t *ref_len, const int8_t *mat,
