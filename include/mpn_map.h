@@ -1,0 +1,98 @@
+/*
+ * mpn_map.h -- C-ABI of the MI355X-native long-read mapper (libmpn.so): the seed-chain-extend path that
+ * MegaPath-Nano runs as an external `minimap2` process.
+ *
+ * Reference interface replaced:  /root/reference/bin/lib/aligner.py:187-231  builds
+ *     [aligner, -c, (-a), -t N, -I xG, (-N 50 -p 1), -x map-ont, <target fasta>, <query fastq>...]
+ * and reads PAF (or SAM) from the child's stdout (:204-206, :225-231); options come from
+ * /root/reference/bin/megapath_nano.py:1124 (human/decoy filter) and :1270 (species placement).
+ * The reference has no in-process FFI for this step (it is a process boundary), so the entry points below are
+ * what a binding for it needs: build/load an index from target sequences, map a batch of reads, get PAF text
+ * with minimap2's `-c` tag order (NM at column 13, AS at column 15, which the awk at aligner.py:271-273
+ * relies on).  The Python mirror megapath_nano_amd/aligner.py Align() wraps them behind the reference's own
+ * function signature; bin/mpn-aligner is the `--aligner` executable drop-in.
+ *
+ * Semantics: minimap2 2.17 `-x map-ont` as restated in oracle/mm2_oracle.c (PARITY UNPINNED: minimap2 is not
+ * vendored by the reference; DESIGN.md section 6 lists the deliberate differences).
+ *
+ * Stage entry points (mpn_sketch_batch, mpn_seed_chain_batch) exist so that the parity tests can compare every
+ * GPU stage with the oracle; mpn_map_batch is the product call.
+ */
+#ifndef MPN_MAP_H
+#define MPN_MAP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpn_index mpn_index;
+
+typedef struct {
+    /* indexing */
+    int32_t k, w;                 /* -k 15 -w 10 (map-ont) */
+    /* seeding / chaining */
+    float mid_occ_frac;           /* -f 2e-4 */
+    int32_t mid_occ;              /* > 0 overrides the quantile */
+    int32_t max_gap, bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+    /* hit selection */
+    float mask_level, pri_ratio;  /* -p */
+    int32_t best_n;               /* -N */
+    int32_t max_join_long, max_join_short, min_join_flank_sc;
+    float min_join_flank_ratio;
+    /* base-level extension (-c) */
+    int32_t a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;
+    float max_clip_ratio;
+    int64_t max_sw_mat;
+    int32_t with_cigar;           /* -c; 0 = mapping_only (aligner.py:188) */
+    uint32_t seed;
+    int32_t host_threads;         /* threads for the host-side hit bookkeeping; 0 = all cores */
+} mpn_map_opt;
+
+/* minimap2 2.17 defaults for `-x map-ont -c` (-N 5 -p 0.8) */
+void mpn_map_opt_init(mpn_map_opt *opt);
+
+/* Build the index of n_seq target sequences (ASCII, any case; non-ACGT = ambiguous) and keep it resident in
+ * HBM together with the 2-bit packed targets.  Returns NULL on failure (mpn_last_error()). */
+mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
+                           int32_t k, int32_t w);
+void mpn_index_destroy(mpn_index *idx);
+int64_t mpn_index_n_minimizers(const mpn_index *idx);
+int64_t mpn_index_n_keys(const mpn_index *idx);
+/* occurrence cut-off for a given -f (minimap2: mm_idx_cal_max_occ) */
+int32_t mpn_index_mid_occ(const mpn_index *idx, float frac);
+/* copies of index arrays for the parity tests: keys[n_keys], key_off[n_keys+1], pos[n_minimizers] */
+int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uint64_t *pos);
+
+/* ---- stage: (w,k)-minimizers of a batch of sequences, one CSR row per sequence ---------------------------
+ * seqs: concatenated ASCII; sequence i = seqs[seq_off[i] .. +seq_len[i]).  mz_off must hold n+1 entries.
+ * Minimizers are returned as (x = hash<<8|span, y = i<<32|last_pos<<1|strand) pairs in mz (cap pairs).
+ * Returns the total number of minimizers, or a negative error (-3: cap too small; mz_off is still filled). */
+int64_t mpn_sketch_batch(int32_t n, const char *seqs, const int64_t *seq_off, const int32_t *seq_len, int32_t k,
+                         int32_t w, int64_t *mz_off, uint64_t *mz, int64_t cap);
+
+/* ---- stage: seeds -> sorted anchors -> chains, for a batch of reads --------------------------------------
+ * Outputs (caller allocated; CSR over reads):
+ *   n_anchor[i], rep_len[i]               anchors found / repetitive-minimizer span (minimap2 rl:i)
+ *   chain_off[n+1], chains u[] (score<<32|cnt), achor_off[n+1], chained anchors b[] as (x, y) pairs
+ * Returns 0, or negative error (-3: a capacity is too small). */
+int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *seqs,
+                         const int64_t *seq_off, const int32_t *seq_len, int64_t *n_anchor, int32_t *rep_len,
+                         int64_t *chain_off, uint64_t *u, int64_t u_cap, int64_t *anchor_off, uint64_t *b,
+                         int64_t b_cap);
+
+/* ---- product call: map a batch of reads, PAF text out ----------------------------------------------------
+ * names: n NUL-terminated read names.  paf receives the lines of all reads in input order (NUL terminated).
+ * Returns the number of bytes written, or negative error (-3: paf_cap too small). */
+int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                      const char *seqs, const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap);
+
+/* Counters of the last mpn_map_batch / mpn_seed_chain_batch on this thread, for bench.py's roofline line:
+ * [0] input bases, [1] read minimizers, [2] anchors, [3] chain predecessor evaluations (not counted: 0),
+ * [4] DP jobs, [5] DP cells, [6] alignments reported, [7] kernel-time ns (HIP events, all kernels of the call). */
+void mpn_map_last_stats(int64_t stats[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

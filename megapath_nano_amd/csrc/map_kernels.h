@@ -1,0 +1,572 @@
+// Device kernels of the mapper's seed + chain stages (gfx950).  Included by mapper.hip only.
+//
+// Data layout in HBM (all struct-of-arrays, CSR over the reads of a batch):
+//   reads      ASCII bytes, concatenated; seq_off[i], seq_len[i]
+//   mz         read minimizers as 16-byte pairs (x = hash<<8|span, y = read<<32|last_pos<<1|strand); mz_off[n+1]
+//   index      keys[n_keys] (sorted 2k-bit hashes), key_off[n_keys+1], pos[] (rid<<32|last_pos<<1|strand)
+//   anchors    16-byte pairs (x = strand<<63|rid<<32|ref_pos, y = flags|span<<32|query_pos); anchor_off[n+1]
+//   chaining   f,p,t,v int32 per anchor; chain ends u (8 B each)
+// Every stage is integer / byte work bound by HBM latency and bandwidth, not by arithmetic: no MFMA.
+#pragma once
+#include "mpn_common.h"
+
+namespace mpn {
+
+struct u128 { uint64_t x, y; };
+
+__device__ __forceinline__ int nt4_code(uint8_t c) {
+    c |= 0x20;
+    return c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;
+}
+
+__device__ __forceinline__ uint64_t hash64m(uint64_t key, uint64_t mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// (w,k)-minimizers, one lane per sequence: the window automaton of minimap2's sketch (ring of the last w
+// non-symmetric k-mers; ties to the newest; identical minima all reported) is inherently sequential per
+// sequence, so parallelism comes from the batch.  The ring lives in LDS as [slot][thread] (conflict-free).
+// FILL=false counts, FILL=true writes at mz_off[i].
+template <bool FILL>
+__global__ __launch_bounds__(64) void sketch_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
+                                                    const int32_t *__restrict__ seq_len, int n, int w, int k,
+                                                    const int64_t *__restrict__ mz_off, int64_t *__restrict__ mz_cnt,
+                                                    u128 *__restrict__ mz, uint32_t rid_base) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t ring[];  // bx[w][64] then by[w][64]
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + tid;
+    uint64_t *bx = ring, *by = ring + (size_t)w * blockDim.x;
+    if (i >= n) return;
+    const uint8_t *s = seqs + seq_off[i];
+    const int len = seq_len[i];
+    const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+    uint64_t kmer0 = 0, kmer1 = 0, minx = ~0ULL, miny = ~0ULL;
+    int l = 0, buf_pos = 0, min_pos = 0;
+    int64_t cnt = 0;
+    u128 *out = FILL ? mz + mz_off[i] : nullptr;
+    const uint32_t rid = rid_base + (uint32_t)i;
+#define MPN_PUSH(X, Y) do { if (FILL) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } while (0)
+    for (int j = 0; j < w; ++j) bx[j * blockDim.x + tid] = ~0ULL, by[j * blockDim.x + tid] = ~0ULL;
+    for (int p = 0; p < len; ++p) {
+        const int c = nt4_code(s[p]);
+        uint64_t ix = ~0ULL, iy = ~0ULL;
+        if (c < 4) {
+            const int kmer_span = l + 1 < k ? l + 1 : k;
+            kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+            kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+            if (kmer0 == kmer1) continue;
+            const int z = kmer0 < kmer1 ? 0 : 1;
+            ++l;
+            if (l >= k) {
+                ix = hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+                iy = (uint64_t)rid << 32 | (uint32_t)p << 1 | (uint32_t)z;
+            }
+        } else l = 0;
+        bx[buf_pos * blockDim.x + tid] = ix, by[buf_pos * blockDim.x + tid] = iy;
+        if (l == w + k - 1 && minx != ~0ULL) {
+            for (int j = buf_pos + 1; j < w; ++j) {
+                uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
+                if (minx == x && y != miny) MPN_PUSH(x, y);
+            }
+            for (int j = 0; j < buf_pos; ++j) {
+                uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
+                if (minx == x && y != miny) MPN_PUSH(x, y);
+            }
+        }
+        if (ix <= minx) {
+            if (l >= w + k && minx != ~0ULL) MPN_PUSH(minx, miny);
+            minx = ix, miny = iy, min_pos = buf_pos;
+        } else if (buf_pos == min_pos) {
+            if (l >= w + k - 1 && minx != ~0ULL) MPN_PUSH(minx, miny);
+            minx = ~0ULL;
+            for (int j = buf_pos + 1; j < w; ++j) {
+                uint64_t x = bx[j * blockDim.x + tid];
+                if (minx >= x) minx = x, miny = by[j * blockDim.x + tid], min_pos = j;
+            }
+            for (int j = 0; j <= buf_pos; ++j) {
+                uint64_t x = bx[j * blockDim.x + tid];
+                if (minx >= x) minx = x, miny = by[j * blockDim.x + tid], min_pos = j;
+            }
+            if (l >= w + k - 1 && minx != ~0ULL) {
+                for (int j = buf_pos + 1; j < w; ++j) {
+                    uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
+                    if (minx == x && miny != y) MPN_PUSH(x, y);
+                }
+                for (int j = 0; j <= buf_pos; ++j) {
+                    uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
+                    if (minx == x && miny != y) MPN_PUSH(x, y);
+                }
+            }
+        }
+        if (++buf_pos == w) buf_pos = 0;
+    }
+    if (minx != ~0ULL) MPN_PUSH(minx, miny);
+#undef MPN_PUSH
+    if (!FILL) mz_cnt[i] = cnt;
+}
+
+// exclusive scan of n int64 by ONE block (n is the number of reads of a batch: small); out[n] = total
+__global__ __launch_bounds__(1024) void scan_i64_kernel(const int64_t *__restrict__ in, int64_t *__restrict__ out, int n) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x, per = (n + 1023) / 1024;
+    const int lo = min(n, tid * per), hi = min(n, lo + per);
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int64_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = tid ? part[tid - 1] : 0;
+    for (int i = lo; i < hi; ++i) { int64_t v = in[i]; out[i] = run; run += v; }
+    if (tid == 1023) out[n] = part[1023];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// seeds: one lane per read minimizer; binary search in the sorted key array
+__global__ __launch_bounds__(256) void seed_lookup_kernel(const uint64_t *__restrict__ keys, const int64_t *__restrict__ key_off,
+                                                          int64_t n_keys, const u128 *__restrict__ mz, int64_t n_mz,
+                                                          int32_t max_occ, int32_t *__restrict__ occ,
+                                                          int64_t *__restrict__ pos_start) {
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_mz; m += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = mz[m].x >> 8;
+        int64_t lo = 0, hi = n_keys;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        int32_t t = 0;
+        int64_t st = 0;
+        if (lo < n_keys && keys[lo] == key) { st = key_off[lo]; t = (int32_t)min<int64_t>(key_off[lo + 1] - st, 0x7fffffff); }
+        occ[m] = t >= max_occ ? -1 : t;  // -1: repetitive, skipped (counts into rep_len)
+        pos_start[m] = st;
+    }
+}
+
+// per read (one lane): anchor offsets of its minimizers, anchor total and rep_len (minimap2 collect_matches)
+__global__ __launch_bounds__(256) void seed_prefix_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int n,
+                                                          const int32_t *__restrict__ occ, int64_t *__restrict__ rel_off,
+                                                          int64_t *__restrict__ n_anchor, int32_t *__restrict__ rep_len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t run = 0;
+    int rep_st = 0, rep_en = 0, rl = 0;
+    for (int64_t m = mz_off[i]; m < mz_off[i + 1]; ++m) {
+        const int32_t t = occ[m];
+        rel_off[m] = run;
+        if (t < 0) {
+            const uint32_t q_pos = (uint32_t)mz[m].y, q_span = mz[m].x & 0xff;
+            const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
+            if (st > rep_en) { rl += rep_en - rep_st; rep_st = st, rep_en = en; }
+            else rep_en = en;
+        } else run += t;
+    }
+    rl += rep_en - rep_st;
+    n_anchor[i] = run;
+    rep_len[i] = rl;
+}
+
+__global__ __launch_bounds__(256) void seed_fill_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz,
+                                                        const int32_t *__restrict__ occ, const int64_t *__restrict__ pos_start,
+                                                        const int64_t *__restrict__ rel_off, const uint64_t *__restrict__ pos,
+                                                        const int64_t *__restrict__ anchor_off, const int32_t *__restrict__ seq_len,
+                                                        u128 *__restrict__ anchors) {
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_mz; m += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t t = occ[m];
+        if (t <= 0) continue;
+        const uint64_t mx = mz[m].x, my = mz[m].y;
+        const int read = (int)(my >> 32);
+        const uint32_t q_pos = (uint32_t)my, q_span = mx & 0xff;
+        const int32_t qlen = seq_len[read];
+        bool tandem = false;
+        if (m > mz_off[read] && mz[m - 1].x >> 8 == mx >> 8) tandem = true;
+        if (m + 1 < mz_off[read + 1] && mz[m + 1].x >> 8 == mx >> 8) tandem = true;
+        u128 *out = anchors + anchor_off[read] + rel_off[m];
+        const uint64_t *cr = pos + pos_start[m];
+        for (int32_t k = 0; k < t; ++k) {
+            const uint64_t r = cr[k];
+            const uint32_t rpos = (uint32_t)r >> 1;
+            u128 a;
+            if ((r & 1) == (q_pos & 1)) {
+                a.x = (r & 0xffffffff00000000ULL) | rpos;
+                a.y = (uint64_t)q_span << 32 | q_pos >> 1;
+            } else {
+                a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+                a.y = (uint64_t)q_span << 32 | (uint32_t)(qlen - ((int32_t)(q_pos >> 1) + 1 - (int32_t)q_span) - 1);
+            }
+            if (tandem) a.y |= 1ULL << 42;
+            out[k] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Segmented LSD radix sort, one workgroup (256 threads) per segment, 8-bit digits, stable.
+// Keys are the 96 bits (x, low 32 bits of y) of 16-byte records; a pass whose digit is constant over the
+// segment costs only its histogram.  Ranks inside a 256-element tile come from ballot-based multisplit.
+__device__ __forceinline__ uint32_t sort_digit(const u128 &r, int pass) {
+    return pass < 4 ? (uint32_t)(r.y >> (8 * pass)) & 0xff : (uint32_t)(r.x >> (8 * (pass - 4))) & 0xff;
+}
+
+__global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, u128 *__restrict__ tmp,
+                                                       const int64_t *__restrict__ seg_off, int n_seg) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t wcnt[4][256];
+    __shared__ int s_skip;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const int64_t base = seg_off[seg];
+        const int64_t n = seg_off[seg + 1] - base;
+        if (n < 2) continue;
+        u128 *src = data + base, *dst = tmp + base;
+        for (int pass = 0; pass < 12; ++pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int64_t i = tid; i < n; i += 256) atomicAdd(&hist[sort_digit(src[i], pass)], 1u);
+            __syncthreads();
+            if (tid == 0) s_skip = 0;
+            __syncthreads();
+            if (hist[tid] == (uint32_t)n) s_skip = 1;
+            __syncthreads();
+            if (s_skip) { __syncthreads(); continue; }
+            // exclusive scan of the histogram (256 entries, thread per bin)
+            {
+                uint32_t v = hist[tid];
+                bins[tid] = v;
+                __syncthreads();
+                for (int d = 1; d < 256; d <<= 1) {
+                    uint32_t a = tid >= d ? bins[tid - d] : 0;
+                    __syncthreads();
+                    bins[tid] += a;
+                    __syncthreads();
+                }
+                uint32_t excl = bins[tid] - v;
+                __syncthreads();
+                bins[tid] = excl;
+                __syncthreads();
+            }
+            for (int64_t t0 = 0; t0 < n; t0 += 256) {
+                const int64_t i = t0 + tid;
+                const bool act = i < n;
+                u128 r;
+                uint32_t dg = 0;
+                if (act) { r = src[i]; dg = sort_digit(r, pass); }
+                wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+                __syncthreads();
+                // lanes of this wave holding the same digit
+                unsigned long long same = __ballot(act);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    unsigned long long m = __ballot((dg >> b) & 1);
+                    same &= ((dg >> b) & 1) ? m : ~m;
+                }
+                const unsigned long long lt = (1ULL << lane) - 1;
+                const uint32_t rank = __popcll(same & lt);
+                if (act && rank == 0) wcnt[wv][dg] = __popcll(same);
+                __syncthreads();
+                if (act) {
+                    uint32_t o = bins[dg] + rank;
+                    for (int w2 = 0; w2 < wv; ++w2) o += wcnt[w2][dg];
+                    dst[o] = r;
+                }
+                __syncthreads();
+                bins[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+                __syncthreads();
+            }
+            u128 *sw = src; src = dst; dst = sw;
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (src != data + base) {
+            for (int64_t i = tid; i < n; i += 256) data[base + i] = src[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Chaining DP (minimap2 mm_chain_dp), one wavefront per read.  Anchor i is processed sequentially; its
+// predecessors j = i-1, i-2, ... are evaluated 64 at a time across the lanes.  The sequential semantics of
+// the max_skip heuristic (a counter that depends on the order in which predecessors are visited) are kept
+// exactly: the running maximum comes from a DPP prefix-max, the "already on a better chain" marks of the
+// current tile are exchanged through LDS, and the skip counter is replayed over the (few) event lanes.
+struct ChainParams {
+    int max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;
+};
+
+__device__ __forceinline__ int ilog2_32(uint32_t v) { return 31 - __clz((int)v); }
+
+__global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
+                                                      int n_reads, ChainParams cp, int32_t *__restrict__ F, int32_t *__restrict__ P,
+                                                      int32_t *__restrict__ T, int32_t *__restrict__ V) {
+    __shared__ int mark[64];
+    const int lane = threadIdx.x;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        if (n == 0) continue;
+        const u128 *a = anchors + base;
+        int32_t *f = F + base, *p = P + base, *t = T + base, *v = V + base;
+        // avg_qspan = (float)sum / n
+        unsigned long long sum = 0;
+        for (int64_t i = lane; i < n; i += 64) { sum += a[i].y >> 32 & 0xff; t[i] = 0; }
+        for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+        const float avg_qspan = (float)sum / (float)n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int64_t st = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const uint64_t ri = a[i].x;
+            const int32_t qi = (int32_t)a[i].y, q_span = a[i].y >> 32 & 0xff;
+            int32_t max_f = q_span, n_skip = 0;
+            int64_t max_j = -1;
+            while (st < i && ri > a[st].x + (uint64_t)cp.max_dist_x) ++st;
+            if (i - st > cp.max_iter) st = i - cp.max_iter;
+            bool broke = false;
+            for (int64_t j0 = i - 1; j0 >= st && !broke; j0 -= 64) {
+                const int64_t j = j0 - lane;
+                const bool in = j >= st;
+                bool cont = true;
+                int32_t sc = NEG_INF, pj = -1, tj = 0;
+                if (in) {
+                    const uint64_t ax = a[j].x, ay = a[j].y;
+                    const int64_t dr = (int64_t)(ri - ax);
+                    const int32_t dq = qi - (int32_t)ay;
+                    pj = p[j]; tj = t[j];
+                    if (!(dr == 0 || dq <= 0) && !(dq > cp.max_dist_y || dq > cp.max_dist_x)) {
+                        const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+                        if (dd <= cp.bw) {
+                            const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+                            int32_t s = min_d > q_span ? q_span : min_d;
+                            const int32_t log_dd = dd ? ilog2_32((uint32_t)dd) : 0;
+                            const int32_t gap_cost = (int)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);
+                            sc = s - gap_cost + f[j];
+                            cont = false;
+                        }
+                    }
+                }
+                // marks made by earlier lanes of this tile (p[j'] == my j)
+                mark[lane] = 0;
+                __syncthreads();
+                if (!cont && pj >= 0 && j0 - pj < 64 && j0 - pj >= 0) mark[(int)(j0 - pj)] = 1;
+                __syncthreads();
+                const bool tmark = (tj == (int32_t)i) || mark[lane];
+                // running maximum before each lane (sequential order = lane order)
+                const int incl = wave_scan_max(cont ? NEG_INF : sc);
+                const int excl_raw = wave_shr1(incl, NEG_INF);
+                const int before = max(max_f, excl_raw);
+                const bool newmax = !cont && sc > before;
+                const bool skipev = !cont && !newmax && tmark;
+                unsigned long long m1 = __ballot(newmax), m2 = __ballot(skipev);
+                int brk = 64;
+                {
+                    unsigned long long m = m1 | m2;
+                    while (m) {
+                        const int b = __builtin_ctzll(m);
+                        if ((m1 >> b) & 1) { if (n_skip > 0) --n_skip; }
+                        else if (++n_skip > cp.max_skip) { brk = b; break; }
+                        m &= m - 1;
+                    }
+                }
+                const bool elig = !cont && lane < brk;
+                const int best = wave_reduce_max(elig ? sc : NEG_INF);
+                if (best > max_f) {
+                    const unsigned long long who = __ballot(elig && sc == best);
+                    const int wl = __builtin_ctzll(who);
+                    max_f = best;
+                    max_j = j0 - wl;
+                }
+                if (elig && pj >= 0) t[pj] = (int32_t)i;
+                if (brk < 64) broke = true;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+            if (lane == 0) {
+                f[i] = max_f;
+                p[i] = (int32_t)max_j;
+                v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+
+// chain ends: anchors nobody points to with peak score >= min_sc; each is walked back to its peak
+__global__ __launch_bounds__(64) void chain_ends_kernel(const int64_t *__restrict__ anchor_off, int n_reads, ChainParams cp,
+                                                        const int32_t *__restrict__ F, const int32_t *__restrict__ P,
+                                                        int32_t *__restrict__ T, const int32_t *__restrict__ V,
+                                                        uint64_t *__restrict__ U, int32_t *__restrict__ n_ends) {
+    const int lane = threadIdx.x;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        const int32_t *f = F + base, *p = P + base, *v = V + base;
+        int32_t *t = T + base;
+        uint64_t *u = U + base;
+        for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        for (int64_t i = lane; i < n; i += 64) if (p[i] >= 0) t[p[i]] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        int cnt = 0;
+        for (int64_t i0 = 0; i0 < n; i0 += 64) {
+            const int64_t i = i0 + lane;
+            bool is_end = i < n && t[i] == 0 && v[i] >= cp.min_sc;
+            uint64_t val = 0;
+            if (is_end) {
+                int64_t j = i;
+                while (j >= 0 && f[j] < v[j]) j = p[j];
+                if (j < 0) j = i;
+                val = (uint64_t)(uint32_t)f[j] << 32 | (uint64_t)j;
+            }
+            const unsigned long long m = __ballot(is_end);
+            if (is_end) u[cnt + __popcll(m & ((1ULL << lane) - 1))] = val;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) n_ends[read] = cnt;
+        __syncthreads();
+    }
+}
+
+// sort the chain ends of every read in DESCENDING (score, index) order: 64-bit keys, reuse of the radix
+// machinery with a complemented key; one workgroup per read
+__global__ __launch_bounds__(256) void chain_sort_ends_kernel(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
+                                                              const int64_t *__restrict__ anchor_off,
+                                                              const int32_t *__restrict__ n_ends, int n_reads) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t wcnt[4][256];
+    __shared__ int s_skip;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int n = n_ends[read];
+        if (n < 2) continue;
+        uint64_t *src = U + base, *dst = Utmp + base;
+        for (int pass = 0; pass < 8; ++pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) atomicAdd(&hist[(uint32_t)(~src[i] >> (8 * pass)) & 0xff], 1u);
+            __syncthreads();
+            if (tid == 0) s_skip = 0;
+            __syncthreads();
+            if (hist[tid] == (uint32_t)n) s_skip = 1;
+            __syncthreads();
+            if (s_skip) { __syncthreads(); continue; }
+            {
+                uint32_t v = hist[tid];
+                bins[tid] = v;
+                __syncthreads();
+                for (int d = 1; d < 256; d <<= 1) {
+                    uint32_t a = tid >= d ? bins[tid - d] : 0;
+                    __syncthreads();
+                    bins[tid] += a;
+                    __syncthreads();
+                }
+                uint32_t excl = bins[tid] - v;
+                __syncthreads();
+                bins[tid] = excl;
+                __syncthreads();
+            }
+            for (int t0 = 0; t0 < n; t0 += 256) {
+                const int i = t0 + tid;
+                const bool act = i < n;
+                uint64_t r = 0;
+                uint32_t dg = 0;
+                if (act) { r = src[i]; dg = (uint32_t)(~r >> (8 * pass)) & 0xff; }
+                wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+                __syncthreads();
+                unsigned long long same = __ballot(act);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    unsigned long long m = __ballot((dg >> b) & 1);
+                    same &= ((dg >> b) & 1) ? m : ~m;
+                }
+                const uint32_t rank = __popcll(same & ((1ULL << lane) - 1));
+                if (act && rank == 0) wcnt[wv][dg] = __popcll(same);
+                __syncthreads();
+                if (act) {
+                    uint32_t o = bins[dg] + rank;
+                    for (int w2 = 0; w2 < wv; ++w2) o += wcnt[w2][dg];
+                    dst[o] = r;
+                }
+                __syncthreads();
+                bins[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+                __syncthreads();
+            }
+            uint64_t *sw = src; src = dst; dst = sw;
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (src != U + base) for (int i = tid; i < n; i += 256) U[base + i] = src[i];
+        __syncthreads();
+    }
+}
+
+// backtrack from the best chain end down: an anchor belongs to one chain only.  One wave per read; the walk
+// is sequential (lane 0), the copy of the chained anchors is parallel.
+//   out: u[k] = score<<32|cnt (in U, compacted), chained anchors in B (chain by chain, forward order), n_chain, n_chained
+__global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
+                                                             int n_reads, ChainParams cp, const int32_t *__restrict__ F,
+                                                             const int32_t *__restrict__ P, int32_t *__restrict__ T,
+                                                             int32_t *__restrict__ V, uint64_t *__restrict__ U,
+                                                             const int32_t *__restrict__ n_ends, u128 *__restrict__ B,
+                                                             int32_t *__restrict__ n_chain, int64_t *__restrict__ n_chained) {
+    __shared__ int s_k, s_nv;
+    const int lane = threadIdx.x;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        const u128 *a = anchors + base;
+        const int32_t *f = F + base, *p = P + base;
+        int32_t *t = T + base, *v = V + base;
+        uint64_t *u = U + base;
+        u128 *b = B + base;
+        const int n_u = n_ends[read];
+        for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (lane == 0) {
+            int n_v = 0, k = 0;
+            for (int i = 0; i < n_u; ++i) {
+                const int n_v0 = n_v, k0 = k;
+                const uint64_t ui = u[i];
+                int64_t j = (int32_t)ui;
+                do { v[n_v++] = (int32_t)j; t[j] = 1; j = p[j]; } while (j >= 0 && t[j] == 0);
+                if (j < 0) {
+                    if (n_v - n_v0 >= cp.min_cnt) u[k++] = ui >> 32 << 32 | (uint32_t)(n_v - n_v0);
+                } else if ((int32_t)(ui >> 32) - f[j] >= cp.min_sc) {
+                    if (n_v - n_v0 >= cp.min_cnt) u[k++] = ((ui >> 32) - (uint64_t)f[j]) << 32 | (uint32_t)(n_v - n_v0);
+                }
+                if (k0 == k) n_v = n_v0;
+            }
+            s_k = k; s_nv = n_v;
+            n_chain[read] = k;
+            n_chained[read] = n_v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        const int k = s_k;
+        int off = 0;
+        for (int c = 0; c < k; ++c) {
+            const int ni = (int32_t)u[c];
+            for (int j = lane; j < ni; j += 64) b[off + j] = a[v[off + (ni - j - 1)]];
+            off += ni;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mpn

@@ -1,0 +1,324 @@
+// Host orchestration of the mapper (index build, seed + chain stages) behind include/mpn_map.h.
+#include "map_kernels.h"
+#include "mapper_internal.h"
+#include "../../include/mpn_map.h"
+
+#include <algorithm>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace mpn {
+
+thread_local int64_t g_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+static int grid_1d(int64_t n, int block, int cap = 256 * 16) {
+    int64_t g = (n + block - 1) / block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+// sketch a batch that is already on the device; fills mz_off (device, n+1) and allocates mz
+int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len, int n, int k, int w,
+                  uint32_t rid_base, DevBuf<int64_t> &mz_off, DevBuf<u128> &mz, int64_t *n_mz, hipStream_t st) {
+    DevBuf<int64_t> cnt;
+    if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1)) return -1;
+    const size_t lds = (size_t)2 * w * 64 * sizeof(uint64_t);
+    if (n > 0) {
+        hipLaunchKernelGGL(sketch_kernel<false>, dim3((n + 63) / 64), dim3(64), lds, st, d_seqs, d_off, d_len, n, w, k,
+                           (const int64_t *)nullptr, cnt.p, (u128 *)nullptr, rid_base);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, cnt.p, mz_off.p, n);
+    MPN_HIP_CHECK(hipGetLastError());
+    int64_t total = 0;
+    MPN_HIP_CHECK(hipMemcpyAsync(&total, mz_off.p + n, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    if (mz.alloc((size_t)total)) return -1;
+    if (n > 0 && total > 0) {
+        hipLaunchKernelGGL(sketch_kernel<true>, dim3((n + 63) / 64), dim3(64), lds, st, d_seqs, d_off, d_len, n, w, k,
+                           (const int64_t *)mz_off.p, (int64_t *)nullptr, mz.p, rid_base);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    *n_mz = total;
+    return 0;
+}
+
+int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32_t *seq_len, DevBuf<uint8_t> &d_seqs,
+                DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st) {
+    int64_t extent = 0, bases = 0;
+    for (int i = 0; i < n; ++i) {
+        if (seq_len[i] < 0 || seq_off[i] < 0) { set_error("negative sequence length/offset at %d", i); return -2; }
+        extent = std::max<int64_t>(extent, seq_off[i] + seq_len[i]);
+        bases += seq_len[i];
+    }
+    if (d_seqs.alloc((size_t)extent + 16)) return -1;
+    if (extent) MPN_HIP_CHECK(hipMemcpyAsync(d_seqs.p, seqs, (size_t)extent, hipMemcpyHostToDevice, st));
+    if (d_off.upload(seq_off, n, st) || d_len.upload(seq_len, n, st)) return -1;
+    *total_bases = bases;
+    return 0;
+}
+
+// seeds -> sorted anchors -> chains for a batch resident on the device
+int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
+                      const int32_t *d_len, SeedChainOut &o, hipStream_t st) {
+    int64_t n_mz = 0;
+    DevBuf<int64_t> mz_off;
+    DevBuf<u128> mz;
+    if (sketch_device(d_seqs, d_off, d_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st)) return -1;
+    g_stats[1] += n_mz;
+    const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
+    DevBuf<int32_t> occ;
+    DevBuf<int64_t> pos_start, rel_off, n_anchor_d;
+    if (occ.alloc(n_mz) || pos_start.alloc(n_mz) || rel_off.alloc(n_mz) || n_anchor_d.alloc((size_t)n + 1) ||
+        o.rep_len.alloc(n) || o.anchor_off.alloc((size_t)n + 1))
+        return -1;
+    if (n_mz > 0) {
+        hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p,
+                           idx->n_keys, mz.p, n_mz, mid_occ, occ.p, pos_start.p);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(seed_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
+                       n_anchor_d.p, o.rep_len.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, n_anchor_d.p, o.anchor_off.p, n);
+    MPN_HIP_CHECK(hipGetLastError());
+    int64_t n_a = 0;
+    MPN_HIP_CHECK(hipMemcpyAsync(&n_a, o.anchor_off.p + n, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    o.n_anchors = n_a;
+    g_stats[2] += n_a;
+    DevBuf<u128> tmp;
+    DevBuf<int32_t> F, P, T, V;
+    DevBuf<uint64_t> Utmp;
+    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || F.alloc(n_a) || P.alloc(n_a) || T.alloc(n_a) || V.alloc(n_a) ||
+        o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n))
+        return -1;
+    if (n_a > 0) {
+        hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
+                           pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, o.anchors.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(seg_sort_kernel, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    ChainParams cp;
+    cp.max_dist_x = opt->max_gap; cp.max_dist_y = opt->max_gap; cp.bw = opt->bw; cp.max_skip = opt->max_chain_skip;
+    cp.max_iter = opt->max_chain_iter; cp.min_cnt = opt->min_cnt; cp.min_sc = opt->min_chain_score;
+    const int g = std::max(1, std::min(n, 256 * 32));
+    hipLaunchKernelGGL(chain_dp_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(chain_sort_ends_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(256), 0, st, o.u.p, Utmp.p,
+                       o.anchor_off.p, o.n_ends.p, n);
+    MPN_HIP_CHECK(hipGetLastError());
+    // chained anchors reuse the sort scratch
+    o.chained.p = tmp.p; o.chained.n = tmp.n; tmp.p = nullptr; tmp.n = 0;
+    hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p,
+                       o.u.p, o.n_ends.p, o.chained.p, o.n_chain.p, o.n_chained.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// download the chains of a batch and put each read's chains in ascending order of their first anchor
+// (minimap2 re-sorts them like this so that neighbouring chains can be joined)
+int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st) {
+    h.anchor_off.resize((size_t)n + 1);
+    h.n_chain.resize(n);
+    h.n_chained.resize(n);
+    h.rep_len.resize(n);
+    if (o.anchor_off.download(h.anchor_off.data(), (size_t)n + 1, st) || o.n_chain.download(h.n_chain.data(), n, st) ||
+        o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st))
+        return -1;
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    // gather only the used prefixes: u[0..n_chain) and chained[0..n_chained) of every read
+    h.chain_off.assign((size_t)n + 1, 0);
+    h.b_off.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) { h.chain_off[i + 1] = h.chain_off[i] + h.n_chain[i]; h.b_off[i + 1] = h.b_off[i] + h.n_chained[i]; }
+    h.u.resize((size_t)h.chain_off[n]);
+    h.b.resize((size_t)h.b_off[n]);
+    // one copy per read would be latency bound; copy everything when dense enough, else per read
+    const int64_t n_a = h.anchor_off[n];
+    std::vector<uint64_t> u_all;
+    std::vector<u128> b_all;
+    if (n_a > 0) {
+        u_all.resize((size_t)n_a);
+        b_all.resize((size_t)n_a);
+        if (o.u.download(u_all.data(), (size_t)n_a, st) || o.chained.download(b_all.data(), (size_t)n_a, st)) return -1;
+        MPN_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    for (int i = 0; i < n; ++i) {
+        const int nc = h.n_chain[i];
+        if (nc == 0) continue;
+        const uint64_t *u = &u_all[(size_t)h.anchor_off[i]];
+        const u128 *b = &b_all[(size_t)h.anchor_off[i]];
+        std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w(nc);
+        int64_t k = 0;
+        for (int c = 0; c < nc; ++c) { w[c] = {{b[k].x, (uint64_t)k << 32 | (uint32_t)c}, c}; k += (int32_t)u[c]; }
+        std::sort(w.begin(), w.end());
+        uint64_t *uo = &h.u[(size_t)h.chain_off[i]];
+        u128 *bo = &h.b[(size_t)h.b_off[i]];
+        int64_t kk = 0;
+        for (int c = 0; c < nc; ++c) {
+            const int j = w[c].second;
+            const int64_t start = (int64_t)(w[c].first.second >> 32);
+            const int32_t cnt = (int32_t)u[j];
+            uo[c] = u[j];
+            memcpy(bo + kk, b + start, (size_t)cnt * sizeof(u128));
+            kk += cnt;
+        }
+    }
+    return 0;
+}
+
+}  // namespace mpn
+
+using namespace mpn;
+
+extern "C" {
+
+void mpn_map_opt_init(mpn_map_opt *o) {
+    memset(o, 0, sizeof(*o));
+    o->k = 15; o->w = 10;
+    o->mid_occ_frac = 2e-4f;
+    o->min_cnt = 3; o->min_chain_score = 40; o->bw = 500; o->max_gap = 5000;
+    o->max_chain_skip = 25; o->max_chain_iter = 5000;
+    o->mask_level = 0.5f; o->pri_ratio = 0.8f; o->best_n = 5;
+    o->max_join_long = 20000; o->max_join_short = 2000; o->min_join_flank_sc = 1000; o->min_join_flank_ratio = 0.5f;
+    o->a = 2; o->b = 4; o->q = 4; o->e = 2; o->q2 = 24; o->e2 = 1;
+    o->sc_ambi = 1; o->zdrop = 400; o->zdrop_inv = 200; o->end_bonus = -1;
+    o->min_dp_max = o->min_chain_score * o->a;
+    o->min_ksw_len = 200;
+    o->max_clip_ratio = 1.0f;
+    o->max_sw_mat = 100000000;
+    o->with_cigar = 1;
+    o->seed = 11;
+    o->host_threads = 0;
+}
+
+mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
+                           int32_t k, int32_t w) {
+    if (n_seq <= 0 || k < 1 || k > 28 || w < 1 || w > 255) { set_error("mpn_index_build: bad arguments"); return nullptr; }
+    mpn_index *idx = new mpn_index();
+    idx->k = k; idx->w = w; idx->n_seq = n_seq;
+    hipStream_t st = 0;
+    std::vector<int64_t> off((size_t)n_seq + 1, 0);
+    for (int i = 0; i < n_seq; ++i) {
+        idx->names.push_back(names[i]);
+        idx->lens.push_back(lens[i]);
+        off[i + 1] = off[i] + lens[i];
+    }
+    idx->seq_off = off;
+    const int64_t total = off[n_seq];
+    // host copy of the targets as one code per base (the hit bookkeeping needs random access to them)
+    idx->seq4.resize((size_t)total);
+    std::vector<char> cat((size_t)total + 16);
+    for (int i = 0; i < n_seq; ++i) {
+        memcpy(cat.data() + off[i], seqs[i], (size_t)lens[i]);
+        for (int64_t j = 0; j < lens[i]; ++j) {
+            unsigned char c = (unsigned char)seqs[i][j] | 0x20;
+            idx->seq4[(size_t)(off[i] + j)] = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;
+        }
+    }
+    auto fail = [&]() { delete idx; return (mpn_index *)nullptr; };
+    DevBuf<uint8_t> d_seqs;
+    DevBuf<int64_t> d_off;
+    DevBuf<int32_t> d_len;
+    if (d_seqs.upload((const uint8_t *)cat.data(), (size_t)total + 16, st) || d_off.upload(off.data(), n_seq, st) ||
+        d_len.upload(lens, n_seq, st))
+        return fail();
+    // GPU sketch of every target, then (round 1) a host sort by (hash, position) and CSR build
+    DevBuf<int64_t> mz_off;
+    DevBuf<u128> mz;
+    int64_t n_mz = 0;
+    if (sketch_device(d_seqs.p, d_off.p, d_len.p, n_seq, k, w, 0, mz_off, mz, &n_mz, st)) return fail();
+    std::vector<u128> h((size_t)n_mz);
+    if (mz.download(h.data(), (size_t)n_mz, st)) return fail();
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: sync failed"); return fail(); }
+    for (auto &r : h) r.x >>= 8;
+    std::sort(h.begin(), h.end(), [](const u128 &a, const u128 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    std::vector<uint64_t> keys, pos((size_t)n_mz);
+    std::vector<int64_t> key_off;
+    for (int64_t i = 0; i < n_mz; ++i) {
+        if (i == 0 || h[i].x != h[i - 1].x) { keys.push_back(h[i].x); key_off.push_back(i); }
+        pos[(size_t)i] = h[i].y;
+    }
+    key_off.push_back(n_mz);
+    idx->n_keys = (int64_t)keys.size();
+    idx->n_mz = n_mz;
+    idx->h_key_off = key_off;
+    if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(key_off.data(), key_off.size(), st) ||
+        idx->pos.upload(pos.data(), pos.size(), st))
+        return fail();
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
+    return idx;
+}
+
+void mpn_index_destroy(mpn_index *idx) { delete idx; }
+int64_t mpn_index_n_minimizers(const mpn_index *idx) { return idx->n_mz; }
+int64_t mpn_index_n_keys(const mpn_index *idx) { return idx->n_keys; }
+
+int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
+    if (f <= 0.f) return INT32_MAX;
+    const int64_t n = idx->n_keys;
+    if (n == 0) return 1;
+    std::vector<uint32_t> a((size_t)n);
+    for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (uint32_t)(idx->h_key_off[(size_t)i + 1] - idx->h_key_off[(size_t)i]);
+    int64_t kk = (int64_t)(uint32_t)((1. - (double)f) * (double)n);
+    if (kk >= n) kk = n - 1;
+    std::nth_element(a.begin(), a.begin() + kk, a.end());
+    return (int32_t)(a[(size_t)kk] + 1);
+}
+
+int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uint64_t *pos) {
+    hipStream_t st = 0;
+    if (idx->keys.download(keys, (size_t)idx->n_keys, st) || idx->key_off.download(key_off, (size_t)idx->n_keys + 1, st) ||
+        idx->pos.download(pos, (size_t)idx->n_mz, st))
+        return -1;
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int64_t mpn_sketch_batch(int32_t n, const char *seqs, const int64_t *seq_off, const int32_t *seq_len, int32_t k, int32_t w,
+                         int64_t *mz_off, uint64_t *mz, int64_t cap) {
+    hipStream_t st = 0;
+    DevBuf<uint8_t> d_seqs;
+    DevBuf<int64_t> d_off, d_mz_off;
+    DevBuf<int32_t> d_len;
+    DevBuf<u128> d_mz;
+    int64_t bases = 0, n_mz = 0;
+    if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
+    if (sketch_device(d_seqs.p, d_off.p, d_len.p, n, k, w, 0, d_mz_off, d_mz, &n_mz, st)) return -1;
+    if (d_mz_off.download(mz_off, (size_t)n + 1, st)) return -1;
+    if (n_mz <= cap && d_mz.download((u128 *)mz, (size_t)n_mz, st)) return -1;
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    return n_mz <= cap ? n_mz : -3;
+}
+
+int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *seqs, const int64_t *seq_off,
+                         const int32_t *seq_len, int64_t *n_anchor, int32_t *rep_len, int64_t *chain_off, uint64_t *u,
+                         int64_t u_cap, int64_t *anchor_off, uint64_t *b, int64_t b_cap) {
+    hipStream_t st = 0;
+    memset(g_stats, 0, sizeof(g_stats));
+    DevBuf<uint8_t> d_seqs;
+    DevBuf<int64_t> d_off;
+    DevBuf<int32_t> d_len;
+    int64_t bases = 0;
+    if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
+    g_stats[0] = bases;
+    SeedChainOut o;
+    if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, o, st)) return -1;
+    HostChains h;
+    if (download_chains(n, o, h, st)) return -1;
+    for (int i = 0; i < n; ++i) { n_anchor[i] = h.anchor_off[i + 1] - h.anchor_off[i]; rep_len[i] = h.rep_len[i]; }
+    memcpy(chain_off, h.chain_off.data(), ((size_t)n + 1) * 8);
+    memcpy(anchor_off, h.b_off.data(), ((size_t)n + 1) * 8);
+    if ((int64_t)h.u.size() > u_cap || (int64_t)h.b.size() > b_cap) return -3;
+    if (!h.u.empty()) memcpy(u, h.u.data(), h.u.size() * 8);
+    if (!h.b.empty()) memcpy(b, h.b.data(), h.b.size() * 16);
+    return 0;
+}
+
+void mpn_map_last_stats(int64_t stats[8]) { memcpy(stats, g_stats, sizeof(g_stats)); }
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// Internal types shared by mapper.hip (seed + chain stages) and align.hip (base-level extension, hit bookkeeping).
+#pragma once
+#include "mpn_common.h"
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+struct mpn_map_opt_s;
+
+namespace mpn {
+struct u128;
+}
+
+struct mpn_index {
+    int k = 15, w = 10;
+    int32_t n_seq = 0;
+    std::vector<std::string> names;
+    std::vector<int32_t> lens;
+    std::vector<int64_t> seq_off;     // host: offset of each target in seq4
+    std::vector<uint8_t> seq4;        // host: one code per base
+    std::vector<int64_t> h_key_off;   // host copy (mid_occ quantile)
+    int64_t n_keys = 0, n_mz = 0;
+    mpn::DevBuf<uint64_t> keys, pos;
+    mpn::DevBuf<int64_t> key_off;
+    mpn::DevBuf<uint8_t> d_seq4;      // device: one code per base (extension kernel)
+    mpn::DevBuf<int64_t> d_seq_off;
+};
+
+namespace mpn {
+
+struct u128;
+
+struct SeedChainOut {
+    int64_t n_anchors = 0;
+    DevBuf<int64_t> anchor_off, n_chained;
+    DevBuf<int32_t> rep_len, n_ends, n_chain;
+    DevBuf<u128> anchors, chained;
+    DevBuf<uint64_t> u;
+};
+
+struct HostChains {
+    std::vector<int64_t> anchor_off, chain_off, b_off, n_chained;
+    std::vector<int32_t> n_chain, rep_len;
+    std::vector<uint64_t> u;
+    std::vector<u128> b;
+};
+
+extern thread_local int64_t g_stats[8];
+
+}  // namespace mpn

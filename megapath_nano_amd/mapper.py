@@ -1,0 +1,186 @@
+"""ctypes wrapper over include/mpn_map.h: index build, stage entry points and the batch mapper."""
+import ctypes as ct
+
+import numpy as np
+
+from . import _ffi
+
+
+class MapOpt(ct.Structure):
+    _fields_ = [('k', ct.c_int32), ('w', ct.c_int32), ('mid_occ_frac', ct.c_float), ('mid_occ', ct.c_int32),
+                ('max_gap', ct.c_int32), ('bw', ct.c_int32), ('max_chain_skip', ct.c_int32), ('max_chain_iter', ct.c_int32),
+                ('min_cnt', ct.c_int32), ('min_chain_score', ct.c_int32), ('mask_level', ct.c_float),
+                ('pri_ratio', ct.c_float), ('best_n', ct.c_int32), ('max_join_long', ct.c_int32),
+                ('max_join_short', ct.c_int32), ('min_join_flank_sc', ct.c_int32), ('min_join_flank_ratio', ct.c_float),
+                ('a', ct.c_int32), ('b', ct.c_int32), ('q', ct.c_int32), ('e', ct.c_int32), ('q2', ct.c_int32),
+                ('e2', ct.c_int32), ('sc_ambi', ct.c_int32), ('zdrop', ct.c_int32), ('zdrop_inv', ct.c_int32),
+                ('end_bonus', ct.c_int32), ('min_dp_max', ct.c_int32), ('min_ksw_len', ct.c_int32),
+                ('max_clip_ratio', ct.c_float), ('max_sw_mat', ct.c_int64), ('with_cigar', ct.c_int32),
+                ('seed', ct.c_uint32), ('host_threads', ct.c_int32)]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    lib = _ffi.lib()
+    if not _bound:
+        P = ct.c_void_p
+        lib.mpn_map_opt_init.argtypes = [ct.POINTER(MapOpt)]
+        lib.mpn_map_opt_init.restype = None
+        lib.mpn_index_build.argtypes = [ct.c_int32, ct.POINTER(ct.c_char_p), ct.POINTER(ct.c_char_p), P, ct.c_int32, ct.c_int32]
+        lib.mpn_index_build.restype = P
+        lib.mpn_index_destroy.argtypes = [P]
+        lib.mpn_index_destroy.restype = None
+        lib.mpn_index_n_minimizers.argtypes = [P]
+        lib.mpn_index_n_minimizers.restype = ct.c_int64
+        lib.mpn_index_n_keys.argtypes = [P]
+        lib.mpn_index_n_keys.restype = ct.c_int64
+        lib.mpn_index_mid_occ.argtypes = [P, ct.c_float]
+        lib.mpn_index_mid_occ.restype = ct.c_int32
+        lib.mpn_index_export.argtypes = [P, P, P, P]
+        lib.mpn_index_export.restype = ct.c_int
+        lib.mpn_sketch_batch.argtypes = [ct.c_int32, P, P, P, ct.c_int32, ct.c_int32, P, P, ct.c_int64]
+        lib.mpn_sketch_batch.restype = ct.c_int64
+        lib.mpn_seed_chain_batch.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, P, P, P, P, P, P, P, ct.c_int64, P, P, ct.c_int64]
+        lib.mpn_seed_chain_batch.restype = ct.c_int
+        if hasattr(lib, 'mpn_map_batch'):
+            lib.mpn_map_batch.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, ct.c_int64]
+            lib.mpn_map_batch.restype = ct.c_int64
+        lib.mpn_map_last_stats.argtypes = [P]
+        lib.mpn_map_last_stats.restype = None
+        _bound = True
+    return lib
+
+
+def default_opt(**kw):
+    o = MapOpt()
+    _bind().mpn_map_opt_init(ct.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def pack_seqs(seqs):
+    """list of bytes / uint8 arrays -> (concatenated uint8 buffer, offsets int64, lengths int32)"""
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    off = np.zeros(len(seqs), dtype=np.int64)
+    if len(seqs) > 1:
+        off[1:] = np.cumsum(lens[:-1].astype(np.int64))
+    total = int(lens.astype(np.int64).sum())
+    buf = np.zeros(total + 16, dtype=np.uint8)
+    for s, o in zip(seqs, off):
+        a = np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.asarray(s, dtype=np.uint8)
+        buf[o:o + len(a)] = a
+    return buf, off, lens
+
+
+class Index:
+    """Target sequences + minimizer index resident in HBM (mpn_index_build)."""
+
+    def __init__(self, genomes, k=15, w=10):
+        lib = _bind()
+        n = len(genomes)
+        self.names = [g[0] for g in genomes]
+        self._seqs = [bytes(g[1]) if not isinstance(g[1], bytes) else g[1] for g in genomes]
+        self.lens = np.array([len(s) for s in self._seqs], dtype=np.int32)
+        names = (ct.c_char_p * n)(*[x.encode() for x in self.names])
+        seqs = (ct.c_char_p * n)(*self._seqs)
+        self.k, self.w = k, w
+        self.h = lib.mpn_index_build(n, names, seqs, self.lens.ctypes.data, k, w)
+        if not self.h:
+            raise _ffi.MpnError('mpn_index_build failed: ' + _ffi.last_error())
+
+    @property
+    def n_minimizers(self):
+        return _bind().mpn_index_n_minimizers(self.h)
+
+    @property
+    def n_keys(self):
+        return _bind().mpn_index_n_keys(self.h)
+
+    def mid_occ(self, f=2e-4):
+        return _bind().mpn_index_mid_occ(self.h, f)
+
+    def export(self):
+        keys = np.zeros(self.n_keys, dtype=np.uint64)
+        key_off = np.zeros(self.n_keys + 1, dtype=np.int64)
+        pos = np.zeros(self.n_minimizers, dtype=np.uint64)
+        _ffi.check(_bind().mpn_index_export(self.h, keys.ctypes.data, key_off.ctypes.data, pos.ctypes.data), 'mpn_index_export')
+        return keys, key_off, pos
+
+    def close(self):
+        if self.h:
+            _bind().mpn_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sketch_batch(seqs, k=15, w=10):
+    """-> list of (n_i, 2) uint64 arrays, one per sequence"""
+    lib = _bind()
+    buf, off, lens = pack_seqs(seqs)
+    n = len(seqs)
+    mz_off = np.zeros(n + 1, dtype=np.int64)
+    cap = int(lens.astype(np.int64).sum()) + 16
+    mz = np.zeros((cap, 2), dtype=np.uint64)
+    r = lib.mpn_sketch_batch(n, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, k, w, mz_off.ctypes.data, mz.ctypes.data, cap)
+    if r < 0:
+        raise _ffi.MpnError(f'mpn_sketch_batch rc={r}: {_ffi.last_error()}')
+    return [mz[mz_off[i]:mz_off[i + 1]].copy() for i in range(n)]
+
+
+def seed_chain_batch(idx, opt, seqs):
+    """-> list of dict(n_anchor, rep_len, u (uint64[n_chain]), b ((n,2) uint64)) per read"""
+    lib = _bind()
+    buf, off, lens = pack_seqs(seqs)
+    n = len(seqs)
+    n_anchor = np.zeros(n, dtype=np.int64)
+    rep_len = np.zeros(n, dtype=np.int32)
+    chain_off = np.zeros(n + 1, dtype=np.int64)
+    anchor_off = np.zeros(n + 1, dtype=np.int64)
+    u_cap, b_cap = 1 << 16, 1 << 20
+    while True:
+        u = np.zeros(u_cap, dtype=np.uint64)
+        b = np.zeros((b_cap, 2), dtype=np.uint64)
+        rc = lib.mpn_seed_chain_batch(idx.h, ct.byref(opt), n, buf.ctypes.data, off.ctypes.data, lens.ctypes.data,
+                                      n_anchor.ctypes.data, rep_len.ctypes.data, chain_off.ctypes.data, u.ctypes.data, u_cap,
+                                      anchor_off.ctypes.data, b.ctypes.data, b_cap)
+        if rc == -3:
+            u_cap, b_cap = max(u_cap, int(chain_off[n]) + 1), max(b_cap, int(anchor_off[n]) + 1)
+            continue
+        _ffi.check(rc, 'mpn_seed_chain_batch')
+        break
+    return [dict(n_anchor=int(n_anchor[i]), rep_len=int(rep_len[i]), u=u[chain_off[i]:chain_off[i + 1]].copy(),
+                 b=b[anchor_off[i]:anchor_off[i + 1]].copy()) for i in range(n)]
+
+
+def map_batch(idx, opt, names, seqs):
+    """-> PAF text of the whole batch (reads in input order)"""
+    lib = _bind()
+    buf, off, lens = pack_seqs(seqs)
+    n = len(seqs)
+    cnames = (ct.c_char_p * n)(*[x.encode() for x in names])
+    cap = int(lens.astype(np.int64).sum()) * 4 + 4096 * n + 4096
+    while True:
+        out = ct.create_string_buffer(cap)
+        r = lib.mpn_map_batch(idx.h, ct.byref(opt), n, cnames, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, out, cap)
+        if r == -3:
+            cap *= 4
+            continue
+        if r < 0:
+            raise _ffi.MpnError(f'mpn_map_batch rc={r}: {_ffi.last_error()}')
+        return out.raw[:r].decode()
+
+
+def last_stats():
+    s = np.zeros(8, dtype=np.int64)
+    _bind().mpn_map_last_stats(s.ctypes.data)
+    return dict(bases=int(s[0]), minimizers=int(s[1]), anchors=int(s[2]), chain_evals=int(s[3]), dp_jobs=int(s[4]),
+                dp_cells=int(s[5]), alignments=int(s[6]), kernel_ns=int(s[7]))

@@ -1,0 +1,77 @@
+"""GPU parity tests (-m gpu) for the mapper's seed + chain stages against oracle/mm2_oracle.c (parity unpinned:
+the oracle restates minimap2 2.17, which the reference does not vendor).  Bit-exact on every integer output."""
+import numpy as np
+import pytest
+
+from map_cases import small_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def world(libmpn, oracle_built):
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads = small_world()
+    gidx = mapper.Index(gen)
+    oidx = mb.Index(gen)
+    yield gen, reads, gidx, oidx
+    gidx.close()
+    oidx.close()
+
+
+def test_sketch_matches_oracle(world):
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, _, _ = world
+    seqs = [r['seq'] for r in reads] + [gen[0][1][:50000], np.zeros(0, dtype=np.uint8)]
+    got = mapper.sketch_batch(seqs)
+    for i, s in enumerate(seqs):
+        want = mb.sketch(s, 10, 15, i)
+        assert np.array_equal(got[i], want), (i, len(s), len(got[i]), len(want))
+    # other (w,k)
+    got = mapper.sketch_batch(seqs[:6], k=19, w=5)
+    for i in range(6):
+        assert np.array_equal(got[i], mb.sketch(seqs[i], 5, 19, i))
+
+
+def test_index_matches_oracle(world):
+    import ctypes as ct
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    keys, key_off, pos = gidx.export()
+    # oracle index via its lookup function on every key
+    L = mb.lib()
+    L.mmo_idx_get.argtypes = [ct.c_void_p, ct.c_uint64, ct.POINTER(ct.POINTER(ct.c_uint64))]
+    L.mmo_idx_get.restype = ct.c_int64
+    assert len(keys) > 1000 and np.all(np.diff(keys.astype(np.int64)) > 0)
+    rng = np.random.default_rng(0)
+    for ki in rng.integers(0, len(keys), size=300):
+        p = ct.POINTER(ct.c_uint64)()
+        n = L.mmo_idx_get(oidx.h, int(keys[ki]), ct.byref(p))
+        assert n == key_off[ki + 1] - key_off[ki]
+        assert [p[j] for j in range(n)] == [int(x) for x in pos[key_off[ki]:key_off[ki + 1]]]
+    for f in (2e-4, 1e-2, 0.5):
+        assert gidx.mid_occ(f) == oidx.mid_occ(f)
+
+
+@pytest.mark.parametrize('mid_occ', [0, 3])
+def test_seed_chain_matches_oracle(world, mid_occ):
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    gopt = mapper.default_opt(mid_occ=mid_occ)
+    oopt = mb.default_opt(mid_occ=mid_occ)
+    occ = mid_occ if mid_occ > 0 else oidx.mid_occ()
+    got = mapper.seed_chain_batch(gidx, gopt, [r['seq'] for r in reads])
+    n_chains = 0
+    for r, g in zip(reads, got):
+        mv = mb.sketch(r['seq'], 10, 15, 0)
+        a, rep = mb.collect_anchors(oidx, occ, mv, len(r['seq']))
+        u, b = mb.chain(oopt, a)
+        assert g['n_anchor'] == len(a), r['name']
+        assert g['rep_len'] == rep, r['name']
+        assert np.array_equal(g['u'], u), r['name']
+        assert np.array_equal(g['b'], b), r['name']
+        n_chains += len(u)
+    assert n_chains > len(reads) // 2
