@@ -1,0 +1,969 @@
+// mpn_map_batch: chains -> hits -> base-level extension -> MAPQ -> PAF  (include/mpn_map.h).
+//
+// Device work: seed/chain kernels (map_kernels.h) and the extension kernels (ext_kernels.h).
+// Host work (this file, multi-threaded over reads): the per-read hit bookkeeping of minimap2's hit.c/align.c --
+// ranking chains, primary/secondary marking, long-join, planning the DP windows of every hit, stitching the
+// CIGARs the GPU returns, MAPQ (float logf, evaluated on the host so that it is libm-exact) and PAF text.
+// All DP windows of a batch are planned up front and run as independent GPU jobs (one wavefront each); a hit
+// whose alignment z-drops is split and its remainder goes through another round.
+#include "map_types.h"
+#include "ext_kernels.h"
+#include "mapper_internal.h"
+#include "../../include/mpn_map.h"
+
+#include <algorithm>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <thread>
+#include <atomic>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace mpn {
+
+int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32_t *seq_len, DevBuf<uint8_t> &d_seqs,
+                DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st);
+int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
+                      const int32_t *d_len, SeedChainOut &o, hipStream_t st);
+int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st);
+
+static const int PARENT_UNSET = -1, PARENT_TMP_PRI = -2;
+static const uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
+
+struct Reg {
+    int32_t id = 0, cnt = 0, rid = 0, score = 0, qs = 0, qe = 0, rs = 0, re = 0, parent = PARENT_UNSET, subsc = 0, as = 0;
+    int32_t mlen = 0, blen = 0, n_sub = 0, score0 = 0;
+    uint32_t mapq = 0, split = 0, rev = 0, inv = 0, sam_pri = 0, split_inv = 0, hash = 0;
+    int32_t has_p = 0, dp_score = 0, dp_max = 0, dp_max2 = 0, n_ambi = 0;
+    std::vector<uint32_t> cigar;
+    int32_t aligned = 0;  // base-level extension already done (or not needed)
+};
+
+static inline uint64_t hash64(uint64_t key) {
+    key = ~key + (key << 21);
+    key = key ^ key >> 24;
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ key >> 14;
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ key >> 28;
+    key = key + (key << 31);
+    return key;
+}
+static inline uint32_t wang32(uint32_t key) {
+    key += ~(key << 15); key ^= (key >> 10); key += (key << 3);
+    key ^= (key >> 6); key += ~(key << 11); key ^= (key >> 16);
+    return key;
+}
+static inline uint32_t x31_hash(const char *s) {
+    uint32_t h = (uint32_t)(unsigned char)*s;
+    if (h) for (++s; *s; ++s) h = (h << 5) - h + (uint32_t)(unsigned char)*s;
+    return h;
+}
+
+static void cal_fuzzy_len(Reg &r, const u128 *a) {
+    r.mlen = r.blen = 0;
+    if (r.cnt <= 0) return;
+    r.mlen = r.blen = a[r.as].y >> 32 & 0xff;
+    for (int i = r.as + 1; i < r.as + r.cnt; ++i) {
+        const int span = a[i].y >> 32 & 0xff;
+        const int tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        r.blen += tl > ql ? tl : ql;
+        r.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+    }
+}
+
+static void reg_set_coor(Reg &r, int32_t qlen, const u128 *a) {
+    const int32_t k = r.as, q_span = (int32_t)(a[k].y >> 32 & 0xff);
+    r.rev = a[k].x >> 63;
+    r.rid = a[k].x << 1 >> 33;
+    r.rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
+    r.re = (int32_t)a[k + r.cnt - 1].x + 1;
+    if (!r.rev) { r.qs = (int32_t)a[k].y + 1 - q_span; r.qe = (int32_t)a[k + r.cnt - 1].y + 1; }
+    else { r.qs = qlen - ((int32_t)a[k + r.cnt - 1].y + 1); r.qe = qlen - ((int32_t)a[k].y + 1 - q_span); }
+    cal_fuzzy_len(r, a);
+}
+
+static void gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const u128 *a, std::vector<Reg> &regs) {
+    struct Z { uint64_t x, y; };
+    std::vector<Z> z(n_u);
+    int k = 0;
+    for (int i = 0; i < n_u; ++i) {
+        const uint32_t h = (uint32_t)hash64((hash64(a[k].x) + hash64(a[k].y)) ^ hash);
+        z[i].x = u[i] ^ h;
+        z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
+        k += (int32_t)u[i];
+    }
+    std::sort(z.begin(), z.end(), [](const Z &p, const Z &q) { return p.x != q.x ? p.x < q.x : p.y < q.y; });
+    regs.assign(n_u, Reg());
+    for (int i = 0; i < n_u; ++i) {
+        Reg &ri = regs[i];
+        const Z &zi = z[n_u - 1 - i];
+        ri.id = i;
+        ri.parent = PARENT_UNSET;
+        ri.score = ri.score0 = (int32_t)(zi.x >> 32);
+        ri.hash = (uint32_t)zi.x;
+        ri.cnt = (int32_t)zi.y;
+        ri.as = (int32_t)(zi.y >> 32);
+        reg_set_coor(ri, qlen, a);
+    }
+}
+
+static void set_parent(float mask_level, std::vector<Reg> &r, int sub_diff) {
+    const int n = (int)r.size();
+    if (n <= 0) return;
+    for (int i = 0; i < n; ++i) r[i].id = i;
+    std::vector<uint64_t> cov(n);
+    std::vector<int> w(n);
+    w[0] = 0; r[0].parent = 0;
+    int k = 1;
+    for (int i = 1; i < n; ++i) {
+        Reg &ri = r[i];
+        const int si = ri.qs, ei = ri.qe;
+        int n_cov = 0, uncov_len = 0, j;
+        for (j = 0; j < k; ++j) {
+            const Reg &rp = r[w[j]];
+            int sj = rp.qs, ej = rp.qe;
+            if (ej <= si || sj >= ei) continue;
+            if (sj < si) sj = si;
+            if (ej > ei) ej = ei;
+            cov[n_cov++] = (uint64_t)sj << 32 | (uint32_t)ej;
+        }
+        if (n_cov > 0) {
+            int x = si;
+            std::sort(cov.begin(), cov.begin() + n_cov);
+            for (j = 0; j < n_cov; ++j) {
+                if ((int)(cov[j] >> 32) > x) uncov_len += (int)(cov[j] >> 32) - x;
+                x = (int32_t)cov[j] > x ? (int32_t)cov[j] : x;
+            }
+            if (ei > x) uncov_len += ei - x;
+            for (j = 0; j < k; ++j) {
+                Reg &rp = r[w[j]];
+                const int sj = rp.qs, ej = rp.qe;
+                if (ej <= si || sj >= ei) continue;
+                const int min = ej - sj < ei - si ? ej - sj : ei - si, max = ej - sj > ei - si ? ej - sj : ei - si;
+                const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+                if ((float)ol / min - (float)uncov_len / max > mask_level) {
+                    int cnt_sub = 0;
+                    ri.parent = rp.parent;
+                    rp.subsc = rp.subsc > ri.score ? rp.subsc : ri.score;
+                    if (ri.cnt >= rp.cnt) cnt_sub = 1;
+                    if (rp.has_p && ri.has_p && (rp.rid != ri.rid || rp.rs != ri.rs || rp.re != ri.re || ol != min)) {
+                        rp.dp_max2 = rp.dp_max2 > ri.dp_max ? rp.dp_max2 : ri.dp_max;
+                        if (rp.dp_max - ri.dp_max <= sub_diff) cnt_sub = 1;
+                    }
+                    if (cnt_sub) ++rp.n_sub;
+                    break;
+                }
+            }
+        } else j = k;
+        if (j == k) { w[k++] = i; ri.parent = i; ri.n_sub = 0; }
+    }
+}
+
+static void set_sam_pri(std::vector<Reg> &r) {
+    int n_pri = 0;
+    for (auto &x : r)
+        if (x.id == x.parent) { ++n_pri; x.sam_pri = (n_pri == 1); }
+        else x.sam_pri = 0;
+}
+
+static void sync_regs(std::vector<Reg> &regs) {
+    const int n_regs = (int)regs.size();
+    if (n_regs <= 0) return;
+    int max_id = -1;
+    for (auto &r : regs) max_id = max_id > r.id ? max_id : r.id;
+    std::vector<int> tmp(max_id + 1 > 0 ? max_id + 1 : 1, -1);
+    for (int i = 0; i < n_regs; ++i) if (regs[i].id >= 0) tmp[regs[i].id] = i;
+    for (int i = 0; i < n_regs; ++i) {
+        Reg &r = regs[i];
+        r.id = i;
+        if (r.parent == PARENT_TMP_PRI) r.parent = i;
+        else if (r.parent >= 0 && r.parent <= max_id && tmp[r.parent] >= 0) r.parent = tmp[r.parent];
+        else r.parent = PARENT_UNSET;
+    }
+    set_sam_pri(regs);
+}
+
+static void select_sub(float pri_ratio, int min_diff, int best_n, std::vector<Reg> &r) {
+    if (pri_ratio > 0.0f && !r.empty()) {
+        const int n = (int)r.size();
+        int k = 0, n_2nd = 0;
+        for (int i = 0; i < n; ++i) {
+            const int p = r[i].parent;
+            if (p == i || r[i].inv) { if (k != i) r[k] = r[i]; ++k; }
+            else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
+                if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) {
+                    if (k != i) r[k] = r[i];
+                    ++k; ++n_2nd;
+                }
+            }
+        }
+        // NB: r[p] above may already have been overwritten when p > k; minimap2 has the same in-place semantics
+        if (k != n) { r.resize(k); sync_regs(r); }
+    }
+}
+
+static void filter_regs(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs) {
+    int k = 0;
+    for (int i = 0; i < (int)regs.size(); ++i) {
+        Reg &r = regs[i];
+        int flt = 0;
+        if (!r.inv && r.cnt < opt->min_cnt) flt = 1;
+        if (r.has_p) {
+            if (r.mlen < opt->min_chain_score) flt = 1;
+            else if (r.dp_max < opt->min_dp_max) flt = 1;
+            else if (r.qs > qlen * opt->max_clip_ratio && qlen - r.qe > qlen * opt->max_clip_ratio) flt = 1;
+        }
+        if (!flt) { if (k < i) regs[k] = regs[i]; ++k; }
+    }
+    regs.resize(k);
+}
+
+static int squeeze_a(std::vector<Reg> &regs, u128 *a) {
+    const int n_regs = (int)regs.size();
+    std::vector<std::pair<uint64_t, int>> aux(n_regs);
+    for (int i = 0; i < n_regs; ++i) aux[i] = {(uint64_t)regs[i].as, i};
+    std::sort(aux.begin(), aux.end());
+    int as = 0;
+    for (int i = 0; i < n_regs; ++i) {
+        Reg &r = regs[aux[i].second];
+        if (r.as != as) { memmove(&a[as], &a[r.as], (size_t)r.cnt * 16); r.as = as; }
+        as += r.cnt;
+    }
+    return as;
+}
+
+static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, u128 *a) {
+    const int n_regs = (int)regs.size();
+    if (n_regs < 2) return;
+    squeeze_a(regs, a);
+    std::vector<std::pair<uint64_t, int>> aux;
+    for (int i = 0; i < n_regs; ++i)
+        if (regs[i].parent == i || regs[i].parent < 0) aux.push_back({(uint64_t)regs[i].as, i});
+    std::sort(aux.begin(), aux.end());
+    int n_drop = 0;
+    for (int i = (int)aux.size() - 1; i >= 1; --i) {
+        Reg &r0 = regs[aux[i - 1].second], &r1 = regs[aux[i].second];
+        if (r0.as + r0.cnt != r1.as) continue;
+        if (r0.rid != r1.rid || r0.rev != r1.rev) continue;
+        const u128 *a0e = &a[r0.as + r0.cnt - 1], *a1s = &a[r1.as];
+        if (a1s->x <= a0e->x || (int32_t)a1s->y <= (int32_t)a0e->y) continue;
+        int max_gap, min_gap;
+        max_gap = min_gap = (int32_t)a1s->y - (int32_t)a0e->y;
+        max_gap = max_gap > (int64_t)(a1s->x - a0e->x) ? max_gap : (int)(a1s->x - a0e->x);
+        min_gap = min_gap < (int64_t)(a1s->x - a0e->x) ? min_gap : (int)(a1s->x - a0e->x);
+        if (max_gap > opt->max_join_long || min_gap > opt->max_join_short) continue;
+        const int sc_thres = (int)((float)opt->min_join_flank_sc / opt->max_join_long * max_gap + .499);
+        if (r0.score < sc_thres || r1.score < sc_thres) continue;
+        const int min_flank_len = (int)(max_gap * opt->min_join_flank_ratio);
+        if (r0.re - r0.rs < min_flank_len || r0.qe - r0.qs < min_flank_len) continue;
+        if (r1.re - r1.rs < min_flank_len || r1.qe - r1.qs < min_flank_len) continue;
+        a[r1.as].y |= SEED_LONG_JOIN;
+        r0.cnt += r1.cnt; r0.score += r1.score;
+        reg_set_coor(r0, qlen, a);
+        r1.cnt = 0;
+        r1.parent = r0.id;
+        ++n_drop;
+    }
+    if (n_drop > 0) {
+        for (auto &r : regs)
+            if (r.parent >= 0 && r.id != r.parent)
+                if (regs[r.parent].parent >= 0 && regs[r.parent].parent != r.parent) r.parent = regs[r.parent].parent;
+        filter_regs(opt, qlen, regs);
+        sync_regs(regs);
+    }
+}
+
+static void hit_sort(std::vector<Reg> &r) {
+    const int n = (int)r.size();
+    if (n <= 1) return;
+    struct A { uint64_t x; int y; };
+    std::vector<A> aux;
+    for (int i = 0; i < n; ++i)
+        if (r[i].inv || r[i].cnt > 0) aux.push_back({(uint64_t)(uint32_t)(r[i].has_p ? r[i].dp_max : r[i].score) << 32 | r[i].hash, i});
+    std::sort(aux.begin(), aux.end(), [](const A &p, const A &q) { return p.x != q.x ? p.x < q.x : p.y < q.y; });
+    std::vector<Reg> t(aux.size());
+    for (int i = (int)aux.size() - 1; i >= 0; --i) t[aux.size() - 1 - i] = r[aux[i].y];
+    r.swap(t);
+}
+
+static void set_mapq(std::vector<Reg> &regs, int min_chain_sc, int match_sc, int rep_len) {
+    static const float q_coef = 40.0f;
+    if (regs.empty()) return;
+    int64_t sum_sc = 0;
+    for (auto &r : regs) if (r.parent == r.id) sum_sc += r.score;
+    const float uniq_ratio = (float)sum_sc / (sum_sc + rep_len);
+    for (auto &r : regs) {
+        if (r.inv) r.mapq = 0;
+        else if (r.parent == r.id) {
+            int mapq;
+            float pen_s1 = (r.score > 100 ? 1.0f : 0.01f * r.score) * uniq_ratio;
+            float pen_cm = r.cnt > 10 ? 1.0f : 0.1f * r.cnt;
+            pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+            const int subsc = r.subsc > min_chain_sc ? r.subsc : min_chain_sc;
+            if (r.has_p && r.dp_max2 > 0 && r.dp_max > 0) {
+                const float identity = (float)r.mlen / r.blen;
+                const float x = (float)r.dp_max2 * subsc / r.dp_max / r.score0;
+                mapq = (int)(identity * pen_cm * q_coef * (1.0f - x * x) * logf((float)r.dp_max / match_sc));
+                const int mapq_alt = (int)(6.02f * identity * identity * (r.dp_max - r.dp_max2) / match_sc + .499f);
+                mapq = mapq < mapq_alt ? mapq : mapq_alt;
+            } else {
+                const float x = (float)subsc / r.score0;
+                if (r.has_p) {
+                    const float identity = (float)r.mlen / r.blen;
+                    mapq = (int)(identity * pen_cm * q_coef * (1.0f - x) * logf((float)r.dp_max / match_sc));
+                } else mapq = (int)(pen_cm * q_coef * (1.0f - x) * logf(r.score));
+            }
+            mapq -= (int)(4.343f * logf(r.n_sub + 1) + .499f);
+            mapq = mapq > 0 ? mapq : 0;
+            r.mapq = mapq < 60 ? mapq : 60;
+            if (r.has_p && r.dp_max > r.dp_max2 && r.mapq == 0) r.mapq = 1;
+        } else r.mapq = 0;
+    }
+}
+
+static void split_reg(Reg &r, Reg &r2, int n, int qlen, const u128 *a) {
+    if (n <= 0 || n >= r.cnt) return;
+    r2 = r;
+    r2.id = -1;
+    r2.sam_pri = 0;
+    r2.has_p = 0; r2.cigar.clear(); r2.dp_score = r2.dp_max = r2.dp_max2 = r2.n_ambi = 0;
+    r2.split_inv = 0;
+    r2.aligned = 0;
+    r2.cnt = r.cnt - n;
+    r2.score = (int32_t)(r.score * ((float)r2.cnt / r.cnt) + .499);
+    r2.as = r.as + n;
+    if (r.parent == r.id) r2.parent = PARENT_TMP_PRI;
+    reg_set_coor(r2, qlen, a);
+    r.cnt -= r2.cnt;
+    r.score -= r2.score;
+    reg_set_coor(r, qlen, a);
+    r.split |= 1; r2.split |= 2;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// planning / stitching of one hit (minimap2 mm_align1 split in two around the GPU DP)
+struct Seg { int32_t qs, qe, rs, re, bw, anchor_i, job; };
+struct Plan {
+    int32_t as1 = 0, cnt1 = 0, rs = 0, qs = 0, re = 0, qe = 0, rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
+    int32_t left_job = -1, right_job = -1;
+    std::vector<Seg> segs;
+};
+
+static void fix_bad_ends(const Reg &r, const u128 *a, int bw, int min_match, int32_t *as, int32_t *cnt) {
+    *as = r.as; *cnt = r.cnt;
+    if (r.cnt < 3) return;
+    int32_t m, l;
+    m = l = a[r.as].y >> 32 & 0xff;
+    for (int i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
+        const int32_t q_span = a[i].y >> 32 & 0xff;
+        if (a[i].y & SEED_LONG_JOIN) break;
+        const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        const int32_t min = lr < lq ? lr : lq, max = lr > lq ? lr : lq;
+        if (max - min > l >> 1) *as = i;
+        l += min;
+        m += min < q_span ? min : q_span;
+        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+    }
+    *cnt = r.as + r.cnt - *as;
+    m = l = a[r.as + r.cnt - 1].y >> 32 & 0xff;
+    for (int i = r.as + r.cnt - 2; i > *as; --i) {
+        const int32_t q_span = a[i + 1].y >> 32 & 0xff;
+        if (a[i + 1].y & SEED_LONG_JOIN) break;
+        const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+        const int32_t min = lr < lq ? lr : lq, max = lr > lq ? lr : lq;
+        if (max - min > l >> 1) *cnt = i + 1 - *as;
+        l += min;
+        m += min < q_span ? min : q_span;
+        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+    }
+}
+
+static void filter_bad_seeds(int as1, int cnt1, u128 *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+    std::vector<int> K;
+    for (int i = 1; i < cnt1; ++i) {
+        const int gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - ((int32_t)a[as1 + i].x - (int32_t)a[as1 + i - 1].x);
+        if (gap < -min_gap || gap > min_gap) K.push_back(i);
+    }
+    const int n = (int)K.size();
+    if (n <= 1) return;
+    int max = 0, max_st = -1, max_en = -1;
+    for (int k = 0;; ++k) {
+        int gap, l, n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1;
+        if (k == n || k >= max_en) {
+            if (max_en > 0) for (int i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= SEED_IGNORE;
+            max = 0; max_st = max_en = -1;
+            if (k == n) break;
+        }
+        const int i = K[k];
+        gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - (int32_t)(a[as1 + i].x - a[as1 + i - 1].x);
+        if (gap > 0) n_ins += gap; else n_del += -gap;
+        const int qs = (int32_t)a[as1 + i - 1].y, rs = (int32_t)a[as1 + i - 1].x;
+        for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+            const int j = K[l];
+            if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
+            gap = ((int32_t)a[as1 + j].y - (int32_t)a[as1 + j - 1].y) - (int32_t)(a[as1 + j].x - a[as1 + j - 1].x);
+            if (gap > 0) n_ins += gap; else n_del += -gap;
+            const int diff = n_ins + n_del - abs(n_ins - n_del);
+            if (max_diff < diff) { max_diff = diff; max_diff_l = l; }
+        }
+        if (max_diff > diff_thres && max_diff > max) { max = max_diff; max_st = k; max_en = max_diff_l; }
+    }
+}
+
+struct JobSink {
+    std::vector<ExtJob> jobs;
+    int add(int read, int rid, int rev, int qs, int qlen, int ts, int tlen, int reversed, int w, int zdrop, int end_bonus, int flag) {
+        ExtJob j;
+        memset(&j, 0, sizeof(j));
+        j.read = read; j.rid = rid; j.rev = rev; j.qs = qs; j.qlen = qlen; j.ts = ts; j.tlen = tlen; j.reversed = reversed;
+        j.w = w; j.zdrop = zdrop; j.end_bonus = end_bonus; j.flag = flag;
+        jobs.push_back(j);
+        return (int)jobs.size() - 1;
+    }
+};
+
+static void plan_align(const mpn_map_opt *opt, const mpn_index *mi, int read, int qlen, Reg &r, int n_a, u128 *a, Plan &pl,
+                       JobSink &sink) {
+    const int32_t rid = a[r.as].x << 1 >> 33, rev = a[r.as].x >> 63;
+    const int32_t tlen_all = mi->lens[rid], kh = mi->k >> 1;
+    const int bw = (int)(opt->bw * 1.5 + 1.);
+    int32_t as1, cnt1, l, i;
+    fix_bad_ends(r, a, opt->bw, opt->min_chain_score * 2, &as1, &cnt1);
+    filter_bad_seeds(as1, cnt1, a, 10, 40, opt->max_gap >> 1, 10);
+    int32_t rs = (int32_t)a[as1].x - kh, qs = (int32_t)a[as1].y - kh;
+    int32_t re = (int32_t)a[as1 + cnt1 - 1].x - kh, qe = (int32_t)a[as1 + cnt1 - 1].y - kh;
+    int32_t rs0, qs0, re0, qe0, rs1 = 0, qs1 = 0, re1, qe1;
+    rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+    qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+    if (rs0 < 0) rs0 = 0;
+    for (i = r.as - 1, l = 0; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
+        const int32_t x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff), y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+        if (x < rs0 && y < qs0) {
+            if (++l > opt->min_cnt) {
+                l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+                rs1 = rs0 - l; qs1 = qs0 - l;
+                if (rs1 < 0) rs1 = 0;
+                break;
+            }
+        }
+    }
+    if (qs > 0 && rs > 0) {
+        l = qs < opt->max_gap ? qs : opt->max_gap;
+        qs1 = qs1 > qs - l ? qs1 : qs - l;
+        qs0 = qs0 < qs1 ? qs0 : qs1;
+        l += l * opt->a > opt->q ? (l * opt->a - opt->q) / opt->e : 0;
+        l = l < opt->max_gap ? l : opt->max_gap;
+        l = l < rs ? l : rs;
+        rs1 = rs1 > rs - l ? rs1 : rs - l;
+        rs0 = rs0 < rs1 ? rs0 : rs1;
+        rs0 = rs0 < rs ? rs0 : rs;
+    } else { rs0 = rs; qs0 = qs; }
+    re0 = (int32_t)a[r.as + r.cnt - 1].x + 1;
+    qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+    re1 = tlen_all; qe1 = qlen;
+    for (i = r.as + r.cnt, l = 0; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
+        const int32_t x = (int32_t)a[i].x + 1, y = (int32_t)a[i].y + 1;
+        if (x > re0 && y > qe0) {
+            if (++l > opt->min_cnt) {
+                l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+                re1 = re0 + l; qe1 = qe0 + l;
+                break;
+            }
+        }
+    }
+    if (qe < qlen && re < tlen_all) {
+        l = qlen - qe < opt->max_gap ? qlen - qe : opt->max_gap;
+        qe1 = qe1 < qe + l ? qe1 : qe + l;
+        qe0 = qe0 > qe1 ? qe0 : qe1;
+        l += l * opt->a > opt->q ? (l * opt->a - opt->q) / opt->e : 0;
+        l = l < opt->max_gap ? l : opt->max_gap;
+        l = l < tlen_all - re ? l : tlen_all - re;
+        re1 = re1 < re + l ? re1 : re + l;
+        re0 = re0 > re1 ? re0 : re1;
+    } else { re0 = re; qe0 = qe; }
+    pl.as1 = as1; pl.cnt1 = cnt1; pl.rs = rs; pl.qs = qs; pl.rs0 = rs0; pl.qs0 = qs0; pl.re0 = re0; pl.qe0 = qe0;
+    pl.segs.clear();
+    pl.left_job = pl.right_job = -1;
+    const int maxsw = opt->max_sw_mat > 0;
+    auto too_big = [&](int ql, int tl) { return maxsw && (int64_t)tl * ql > opt->max_sw_mat; };
+    if (qs > 0 && rs > 0 && !too_big(qs - qs0, rs - rs0))
+        pl.left_job = sink.add(read, rid, rev, qs0, qs - qs0, rs0, rs - rs0, 1, bw, r.split_inv ? opt->zdrop_inv : opt->zdrop,
+                               opt->end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR);
+    for (i = 1; i < cnt1; ++i) {
+        if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+        re = (int32_t)a[as1 + i].x - kh; qe = (int32_t)a[as1 + i].y - kh;
+        if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt->min_ksw_len && re - rs >= opt->min_ksw_len)) {
+            int bw1 = bw;
+            if (a[as1 + i].y & SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+            Seg s;
+            s.qs = qs; s.qe = qe; s.rs = rs; s.re = re; s.bw = bw1; s.anchor_i = i; s.job = -1;
+            if (!too_big(qe - qs, re - rs) && qe - qs > 0 && re - rs > 0)
+                s.job = sink.add(read, rid, rev, qs, qe - qs, rs, re - rs, 0, bw1, opt->zdrop, -1, EZ_APPROX_MAX);
+            pl.segs.push_back(s);
+            rs = re; qs = qe;
+        }
+    }
+    pl.re = re; pl.qe = qe;
+    if (qe < qe0 && re < re0 && !too_big(qe0 - qe, re0 - re))
+        pl.right_job = sink.add(read, rid, rev, qe, qe0 - qe, re, re0 - re, 0, bw, opt->zdrop, opt->end_bonus, EZ_EXTZ_ONLY);
+}
+
+struct JobOut { const ExtRes *res; const uint32_t *cig; };
+
+static void append_cigar(Reg &r, int n_cigar, const uint32_t *cigar) {
+    if (n_cigar == 0) return;
+    r.has_p = 1;
+    if (!r.cigar.empty() && (r.cigar.back() & 0xf) == (cigar[0] & 0xf)) {
+        r.cigar.back() += (cigar[0] >> 4) << 4;
+        r.cigar.insert(r.cigar.end(), cigar + 1, cigar + n_cigar);
+    } else r.cigar.insert(r.cigar.end(), cigar, cigar + n_cigar);
+}
+
+static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift) {
+    int32_t toff = 0, qoff = 0, to_shrink = 0;
+    *qshift = *tshift = 0;
+    int n_cigar = (int)r.cigar.size();
+    uint32_t *cigar = r.cigar.data();
+    if (n_cigar <= 1) return;
+    for (int k = 0; k < n_cigar; ++k) {
+        const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+        if (len == 0) to_shrink = 1;
+        if (op == 0) { toff += len; qoff += len; }
+        else if (op == 1 || op == 2) {
+            if (k > 0 && k < n_cigar - 1 && (cigar[k - 1] & 0xf) == 0 && (cigar[k + 1] & 0xf) == 0) {
+                int l;
+                const int prev_len = cigar[k - 1] >> 4;
+                if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
+                else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
+                if (l > 0) { cigar[k - 1] -= l << 4; cigar[k + 1] += l << 4; qoff -= l; toff -= l; }
+                if (l == prev_len) to_shrink = 1;
+            }
+            if (op == 1) qoff += len; else toff += len;
+        }
+    }
+    for (int k = 0; k < n_cigar - 2; ++k) {
+        if ((cigar[k] & 0xf) > 0 && (cigar[k] & 0xf) + (cigar[k + 1] & 0xf) == 3) {
+            uint32_t l, s[3] = {0, 0, 0};
+            for (l = k; l < (uint32_t)n_cigar; ++l) {
+                const uint32_t op = cigar[l] & 0xf;
+                if (op == 1 || op == 2 || cigar[l] >> 4 == 0) s[op] += cigar[l] >> 4;
+                else break;
+            }
+            if (s[1] > 0 && s[2] > 0 && l - k > 2) {
+                cigar[k] = s[1] << 4 | 1;
+                cigar[k + 1] = s[2] << 4 | 2;
+                for (k += 2; k < (int)l; ++k) cigar[k] &= 0xf;
+                to_shrink = 1;
+            }
+            k = l;
+        }
+    }
+    if (to_shrink) {
+        int32_t l = 0;
+        for (int k = 0; k < n_cigar; ++k) if (cigar[k] >> 4 != 0) cigar[l++] = cigar[k];
+        n_cigar = l;
+        l = 0;
+        for (int k = 0; k < n_cigar; ++k)
+            if (k == n_cigar - 1 || (cigar[k] & 0xf) != (cigar[k + 1] & 0xf)) cigar[l++] = cigar[k];
+            else cigar[k + 1] += cigar[k] >> 4 << 4;
+        n_cigar = l;
+    }
+    if ((cigar[0] & 0xf) == 1 || (cigar[0] & 0xf) == 2) {
+        const int32_t l = cigar[0] >> 4;
+        if ((cigar[0] & 0xf) == 1) { if (r.rev) r.qe -= l; else r.qs += l; *qshift = l; }
+        else { r.rs += l; *tshift = l; }
+        --n_cigar;
+        memmove(cigar, cigar + 1, (size_t)n_cigar * 4);
+    }
+    r.cigar.resize(n_cigar);
+}
+
+static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e) {
+    if (!r.has_p) return;
+    int qshift, tshift;
+    int32_t s = 0, max = 0, toff = 0, qoff = 0;
+    fix_cigar(r, qseq, tseq, &qshift, &tshift);
+    qseq += qshift; tseq += tshift;
+    r.blen = r.mlen = 0;
+    for (size_t k = 0; k < r.cigar.size(); ++k) {
+        const uint32_t op = r.cigar[k] & 0xf, len = r.cigar[k] >> 4;
+        if (op == 0) {
+            int n_ambi = 0, n_diff = 0;
+            for (uint32_t l = 0; l < len; ++l) {
+                const int cq = qseq[qoff + l], ct = tseq[toff + l];
+                if (ct > 3 || cq > 3) ++n_ambi;
+                else if (ct != cq) ++n_diff;
+                s += mat[ct * 5 + cq];
+                if (s < 0) s = 0; else max = max > s ? max : s;
+            }
+            r.blen += len - n_ambi; r.mlen += len - (n_ambi + n_diff); r.n_ambi += n_ambi;
+            toff += len; qoff += len;
+        } else if (op == 1) {
+            int n_ambi = 0;
+            for (uint32_t l = 0; l < len; ++l) if (qseq[qoff + l] > 3) ++n_ambi;
+            r.blen += len - n_ambi; r.n_ambi += n_ambi;
+            s -= q + e * len;
+            if (s < 0) s = 0;
+            qoff += len;
+        } else if (op == 2) {
+            int n_ambi = 0;
+            for (uint32_t l = 0; l < len; ++l) if (tseq[toff + l] > 3) ++n_ambi;
+            r.blen += len - n_ambi; r.n_ambi += n_ambi;
+            s -= q + e * len;
+            if (s < 0) s = 0;
+            toff += len;
+        }
+    }
+    r.dp_max = max;
+}
+
+// returns true if a split remainder was produced in r2
+static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, const uint8_t *qseq_strand[2], Reg &r, Reg &r2,
+                         const u128 *a, const Plan &pl, const std::vector<ExtRes> &res, const std::vector<ExtJob> &jobs,
+                         const uint32_t *cig_pool) {
+    const int32_t rid = a[r.as].x << 1 >> 33, rev = a[r.as].x >> 63;
+    int8_t mat[25];
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = i == j ? opt->a : -opt->b; mat[i * 5 + 4] = -opt->sc_ambi; }
+    for (int i = 0; i < 5; ++i) mat[20 + i] = -opt->sc_ambi;
+    auto cig_of = [&](int job, int *n) -> const uint32_t * {
+        const ExtRes &e = res[job];
+        const ExtJob &j = jobs[job];
+        *n = e.n_cigar;
+        if (j.flag & EZ_REV_CIGAR) return cig_pool + (j.cig_off - (j.qlen + j.tlen + 2));
+        return cig_pool + (j.cig_off - e.n_cigar);
+    };
+    bool has_r2 = false;
+    int32_t rs = pl.rs, qs = pl.qs, rs1, qs1, re1, qe1, dropped = 0;
+    r2.cnt = 0;
+    if (qs > 0 && rs > 0) {
+        ExtRes ez;
+        memset(&ez, 0, sizeof(ez));
+        ez.max_q = ez.max_t = ez.mqe_t = -1;
+        int nc = 0;
+        const uint32_t *cg = nullptr;
+        if (pl.left_job >= 0) { ez = res[pl.left_job]; cg = cig_of(pl.left_job, &nc); }
+        else ez.zdropped = 1;  // refused by max_sw_mat
+        if (nc > 0) { append_cigar(r, nc, cg); r.dp_score += ez.max; }
+        rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+        qs1 = qs - (ez.reach_end ? qs - pl.qs0 : ez.max_q + 1);
+    } else { rs1 = rs; qs1 = qs; }
+    re1 = rs; qe1 = qs;
+    for (size_t si = 0; si < pl.segs.size(); ++si) {
+        const Seg &s = pl.segs[si];
+        re1 = s.re; qe1 = s.qe;
+        ExtRes ez;
+        memset(&ez, 0, sizeof(ez));
+        ez.max_q = ez.max_t = -1;
+        int nc = 0;
+        const uint32_t *cg = nullptr;
+        if (s.job >= 0) { ez = res[s.job]; cg = cig_of(s.job, &nc); }
+        else ez.zdropped = 1;
+        if (nc > 0) append_cigar(r, nc, cg);
+        if (ez.zdropped) {
+            r.has_p = 1;
+            int j;
+            for (j = s.anchor_i - 1; j >= 0; --j) if ((int32_t)a[pl.as1 + j].x <= s.rs + ez.max_t) break;
+            dropped = 1;
+            if (j < 0) j = 0;
+            r.dp_score += ez.max;
+            re1 = s.rs + (ez.max_t + 1);
+            qe1 = s.qs + (ez.max_q + 1);
+            if (pl.cnt1 - (j + 1) >= opt->min_cnt) {
+                const int old_cnt = r.cnt;
+                split_reg(r, r2, pl.as1 + j + 1 - r.as, qlen, a);
+                has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
+            }
+            break;
+        } else r.dp_score += ez.score;
+    }
+    if (!dropped && pl.qe < pl.qe0 && pl.re < pl.re0) {
+        ExtRes ez;
+        memset(&ez, 0, sizeof(ez));
+        ez.max_q = ez.max_t = ez.mqe_t = -1;
+        int nc = 0;
+        const uint32_t *cg = nullptr;
+        if (pl.right_job >= 0) { ez = res[pl.right_job]; cg = cig_of(pl.right_job, &nc); }
+        else ez.zdropped = 1;
+        if (nc > 0) { append_cigar(r, nc, cg); r.dp_score += ez.max; }
+        re1 = pl.re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+        qe1 = pl.qe + (ez.reach_end ? pl.qe0 - pl.qe : ez.max_q + 1);
+    }
+    r.rs = rs1; r.re = re1;
+    if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; }
+    else { r.qs = qs1; r.qe = qe1; }
+    if (r.has_p) update_extra(r, qseq_strand[rev] + qs1, mi->seq4.data() + mi->seq_off[rid] + rs1, mat, (int8_t)opt->q, (int8_t)opt->e);
+    r.aligned = 1;
+    return has_r2;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn) {
+    if (n_threads <= 1 || n < 2) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() { for (;;) { int i = next.fetch_add(1); if (i >= n) break; fn(i, t); } });
+    for (auto &x : th) x.join();
+}
+
+struct ReadState {
+    std::vector<Reg> regs;
+    std::vector<u128> a;   // chained anchors (squeezed)
+    int n_a = 0;
+    std::vector<uint8_t> q4[2];
+    std::vector<Plan> plans;  // per reg (only for regs being aligned this round)
+    std::vector<int> pending; // reg indices aligned this round
+};
+
+static double event_identity(const Reg &r) {
+    int32_t n_gapo = 0, n_gap = 0;
+    for (uint32_t c : r.cigar) { const int32_t op = c & 0xf, len = c >> 4; if (op == 1 || op == 2) { ++n_gapo; n_gap += len; } }
+    return (double)r.mlen / (r.blen + r.n_ambi - n_gap + n_gapo);
+}
+
+static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *name, int32_t qlen, const std::vector<Reg> &regs,
+                      int32_t rep_len, std::string &out) {
+    char buf[1024];
+    for (const Reg &r : regs) {
+        const int type = r.id == r.parent ? (r.inv ? 'I' : 'P') : (r.inv ? 'i' : 'S');
+        out += name;
+        snprintf(buf, sizeof(buf), "\t%d\t%d\t%d\t%c\t", qlen, r.qs, r.qe, "+-"[r.rev]);
+        out += buf;
+        out += mi->names[r.rid];
+        snprintf(buf, sizeof(buf), "\t%d\t%d\t%d\t%d\t%d\t%d", mi->lens[r.rid], r.rs, r.re, r.mlen, r.blen, r.mapq);
+        out += buf;
+        if (r.has_p) {
+            snprintf(buf, sizeof(buf), "\tNM:i:%d\tms:i:%d\tAS:i:%d\tnn:i:%d", r.blen - r.mlen + r.n_ambi, r.dp_max, r.dp_score, r.n_ambi);
+            out += buf;
+        }
+        snprintf(buf, sizeof(buf), "\ttp:A:%c\tcm:i:%d\ts1:i:%d", type, r.cnt, r.score);
+        out += buf;
+        if (r.parent == r.id) { snprintf(buf, sizeof(buf), "\ts2:i:%d", r.subsc); out += buf; }
+        if (r.has_p) {
+            const double div = 1.0 - event_identity(r);
+            if (div == 0.0) out += "\tde:f:0";
+            else { snprintf(buf, sizeof(buf), "\tde:f:%.4f", div); out += buf; }
+        }
+        if (r.split) { snprintf(buf, sizeof(buf), "\tzd:i:%d", r.split); out += buf; }
+        snprintf(buf, sizeof(buf), "\trl:i:%d", rep_len);
+        out += buf;
+        if (r.has_p && o->with_cigar) {
+            out += "\tcg:Z:";
+            for (uint32_t c : r.cigar) { snprintf(buf, sizeof(buf), "%d%c", c >> 4, "MIDNSH"[c & 0xf]); out += buf; }
+        }
+        out += '\n';
+    }
+}
+
+// run all DP jobs of one round on the GPU
+static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<ExtJob> &jobs, const uint8_t *d_reads,
+                    const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res, std::vector<uint32_t> &cig,
+                    hipStream_t st) {
+    const int nj = (int)jobs.size();
+    res.assign(nj, ExtRes());
+    if (nj == 0) return 0;
+    // scratch layout + size classes (LDS need)
+    int64_t p_tot = 0, row_tot = 0, cig_tot = 0, state_tot = 0;
+    std::vector<int32_t> order[5];
+    const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
+    size_t lds_need_max[5] = {0, 0, 0, 0, 0};
+    int64_t cells = 0;
+    for (int j = 0; j < nj; ++j) {
+        ExtJob &jb = jobs[j];
+        int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
+        int n_col = std::min(jb.qlen, jb.tlen);
+        n_col = std::min(n_col, w + 1) + 1;
+        jb.n_col = n_col;
+        const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
+        jb.p_off = p_tot; p_tot += n_r * n_col;
+        jb.row_off = row_tot; row_tot += n_r;
+        cig_tot += jb.qlen + jb.tlen + 2; jb.cig_off = cig_tot;
+        cells += n_r * n_col;
+        const size_t seqb = (size_t)((jb.qlen + 3) & ~3) + (size_t)((jb.tlen + 3) & ~3);
+        const size_t stateb = (size_t)(((size_t)6 * jb.tlen + 3) & ~(size_t)3) + (size_t)4 * jb.tlen;
+        int cls = 4;
+        for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
+        if (cls == 4) {
+            if (seqb > lds_cap[3]) { set_error("DP window too large for LDS staging (%d x %d)", jb.qlen, jb.tlen); return -4; }
+            jb.state_mode = 1; jb.state_off = state_tot; state_tot += (int64_t)((stateb + 15) & ~(size_t)15);
+            lds_need_max[4] = std::max(lds_need_max[4], seqb);
+        } else { jb.state_mode = 0; lds_need_max[cls] = std::max(lds_need_max[cls], seqb + stateb); }
+        order[cls].push_back(j);
+    }
+    g_stats[4] += nj; g_stats[5] += cells;
+    DevBuf<ExtJob> d_jobs;
+    DevBuf<uint8_t> P;
+    DevBuf<int32_t> OFF, d_order;
+    DevBuf<int8_t> gstate;
+    DevBuf<uint32_t> CIG;
+    DevBuf<ExtRes> d_res;
+    std::vector<int32_t> flat;
+    int base[5];
+    for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
+    if (d_jobs.upload(jobs.data(), nj, st) || P.alloc((size_t)p_tot) || OFF.alloc((size_t)row_tot * 2) || gstate.alloc((size_t)state_tot) ||
+        CIG.alloc((size_t)cig_tot) || d_res.alloc(nj) || d_order.upload(flat.data(), flat.size(), st))
+        return -1;
+    ExtParams prm;
+    prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
+    prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
+    auto launch_dp = [&](const int32_t *ord, int cnt, size_t lds) -> int {
+        if (cnt == 0) return 0;
+        if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ext_dp_kernel, dim3(cnt), dim3(64), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len,
+                           idx->d_seq4.p, idx->d_seq_off.p, P.p, OFF.p, gstate.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        return 0;
+    };
+    for (int c = 0; c < 5; ++c)
+        if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+    hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_res.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    // z-drop test of the gap-fill CIGARs; flagged jobs are recomputed with the exact maximum
+    std::vector<int32_t> gap;
+    for (int j = 0; j < nj; ++j) if ((jobs[j].flag & EZ_APPROX_MAX)) gap.push_back(j);
+    if (!gap.empty()) {
+        DevBuf<int32_t> d_gap;
+        if (d_gap.upload(gap.data(), gap.size(), st)) return -1;
+        hipLaunchKernelGGL(ext_ztest_kernel, dim3(((int)gap.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_gap.p, (int)gap.size(), prm,
+                           d_reads, d_read_off, d_read_len, idx->d_seq4.p, idx->d_seq_off.p, CIG.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        if (d_res.download(res.data(), nj, st)) return -1;
+        MPN_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<int32_t> redo[5];
+        std::vector<int32_t> redo_flat;
+        for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; }
+        for (int c = 0; c < 5; ++c) for (int j : order[c]) if ((res[j].zcode) && !(jobs[j].flag & EZ_APPROX_MAX) && !(jobs[j].flag & EZ_EXTZ_ONLY)) redo[c].push_back(j);
+        int rbase[5];
+        for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }
+        if (!redo_flat.empty()) {
+            DevBuf<int32_t> d_redo;
+            if (d_jobs.upload(jobs.data(), nj, st) || d_redo.upload(redo_flat.data(), redo_flat.size(), st)) return -1;
+            for (int c = 0; c < 5; ++c)
+                if (launch_dp(d_redo.p + rbase[c], (int)redo[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+            hipLaunchKernelGGL(ext_bt_kernel, dim3(((int)redo_flat.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p,
+                               (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_res.p);
+            MPN_HIP_CHECK(hipGetLastError());
+        }
+    }
+    cig.resize((size_t)cig_tot);
+    if (d_res.download(res.data(), nj, st) || CIG.download(cig.data(), (size_t)cig_tot, st)) return -1;
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace mpn
+
+using namespace mpn;
+
+extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                                 const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap) {
+    hipStream_t st = 0;
+    memset(g_stats, 0, sizeof(g_stats));
+    if (n <= 0) { if (paf_cap > 0) paf[0] = 0; return 0; }
+    DevBuf<uint8_t> d_seqs;
+    DevBuf<int64_t> d_off;
+    DevBuf<int32_t> d_len;
+    int64_t bases = 0;
+    if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
+    g_stats[0] = bases;
+    HostChains h;
+    {
+        SeedChainOut o;
+        if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, o, st)) return -1;
+        if (download_chains(n, o, h, st)) return -1;
+    }
+    int n_threads = opt->host_threads > 0 ? opt->host_threads : (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    std::vector<ReadState> rs(n);
+    // hits from chains
+    parallel_for(n, n_threads, [&](int i, int) {
+        ReadState &S = rs[i];
+        const int nc = h.n_chain[i];
+        if (nc == 0) return;
+        const int qlen = seq_len[i];
+        S.a.assign(h.b.begin() + h.b_off[i], h.b.begin() + h.b_off[i + 1]);
+        uint32_t hash = names && names[i] ? x31_hash(names[i]) : 0;
+        hash ^= wang32((uint32_t)qlen) + wang32(opt->seed);
+        hash = wang32(hash);
+        gen_regs(hash, qlen, nc, &h.u[h.chain_off[i]], S.a.data(), S.regs);
+        set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
+        select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
+        join_long(opt, qlen, S.regs, S.a.data());
+        if (opt->with_cigar) {
+            S.n_a = squeeze_a(S.regs, S.a.data());
+            const char *s = seqs + seq_off[i];
+            S.q4[0].resize(qlen); S.q4[1].resize(qlen);
+            for (int j = 0; j < qlen; ++j) {
+                unsigned char c = (unsigned char)s[j] | 0x20;
+                const uint8_t code = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;
+                S.q4[0][j] = code;
+                S.q4[1][qlen - 1 - j] = code < 4 ? 3 - code : 4;
+            }
+        }
+    });
+    if (opt->with_cigar) {
+        for (int round = 0; round < 64; ++round) {
+            // plan (serial append into one job list keeps job ids deterministic)
+            JobSink sink;
+            bool any = false;
+            for (int i = 0; i < n; ++i) {
+                ReadState &S = rs[i];
+                S.pending.clear(); S.plans.clear();
+                for (int k = 0; k < (int)S.regs.size(); ++k) {
+                    Reg &r = S.regs[k];
+                    if (r.aligned) continue;
+                    if (r.cnt == 0) { r.aligned = 1; continue; }
+                    S.pending.push_back(k);
+                    S.plans.emplace_back();
+                    plan_align(opt, idx, i, seq_len[i], r, S.n_a, S.a.data(), S.plans.back(), sink);
+                    any = true;
+                }
+            }
+            if (!any) break;
+            std::vector<ExtRes> res;
+            std::vector<uint32_t> cig;
+            if (run_jobs(idx, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
+            parallel_for(n, n_threads, [&](int i, int) {
+                ReadState &S = rs[i];
+                if (S.pending.empty()) return;
+                const uint8_t *q2[2] = {S.q4[0].data(), S.q4[1].data()};
+                int shift = 0;
+                for (size_t pi = 0; pi < S.pending.size(); ++pi) {
+                    const int k = S.pending[pi] + shift;
+                    Reg r2;
+                    const bool has = stitch_align(opt, idx, seq_len[i], q2, S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs, cig.data());
+                    if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
+                }
+            });
+        }
+    }
+    // rank, MAPQ, text
+    std::vector<std::string> lines(n);
+    std::atomic<int64_t> n_aln(0);
+    parallel_for(n, n_threads, [&](int i, int) {
+        ReadState &S = rs[i];
+        if (S.regs.empty()) return;
+        const int qlen = seq_len[i];
+        if (opt->with_cigar) {
+            filter_regs(opt, qlen, S.regs);
+            hit_sort(S.regs);
+            set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
+            select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
+            set_sam_pri(S.regs);
+        }
+        set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
+        write_paf(idx, opt, names && names[i] ? names[i] : "*", qlen, S.regs, h.rep_len[i], lines[i]);
+        n_aln += (int64_t)S.regs.size();
+    });
+    g_stats[6] = n_aln;
+    int64_t tot = 0;
+    for (auto &l : lines) tot += (int64_t)l.size();
+    if (tot + 1 > paf_cap) return -3;
+    int64_t w = 0;
+    for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
+    paf[w] = 0;
+    return w;
+}

@@ -1,0 +1,319 @@
+// Base-level extension kernels (gfx950): banded dual-affine-gap DP with z-drop on anti-diagonals
+// (the ksw2 formulation minimap2 uses for `-c`), traceback, and the z-drop test of a finished CIGAR.
+//
+// One wavefront per DP job.  Anti-diagonal r is processed 64 cells (target positions t) at a time across the
+// lanes; the Suzuki-Kasahara difference states u,v,x,y,x2,y2 (one int8 per target position) and the 32-bit H row
+// live in LDS next to the staged query/target windows; the left neighbour (t-1) of the previous anti-diagonal
+// arrives by DPP wave_shr (lane 0 takes the carry of the previous tile).  Direction codes (1 B/cell) stream to an
+// HBM scratch in coalesced 64-byte rows.  Integer VALU + LDS work: no MFMA.
+// Traceback is latency bound and serial per job, so it runs in a second kernel with one LANE per job.
+#pragma once
+#include "mpn_common.h"
+#include "map_types.h"
+
+namespace mpn {
+
+enum { EZ_APPROX_MAX = 0x02, EZ_RIGHT = 0x08, EZ_EXTZ_ONLY = 0x40, EZ_REV_CIGAR = 0x80 };
+
+struct ExtJob {
+    int32_t read;        // read index in the batch
+    int32_t rid;         // target sequence
+    int32_t rev;         // hit strand
+    int32_t qs, qlen;    // query window [qs, qs+qlen) in strand coordinates
+    int32_t ts, tlen;    // target window
+    int32_t reversed;    // 1: both windows are read back to front (left extension)
+    int32_t w, zdrop, end_bonus, flag;
+    int64_t p_off;       // direction scratch offset
+    int64_t row_off;     // anti-diagonal row offset (band start/end scratch)
+    int64_t cig_off;     // cigar scratch END offset (ops are written back to front unless REV_CIGAR)
+    int32_t n_col;
+    int32_t state_mode;  // 0: state arrays in LDS, 1: in global scratch
+    int64_t state_off;
+};
+
+struct ExtRes {
+    int32_t max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar, r_done, bt_i, bt_j, do_bt, zcode;
+};
+
+struct ExtParams {
+    int8_t sc_mch, sc_mis, sc_n, q, e, q2, e2;
+    int32_t zdrop_thres;  // opt->zdrop for the path test
+};
+
+__device__ __forceinline__ uint8_t ext_qbase(const uint8_t *__restrict__ reads, int64_t roff, int32_t rlen, int rev, int x) {
+    // base x of the read on the hit's strand, as a 0..4 code
+    if (!rev) return (uint8_t)nt4_code(reads[roff + x]);
+    const int c = nt4_code(reads[roff + (rlen - 1 - x)]);
+    return (uint8_t)(c < 4 ? 3 - c : 4);
+}
+
+struct ExtApply {  // running z-drop state (ksw_extz_t subset)
+    int32_t max, max_t, max_q, zdropped;
+};
+
+__device__ __forceinline__ bool ext_apply_zdrop(ExtApply &ez, int32_t H, int r, int t, int zdrop, int e) {
+    if (H > ez.max) { ez.max = H; ez.max_t = t; ez.max_q = r - t; }
+    else if (t >= ez.max_t && r - t >= ez.max_q) {
+        const int tl = t - ez.max_t, ql = (r - t) - ez.max_q;
+        const int l = tl > ql ? tl - ql : ql - tl;
+        if (zdrop >= 0 && ez.max - H > zdrop + l * e) { ez.zdropped = 1; return true; }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void ext_dp_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                    ExtParams prm, const uint8_t *__restrict__ reads,
+                                                    const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                    const uint8_t *__restrict__ ref4, const int64_t *__restrict__ ref_off,
+                                                    uint8_t *__restrict__ P, int32_t *__restrict__ OFF, int8_t *__restrict__ gstate,
+                                                    ExtRes *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x;
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    const int qlen = jb.qlen, tlen = jb.tlen;
+    int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    ExtRes out;
+    out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
+    out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0;
+    if (qlen <= 0 || tlen <= 0 || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
+    int w = jb.w;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    const int n_col = jb.n_col;
+    // LDS carve: qseq[qlen] tseq[tlen] (padded to 4) then state
+    uint8_t *qs_ = smem;
+    uint8_t *ts_ = smem + ((qlen + 3) & ~3);
+    int8_t *sbase = jb.state_mode ? gstate + jb.state_off : (int8_t *)(ts_ + ((tlen + 3) & ~3));
+    int8_t *u = sbase, *v = u + tlen, *x = v + tlen, *y = x + tlen, *x2 = y + tlen, *y2 = x2 + tlen;
+    int32_t *H = (int32_t *)(sbase + (((size_t)6 * tlen + 3) & ~(size_t)3));
+    const bool approx = (jb.flag & EZ_APPROX_MAX) != 0;
+    {
+        const int64_t roff = read_off[jb.read];
+        const int32_t rlen = read_len[jb.read];
+        for (int i = lane; i < qlen; i += 64) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
+        const uint8_t *tp = ref4 + ref_off[jb.rid] + jb.ts;
+        for (int i = lane; i < tlen; i += 64) ts_[i] = tp[jb.reversed ? tlen - 1 - i : i];
+        for (int i = lane; i < tlen; i += 64) {
+            u[i] = v[i] = x[i] = y[i] = (int8_t)-qe;
+            x2[i] = y2[i] = (int8_t)-qe2;
+            if (!approx) H[i] = NEG_INF;
+        }
+    }
+    __syncthreads();
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+    uint8_t *p = P + jb.p_off;
+    const int n_r = qlen + tlen - 1;
+    int32_t *off = OFF + 2 * jb.row_off;  // [r] band start, [n_r + r] band end
+    int32_t *off_end = off + n_r;
+    ExtApply ez; ez.max = 0; ez.max_t = ez.max_q = -1; ez.zdropped = 0;
+    int32_t mqe = NEG_INF, mqe_t = -1, score = NEG_INF, H0 = 0, last_H0_t = 0;
+    int last_st = -1, last_en = -1, r;
+    const bool right = (jb.flag & EZ_RIGHT) != 0;
+    for (r = 0; r < n_r; ++r) {
+        int st = 0, en = tlen - 1;
+        if (st < r - qlen + 1) st = r - qlen + 1;
+        if (en > r) en = r;
+        if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+        if (en > (r + w) >> 1) en = (r + w) >> 1;
+        if (st > en) { ez.zdropped = 1; break; }
+        int cx1, cx21, cv1;
+        if (st > 0) {
+            if (st - 1 >= last_st && st - 1 <= last_en) { cx1 = x[st - 1]; cx21 = x2[st - 1]; cv1 = v[st - 1]; }
+            else { cx1 = -qe; cx21 = -qe2; cv1 = -qe; }
+        } else {
+            cx1 = -qe; cx21 = -qe2;
+            cv1 = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+        }
+        if (en >= r) {
+            if (lane == 0) {
+                y[r] = (int8_t)-qe; y2[r] = (int8_t)-qe2;
+                u[r] = (int8_t)(r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2);
+            }
+            __syncthreads();
+        }
+        if (lane == 0) { off[r] = st; off_end[r] = en; }
+        uint8_t *pr = p + (int64_t)r * n_col;
+        // exact-max bookkeeping needs OLD H[en-1]
+        int32_t Hen_new = 0;
+        if (!approx && r > 0) Hen_new = en > 0 ? H[en - 1] : H[en];
+        int32_t bestH = NEG_INF, bestKey = 0x7fffffff;
+        const int en1 = st + (en - st) / 4 * 4;
+        for (int c0 = st; c0 <= en; c0 += 64) {
+            const int t = c0 + lane;
+            const bool act = t <= en;
+            int ut = 0, vt = 0, xt = 0, x2t = 0, yt = 0, y2t = 0, sc = 0;
+            if (act) {
+                ut = u[t]; vt = v[t]; xt = x[t]; x2t = x2[t]; yt = y[t]; y2t = y2[t];
+                const int sq = ts_[t], sr = qs_[r - t];
+                sc = (sq == 4 || sr == 4) ? prm.sc_n : sq == sr ? prm.sc_mch : prm.sc_mis;
+            }
+            const int v1 = wave_shr1(vt, cv1), x1 = wave_shr1(xt, cx1), x21 = wave_shr1(x2t, cx21);
+            cv1 = __builtin_amdgcn_readlane(vt, 63); cx1 = __builtin_amdgcn_readlane(xt, 63); cx21 = __builtin_amdgcn_readlane(x2t, 63);
+            int z = sc, a = x1 + v1, b = yt + ut, a2 = x21 + v1, b2 = y2t + ut, d;
+            if (!right) {
+                d = a > z ? 1 : 0; z = max(z, a);
+                d = b > z ? 2 : d; z = max(z, b);
+                d = a2 > z ? 3 : d; z = max(z, a2);
+                d = b2 > z ? 4 : d; z = max(z, b2);
+            } else {
+                d = z > a ? 0 : 1; z = max(z, a);
+                d = z > b ? d : 2; z = max(z, b);
+                d = z > a2 ? d : 3; z = max(z, a2);
+                d = z > b2 ? d : 4; z = max(z, b2);
+            }
+            z = min(z, (int)prm.sc_mch);
+            const int nu = z - v1, nv = z - ut;
+            int tmp = z - q; a -= tmp; b -= tmp;
+            tmp = z - q2; a2 -= tmp; b2 -= tmp;
+            if (!right) {
+                d |= a > 0 ? 0x08 : 0; d |= b > 0 ? 0x10 : 0; d |= a2 > 0 ? 0x20 : 0; d |= b2 > 0 ? 0x40 : 0;
+            } else {
+                d |= a >= 0 ? 0x08 : 0; d |= b >= 0 ? 0x10 : 0; d |= a2 >= 0 ? 0x20 : 0; d |= b2 >= 0 ? 0x40 : 0;
+            }
+            if (act) {
+                u[t] = (int8_t)nu; v[t] = (int8_t)nv;
+                x[t] = (int8_t)(max(a, 0) - qe); y[t] = (int8_t)(max(b, 0) - qe);
+                x2[t] = (int8_t)(max(a2, 0) - qe2); y2[t] = (int8_t)(max(b2, 0) - qe2);
+                pr[t - st] = (uint8_t)d;
+                if (!approx && r > 0 && t < en) {
+                    const int32_t h = H[t] + nv;
+                    H[t] = h;
+                    const int key = (t < en1 ? 1 + ((t - st) & 3) : 5) << 24 | t;
+                    if (h > bestH || (h == bestH && key < bestKey)) { bestH = h; bestKey = key; }
+                }
+            }
+        }
+        __syncthreads();
+        if (!approx) {
+            int32_t max_H, max_t;
+            if (r > 0) {
+                const int32_t hen = Hen_new + (en > 0 ? (int)u[en] : (int)v[en]);
+                if (lane == 0) H[en] = hen;
+                // en wins every tie; then (t-st)&3 class order for t < en1; then the tail
+                const int32_t m = wave_reduce_max(bestH);
+                int kk = (bestH == m && m > NEG_INF) ? bestKey : 0x7fffffff;
+                kk = wave_reduce_min(kk);
+                if (m > hen) { max_H = m; max_t = kk & 0xffffff; }
+                else { max_H = hen; max_t = en; }
+            } else {
+                const int32_t h0 = (int)v[0] - qe;
+                if (lane == 0) H[0] = h0;
+                max_H = h0; max_t = 0;
+            }
+            __syncthreads();
+            if (r - st == qlen - 1) { const int32_t hs = H[st]; if (hs > mqe) { mqe = hs; mqe_t = st; } }
+            if (ext_apply_zdrop(ez, max_H, r, max_t, jb.zdrop, e2)) break;
+            if (r == n_r - 1 && en == tlen - 1) score = H[tlen - 1];
+        } else {
+            if (r > 0) {
+                if (last_H0_t >= st && last_H0_t <= en && last_H0_t + 1 >= st && last_H0_t + 1 <= en) {
+                    const int32_t d0 = v[last_H0_t], d1 = u[last_H0_t + 1];
+                    if (d0 > d1) H0 += d0; else { H0 += d1; ++last_H0_t; }
+                } else if (last_H0_t >= st && last_H0_t <= en) H0 += v[last_H0_t];
+                else { ++last_H0_t; H0 += u[last_H0_t]; }
+            } else { H0 = (int)v[0] - qe; last_H0_t = 0; }
+            if (r == n_r - 1 && en == tlen - 1) score = H0;
+        }
+        last_st = st; last_en = en;
+    }
+    out.max = ez.max; out.max_t = ez.max_t; out.max_q = ez.max_q; out.zdropped = ez.zdropped;
+    out.mqe = mqe; out.mqe_t = mqe_t; out.score = score;
+    out.r_done = r < n_r ? r : n_r - 1;
+    if (!ez.zdropped && !(jb.flag & EZ_EXTZ_ONLY)) { out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1; }
+    else if (!ez.zdropped && (jb.flag & EZ_EXTZ_ONLY) && mqe + jb.end_bonus > ez.max) { out.reach_end = 1; out.do_bt = 1; out.bt_i = mqe_t; out.bt_j = qlen - 1; }
+    else if (ez.max_t >= 0 && ez.max_q >= 0) { out.do_bt = 1; out.bt_i = ez.max_t; out.bt_j = ez.max_q; }
+    if (lane == 0) res[jid] = out;
+}
+
+// traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
+__global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                    const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
+                                                    uint32_t *__restrict__ CIG, ExtRes *__restrict__ res) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_jobs) return;
+    const int jid = order[k];
+    const ExtJob jb = jobs[jid];
+    ExtRes r = res[jid];
+    if (!r.do_bt) { return; }
+    const int n_col = jb.n_col, n_r = jb.qlen + jb.tlen - 1;
+    const uint8_t *p = P + jb.p_off;
+    const int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
+    const bool rev_cigar = (jb.flag & EZ_REV_CIGAR) != 0;
+    // ops are generated last-to-first.  REV_CIGAR keeps that order (write forward from the region start),
+    // otherwise they are written back to front so that they read forward.
+    uint32_t *cend = CIG + jb.cig_off;
+    const int cap = jb.qlen + jb.tlen + 2;
+    uint32_t *cbeg = cend - cap;
+    int n = 0, i = r.bt_i, j = r.bt_j, state = 0;
+    uint32_t cur_op = 0xf, cur_len = 0;
+#define MPN_FLUSH() do { if (cur_len) { if (rev_cigar) cbeg[n] = cur_len << 4 | cur_op; else cend[-1 - n] = cur_len << 4 | cur_op; ++n; } } while (0)
+#define MPN_PUSHOP(OP, LEN) do { if ((uint32_t)(OP) == cur_op) cur_len += (LEN); else { MPN_FLUSH(); cur_op = (OP); cur_len = (LEN); } } while (0)
+    while (i >= 0 && j >= 0) {
+        const int rr = i + j;
+        int force_state = -1, tmp;
+        if (i < off[rr]) force_state = 2;
+        if (i > off_end[rr]) force_state = 1;
+        tmp = force_state < 0 ? p[(int64_t)rr * n_col + i - off[rr]] : 0;
+        if (state == 0) state = tmp & 7;
+        else if (!(tmp >> (state + 2) & 1)) state = 0;
+        if (state == 0) state = tmp & 7;
+        if (force_state >= 0) state = force_state;
+        if (state == 0) { MPN_PUSHOP(0, 1); --i; --j; }
+        else if (state == 1 || state == 3) { MPN_PUSHOP(2, 1); --i; }
+        else { MPN_PUSHOP(1, 1); --j; }
+    }
+    if (i >= 0) MPN_PUSHOP(2, (uint32_t)(i + 1));
+    if (j >= 0) MPN_PUSHOP(1, (uint32_t)(j + 1));
+    MPN_FLUSH();
+#undef MPN_PUSHOP
+#undef MPN_FLUSH
+    res[jid].n_cigar = n;
+}
+
+// z-drop test of a finished gap-fill CIGAR (minimap2 mm_test_zdrop without the inversion probe): one lane per job
+__global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                       ExtParams prm, const uint8_t *__restrict__ reads,
+                                                       const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                       const uint8_t *__restrict__ ref4, const int64_t *__restrict__ ref_off,
+                                                       const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_jobs) return;
+    const int jid = order[k];
+    const ExtJob jb = jobs[jid];
+    const ExtRes r = res[jid];
+    const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
+    const int64_t roff = read_off[jb.read];
+    const int32_t rlen = read_len[jb.read];
+    const uint8_t *tp = ref4 + ref_off[jb.rid] + jb.ts;
+    int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+    for (int c = 0; c < r.n_cigar; ++c) {
+        const uint32_t op = cig[c] & 0xf, len = cig[c] >> 4;
+        if (op == 0) {
+            for (uint32_t l = 0; l < len; ++l) {
+                const int ct = tp[i + l], cq = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + j + l);
+                score += (ct == 4 || cq == 4) ? -(int)(-prm.sc_n) : ct == cq ? prm.sc_mch : prm.sc_mis;
+                if (score < mx) {
+                    const int li = i + (int)l - max_i, lj = j + (int)l - max_j, diff = li > lj ? li - lj : lj - li;
+                    const int z = mx - score - diff * prm.e;
+                    if (z > max_zdrop) max_zdrop = z;
+                } else { mx = score; max_i = i + l; max_j = j + l; }
+            }
+            i += len; j += len;
+        } else if (op == 1 || op == 2) {
+            score -= prm.q + prm.e * (int)len;
+            if (op == 1) j += len; else i += len;
+            if (score < mx) {
+                const int li = i - max_i, lj = j - max_j, diff = li > lj ? li - lj : lj - li;
+                const int z = mx - score - diff * prm.e;
+                if (z > max_zdrop) max_zdrop = z;
+            } else { mx = score; max_i = i; max_j = j; }
+        }
+    }
+    res[jid].zcode = max_zdrop > prm.zdrop_thres ? 1 : 0;
+}
+
+}  // namespace mpn

@@ -9,15 +9,9 @@
 // Every stage is integer / byte work bound by HBM latency and bandwidth, not by arithmetic: no MFMA.
 #pragma once
 #include "mpn_common.h"
+#include "map_types.h"
 
 namespace mpn {
-
-struct u128 { uint64_t x, y; };
-
-__device__ __forceinline__ int nt4_code(uint8_t c) {
-    c |= 0x20;
-    return c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;
-}
 
 __device__ __forceinline__ uint64_t hash64m(uint64_t key, uint64_t mask) {
     key = (~key + (key << 21)) & mask;

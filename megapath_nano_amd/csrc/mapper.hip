@@ -248,7 +248,8 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
     idx->n_mz = n_mz;
     idx->h_key_off = key_off;
     if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(key_off.data(), key_off.size(), st) ||
-        idx->pos.upload(pos.data(), pos.size(), st))
+        idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq4.upload(idx->seq4.data(), idx->seq4.size(), st) ||
+        idx->d_seq_off.upload(off.data(), off.size(), st))
         return fail();
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
     return idx;

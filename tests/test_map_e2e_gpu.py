@@ -1,0 +1,87 @@
+"""GPU parity tests (-m gpu): mpn_map_batch (seed-chain-extend + hit bookkeeping + PAF) against the CPU oracle
+oracle/mm2_oracle.c, line by line.  Parity unpinned against a real minimap2 (not vendored by the reference);
+bit-exact against the oracle on coordinates, CIGAR, scores, MAPQ and tags."""
+import numpy as np
+import pytest
+
+from map_cases import small_world
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_paf(oidx, oopt, reads):
+    from oracle import mm2_bindings as mb
+    out = []
+    for r in reads:
+        _, _, paf = mb.map_read(oidx, oopt, r['name'], r['seq'])
+        out.append(paf)
+    return out
+
+
+def split_by_read(paf, names):
+    by = {n: [] for n in names}
+    for line in paf.splitlines():
+        by[line.split('\t', 1)[0]].append(line)
+    return ['\n'.join(by[n]) + ('\n' if by[n] else '') for n in names]
+
+
+@pytest.fixture(scope='module')
+def world(libmpn, oracle_built):
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads = small_world(seed=3, n_genomes=6, glen=150000, n_reads=60, mean_len=4000)
+    gidx = mapper.Index(gen)
+    oidx = mb.Index(gen)
+    yield gen, reads, gidx, oidx
+    gidx.close()
+    oidx.close()
+
+
+@pytest.mark.parametrize('best_n,pri_ratio,with_cigar', [(5, 0.8, 1), (50, 1.0, 1), (5, 0.8, 0)])
+def test_paf_matches_oracle(world, best_n, pri_ratio, with_cigar):
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    gopt = mapper.default_opt(best_n=best_n, pri_ratio=pri_ratio, with_cigar=with_cigar)
+    oopt = mb.default_opt(best_n=best_n, pri_ratio=pri_ratio, with_cigar=with_cigar)
+    names = [r['name'] for r in reads]
+    got = split_by_read(mapper.map_batch(gidx, gopt, names, [r['seq'] for r in reads]), names)
+    want = oracle_paf(oidx, oopt, reads)
+    n_lines = 0
+    for r, g, w in zip(reads, got, want):
+        assert g == w, (r['name'], len(r['seq']))
+        n_lines += w.count('\n')
+    assert n_lines >= len(reads) // 2
+    if with_cigar:
+        # column contract relied on by the reference's awk (aligner.py:271-273): NM at 13, AS at 15
+        for line in ''.join(want).splitlines():
+            f = line.split('\t')
+            assert f[12].startswith('NM:i:') and f[14].startswith('AS:i:')
+
+
+def test_mapping_lands_on_truth(world):
+    """size-independent sanity: the primary hit of a simulated read overlaps its true origin"""
+    from megapath_nano_amd import mapper
+    gen, reads, gidx, _ = world
+    gopt = mapper.default_opt()
+    names = [r['name'] for r in reads]
+    paf = mapper.map_batch(gidx, gopt, names, [r['seq'] for r in reads])
+    prim = {}
+    for line in paf.splitlines():
+        f = line.split('\t')
+        if 'tp:A:P' in f and f[0] not in prim:
+            prim[f[0]] = f
+    ok = tot = 0
+    name_to_idx = {g[0]: i for i, g in enumerate(gen)}
+    for r in reads:
+        if r['genome'] < 0 or len(r['seq']) < 500:
+            continue
+        tot += 1
+        f = prim.get(r['name'])
+        if f is None:
+            continue
+        gi = name_to_idx[f[5]]
+        same = gi == r['genome'] or {gen[gi][0][:6], gen[r['genome']][0][:6]} == {'NZ_SYN', 'NZ_STR'}
+        if same and int(f[7]) < r['end'] and int(f[8]) > r['start'] and f[4] == r['strand']:
+            ok += 1
+    assert ok >= tot * 0.9, (ok, tot)
