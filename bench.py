@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- Gbp/min of ONT reads aligned + species-assigned on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM:
+seed-chain-extend against the resident index (HIP kernels), host hit bookkeeping, read reassignment (HIP kernels),
+best hit per read and the per-species / per-name counters, followed for N > 1 by the RCCL all-reduce of those counters.
+Workload = BASELINE.json configs[2] scaled to what the round-1 index build handles (see config.workload):
+a 10-species community (two close relatives) sampled against an index of synthetic genomes; every rank holds the
+whole index and maps its own reads (weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest device time (HIP events on the stream the
+library launches on); `cpu_baseline` times the CPU oracle (oracle/mm2_oracle.c, a port) on a bounded sample of the
+same reads on this host's cores.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_world(args, rank):
+    from megapath_nano_amd import synth
+    from megapath_nano_amd.pipeline import Taxonomy
+    genomes = synth.make_genomes(20240901, args.genomes, args.genome_len, strain_pairs=args.strain_pairs)
+    n = len(genomes)
+    # community: 10 members with log-normal abundance, including a close-relative pair (genome 0 and its 99% copy)
+    rng = np.random.default_rng(7)
+    base = n - args.strain_pairs
+    members = list(range(min(9, base))) + ([base] if args.strain_pairs > 0 else [])
+    weights = np.zeros(n)
+    weights[members] = rng.lognormal(0.0, 1.0, size=len(members))
+    # taxonomy: every genome carries its own name and species_tax_id (the strain copy plays the close relative)
+    name_code = np.arange(n, dtype=np.int32)
+    species_code = np.arange(n, dtype=np.int32)
+    tax = Taxonomy(name_code, n, species_code, n)
+    return genomes, weights, tax
+
+
+def make_batch(genomes, weights, args, seed, device):
+    from megapath_nano_amd import synth, mapper
+    reads = synth.make_reads(seed, genomes, args.reads_per_step, mean_len=args.mean_len, weights=weights)
+    return mapper.PackedReads([r['name'] for r in reads], [r['seq'] for r in reads], device=device), reads
+
+
+def cpu_baseline(genomes, reads, opt_kw, seconds_target=15.0):
+    """Oracle (port of the minimap2 path) on a bounded sample of the same reads, all host cores up to 16."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
+    from oracle import mm2_bindings as mb
+    cores = max(1, min(16, os.cpu_count() or 1))
+    oidx = mb.Index(genomes)
+    oopt = mb.default_opt(**opt_kw)
+    oopt.mid_occ = oidx.mid_occ()
+    # calibrate on a few reads, then size the sample for ~seconds_target of wall time
+    t0 = time.time()
+    for r in reads[:4]:
+        mb.map_read(oidx, oopt, r['name'], r['seq'])
+    per_read = (time.time() - t0) / 4
+    n = int(max(8, min(len(reads), seconds_target * cores / max(per_read, 1e-4))))
+    sample = reads[:n]
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda r: mb.map_read(oidx, oopt, r['name'], r['seq'])[1], sample))
+    dt = time.time() - t0
+    bases = sum(len(r['seq']) for r in sample)
+    oidx.close()
+    return dict(value=bases / dt * 60 / 1e9, unit='Gbp/min', cores=cores, kind='port',
+                sample=f'{n} reads ({bases} bp) of the step batch, oracle/mm2_oracle.c seed-chain-extend, {dt:.1f} s wall')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--genomes', type=int, default=100)
+    ap.add_argument('--genome-len', type=int, default=2000000)
+    ap.add_argument('--strain-pairs', type=int, default=2)
+    ap.add_argument('--reads-per-step', type=int, default=16384)
+    ap.add_argument('--mean-len', type=int, default=8000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from megapath_nano_amd import dist as mdist, mapper
+    from megapath_nano_amd.pipeline import align_and_assign
+    rank, world, local = mdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    device = torch.device('cuda', local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    from megapath_nano_amd import build
+    if rank == 0:
+        build.build()
+    mdist.barrier()
+
+    genomes, weights, tax = build_world(args, rank)
+    t0 = time.time()
+    idx = mapper.Index(genomes)
+    index_s = time.time() - t0
+    opt_kw = dict(best_n=50, pri_ratio=1.0)  # megapath_nano.py:1270  -N 50 -p 1 -x map-ont
+    opt = mapper.default_opt(**opt_kw)
+    opt.mid_occ = idx.mid_occ()
+    allreduce = mdist.make_allreduce(device)
+    rnd = random.Random(12345 + rank)
+
+    total = args.warmup + args.steps
+    batches = [make_batch(genomes, weights, args, 1000 * (rank + 1) + s, device) for s in range(total)]
+
+    def run(b):
+        return align_and_assign(idx, opt, b[0], tax, allreduce=allreduce, rng=rnd)
+
+    for s in range(args.warmup):
+        run(batches[s])
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats_acc = {}
+    counts = None
+    for s in range(args.warmup, total):
+        out = run(batches[s])
+        counts = out['read_count'] if counts is None else counts + out['read_count']
+        for k, v in mapper.last_stats().items():
+            stats_acc[k] = stats_acc.get(k, 0) + v
+    torch.cuda.synchronize()
+    mdist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        b = torch.tensor([sum(batches[s][0].bases for s in range(args.warmup, total))], dtype=torch.int64, device=device)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        bases = int(b.item())
+    else:
+        bases = sum(batches[s][0].bases for s in range(args.warmup, total))
+    if rank != 0:
+        return
+
+    K = max(1, args.steps)
+    st = {k: v / K for k, v in stats_acc.items()}  # per step (rank 0)
+    # dominant kernel by device time; algorithmic bytes per launch
+    kern = {
+        'sketch_kernel': (st['ev_sketch_ns'], 2 * st['bases'] + 16 * st['minimizers']),            # 2 passes over the reads + minimizers out
+        'seed_lookup+fill': (st['ev_seed_ns'], 16 * st['minimizers'] + 8 * st['anchors'] + 16 * st['anchors']),
+        'seg_sort_kernel': (st['ev_sort_ns'], 2 * 16 * st['anchors']),
+        'chain_dp_kernel': (st['ev_chain_dp_ns'], (16 + 16) * st['anchors']),
+        'ext_dp_kernel': (st['ev_ext_dp_ns'], st['dp_cells']),                                         # 1 direction byte per cell out (+ windows in)
+        'ext_bt_kernel': (st['ev_ext_bt_ns'], 0),
+    }
+    dom = max(kern, key=lambda k: kern[k][0])
+    dom_ns, dom_bytes = kern[dom]
+    achieved = dom_bytes / max(dom_ns, 1) if dom_ns else 0.0  # bytes/ns == GB/s
+    dev_ns = sum(v[0] for v in kern.values()) + st['ev_chain_bt_ns'] + st['ev_ext_ztest_ns']
+    line = {
+        'metric': 'Gbp/min ONT reads aligned+species-assigned vs RefSeq, 1/2/4/8 MI355X',
+        'value': bases / dt * 60 / 1e9,
+        'unit': 'Gbp/min',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': dt / K * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'int32',
+        'data': 'synthetic',
+        'config': {
+            'workload': f'configs[2] scaled: {args.reads_per_step} synthetic ONT-like reads/step/GPU (Gamma lengths, mean '
+                        f'{args.mean_len} bp, 12% errors; in-repo stand-in for badread) from a 10-member community incl. a '
+                        f'99%-identity strain pair, vs a resident index of {args.genomes} synthetic genomes x '
+                        f'{args.genome_len} bp (NOT full RefSeq: round-1 index build sorts on the host), '
+                        f'-N 50 -p 1 -x map-ont -c, reassignment on',
+            'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': args.genomes, 'index_bp': args.genomes * args.genome_len,
+            'index_build_s': round(index_s, 2), 'parallelism': f'reads sharded over {world} GPU(s), index replicated',
+        },
+        'roofline': {
+            'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+            'note': 'integer DP / byte work; dominant kernel by HIP-event time per step on rank 0',
+            'kernel_ms_per_step': {k: round(v[0] / 1e6, 2) for k, v in kern.items()},
+            'device_ms_per_step': round(dev_ns / 1e6, 2),
+            'dp_gcups': round(st['dp_cells'] / max(st['ev_ext_dp_ns'], 1), 1),
+        },
+        'per_step': {k: (round(v / 1e6, 2) if k.endswith('_ns') else int(v)) for k, v in st.items()},
+        'reads_per_name_top': sorted(((int(c), int(i)) for i, c in enumerate(counts) if c), reverse=True)[:5],
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(genomes, batches[args.warmup][1], opt_kw)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -87,10 +87,33 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
 int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
                       const char *seqs, const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap);
 
-/* Counters of the last mpn_map_batch / mpn_seed_chain_batch on this thread, for bench.py's roofline line:
- * [0] input bases, [1] read minimizers, [2] anchors, [3] chain predecessor evaluations (not counted: 0),
- * [4] DP jobs, [5] DP cells, [6] alignments reported, [7] kernel-time ns (HIP events, all kernels of the call). */
-void mpn_map_last_stats(int64_t stats[8]);
+/* ---- product call, extended: device-resident reads in, alignment columns out --------------------------------
+ * d_seqs/d_off/d_len (DEVICE pointers, may be NULL): the same reads already resident in HBM (bench.py uploads them
+ * before the timed region); the host copies are still needed for the CIGAR bookkeeping.
+ * paf may be NULL.  cols may be NULL; otherwise every reported alignment fills one row of the caller-allocated
+ * arrays (cap rows each), in PAF order: the 12 PAF columns as integers plus NM, AS and the tp flag; these are
+ * the fields aligner.py:291-294 keeps.  Returns PAF bytes written (0 if paf is NULL) or a negative error
+ * (-3: paf_cap or cols->cap too small; cols->n_rows then holds the required number). */
+typedef struct {
+    int64_t cap, n_rows;
+    int32_t *read_idx, *qs, *qe, *rev, *rid, *rs, *re, *mlen, *blen, *mapq, *nm, *as, *primary;
+} mpn_aln_cols;
+
+int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                         const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs,
+                         const int64_t *d_off, const int32_t *d_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols);
+
+/* Counters and timers of the last mpn_map_batch / mpn_seed_chain_batch on this thread (bench.py roofline line):
+ *  [0] input bases  [1] read minimizers  [2] anchors  [3] chains  [4] DP jobs  [5] DP cells  [6] alignments reported
+ *  [7] DP rounds    [8] second-pass (exact z-drop) jobs
+ * wall-clock ns of the host phases:
+ *  [16] H2D reads  [17] seed+chain stage (incl. its kernels)  [18] D2H chains  [19] host: hits from chains
+ *  [20] host: plan DP windows  [21] extension stage (H2D jobs, kernels, D2H results)  [22] host: stitch
+ *  [23] host: rank/MAPQ/PAF  [24] whole call
+ * device ns measured with HIP events on the stream the kernels run on:
+ *  [10] sketch  [11] seed lookup+fill  [12] anchor sort  [13] chain DP  [14] chain ends+backtrack
+ *  [15] extension DP kernel  [25] traceback kernel  [26] z-drop test kernel */
+void mpn_map_last_stats(int64_t stats[32]);
 
 #ifdef __cplusplus
 }

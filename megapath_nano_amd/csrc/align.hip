@@ -758,8 +758,8 @@ static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *nam
     }
 }
 
-// run all DP jobs of one round on the GPU
-static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<ExtJob> &jobs, const uint8_t *d_reads,
+// run one group of DP jobs on the GPU (its scratch fits the budget)
+static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vector<ExtJob> &jobs, const uint8_t *d_reads,
                     const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res, std::vector<uint32_t> &cig,
                     hipStream_t st) {
     const int nj = (int)jobs.size();
@@ -817,10 +817,13 @@ static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<Ex
         MPN_HIP_CHECK(hipGetLastError());
         return 0;
     };
+    EvTimer ev(st);
     for (int c = 0; c < 5; ++c)
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+    ev.stop_into(g_stats[15]);
     hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());
+    ev.stop_into(g_stats[25]);
     // z-drop test of the gap-fill CIGARs; flagged jobs are recomputed with the exact maximum
     std::vector<int32_t> gap;
     for (int j = 0; j < nj; ++j) if ((jobs[j].flag & EZ_APPROX_MAX)) gap.push_back(j);
@@ -830,6 +833,7 @@ static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<Ex
         hipLaunchKernelGGL(ext_ztest_kernel, dim3(((int)gap.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_gap.p, (int)gap.size(), prm,
                            d_reads, d_read_off, d_read_len, idx->d_seq4.p, idx->d_seq_off.p, CIG.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
+        ev.stop_into(g_stats[26]);
         if (d_res.download(res.data(), nj, st)) return -1;
         MPN_HIP_CHECK(hipStreamSynchronize(st));
         std::vector<int32_t> redo[5];
@@ -838,14 +842,18 @@ static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<Ex
         for (int c = 0; c < 5; ++c) for (int j : order[c]) if ((res[j].zcode) && !(jobs[j].flag & EZ_APPROX_MAX) && !(jobs[j].flag & EZ_EXTZ_ONLY)) redo[c].push_back(j);
         int rbase[5];
         for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }
+        g_stats[8] += (int64_t)redo_flat.size();
         if (!redo_flat.empty()) {
             DevBuf<int32_t> d_redo;
             if (d_jobs.upload(jobs.data(), nj, st) || d_redo.upload(redo_flat.data(), redo_flat.size(), st)) return -1;
+            EvTimer ev2(st);
             for (int c = 0; c < 5; ++c)
                 if (launch_dp(d_redo.p + rbase[c], (int)redo[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+            ev2.stop_into(g_stats[15]);
             hipLaunchKernelGGL(ext_bt_kernel, dim3(((int)redo_flat.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p,
                                (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_res.p);
             MPN_HIP_CHECK(hipGetLastError());
+            ev2.stop_into(g_stats[25]);
         }
     }
     cig.resize((size_t)cig_tot);
@@ -854,28 +862,78 @@ static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<Ex
     return 0;
 }
 
+// run all DP jobs of one round, in groups whose direction scratch stays under the budget
+static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<ExtJob> &jobs, const uint8_t *d_reads,
+                    const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res, std::vector<uint32_t> &cig,
+                    hipStream_t st) {
+    const int64_t budget = (int64_t)16 << 30;  // bytes of direction codes per group
+    const int nj = (int)jobs.size();
+    res.assign(nj, ExtRes());
+    cig.clear();
+    int lo = 0;
+    while (lo < nj) {
+        int hi = lo;
+        int64_t acc = 0;
+        while (hi < nj) {
+            const ExtJob &jb = jobs[hi];
+            const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
+            const int64_t sz = ((int64_t)jb.qlen + jb.tlen - 1) * (std::min(std::min(jb.qlen, jb.tlen), w + 1) + 1);
+            if (hi > lo && acc + sz > budget) break;
+            acc += sz;
+            ++hi;
+        }
+        std::vector<ExtJob> sub(jobs.begin() + lo, jobs.begin() + hi);
+        std::vector<ExtRes> rsub;
+        std::vector<uint32_t> csub;
+        if (run_job_group(idx, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
+        const int64_t base = (int64_t)cig.size();
+        for (int k = 0; k < hi - lo; ++k) { sub[k].cig_off += base; jobs[lo + k] = sub[k]; res[lo + k] = rsub[k]; }
+        cig.insert(cig.end(), csub.begin(), csub.end());
+        lo = hi;
+    }
+    return 0;
+}
+
 }  // namespace mpn
 
 using namespace mpn;
 
-extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
-                                 const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap) {
+extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                                    const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
+                                    const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
     hipStream_t st = 0;
     memset(g_stats, 0, sizeof(g_stats));
-    if (n <= 0) { if (paf_cap > 0) paf[0] = 0; return 0; }
-    DevBuf<uint8_t> d_seqs;
-    DevBuf<int64_t> d_off;
-    DevBuf<int32_t> d_len;
+    if (cols) cols->n_rows = 0;
+    if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; return 0; }
+    struct Borrowed {  // device views of the reads: owned uploads or the caller's resident buffers
+        DevBuf<uint8_t> seqs; DevBuf<int64_t> off; DevBuf<int32_t> len;
+        const uint8_t *p = nullptr; const int64_t *po = nullptr; const int32_t *pl = nullptr;
+    } dv;
     int64_t bases = 0;
-    if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
+    WallTimer whole, wt;
+    if (r_seqs && r_off && r_len) {
+        dv.p = (const uint8_t *)r_seqs; dv.po = r_off; dv.pl = r_len;
+        for (int i = 0; i < n; ++i) bases += seq_len[i];
+    } else {
+        if (upload_seqs(n, seqs, seq_off, seq_len, dv.seqs, dv.off, dv.len, &bases, st)) return -1;
+        dv.p = dv.seqs.p; dv.po = dv.off.p; dv.pl = dv.len.p;
+    }
+    struct { const uint8_t *p; } d_seqs{dv.p};
+    struct { const int64_t *p; } d_off{dv.po};
+    struct { const int32_t *p; } d_len{dv.pl};
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    wt.stop_into(g_stats[16]);
     g_stats[0] = bases;
     HostChains h;
     {
         SeedChainOut o;
         if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, o, st)) return -1;
+        wt.stop_into(g_stats[17]);
         if (download_chains(n, o, h, st)) return -1;
+        wt.stop_into(g_stats[18]);
     }
-    int n_threads = opt->host_threads > 0 ? opt->host_threads : (int)std::thread::hardware_concurrency();
+    g_stats[3] = (int64_t)h.u.size();
+    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, (int)std::thread::hardware_concurrency());
     if (n_threads < 1) n_threads = 1;
     std::vector<ReadState> rs(n);
     // hits from chains
@@ -904,8 +962,10 @@ extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, i
             }
         }
     });
+    wt.stop_into(g_stats[19]);
     if (opt->with_cigar) {
         for (int round = 0; round < 64; ++round) {
+            wt.stop_into(g_stats[23]);
             // plan (serial append into one job list keeps job ids deterministic)
             JobSink sink;
             bool any = false;
@@ -922,10 +982,13 @@ extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, i
                     any = true;
                 }
             }
+            wt.stop_into(g_stats[20]);
             if (!any) break;
+            ++g_stats[7];
             std::vector<ExtRes> res;
             std::vector<uint32_t> cig;
             if (run_jobs(idx, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
+            wt.stop_into(g_stats[21]);
             parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
                 if (S.pending.empty()) return;
@@ -938,8 +1001,10 @@ extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, i
                     if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
                 }
             });
+            wt.stop_into(g_stats[22]);
         }
     }
+    wt.stop_into(g_stats[23]);
     // rank, MAPQ, text
     std::vector<std::string> lines(n);
     std::atomic<int64_t> n_aln(0);
@@ -955,15 +1020,38 @@ extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, i
             set_sam_pri(S.regs);
         }
         set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
-        write_paf(idx, opt, names && names[i] ? names[i] : "*", qlen, S.regs, h.rep_len[i], lines[i]);
+        if (paf) write_paf(idx, opt, names && names[i] ? names[i] : "*", qlen, S.regs, h.rep_len[i], lines[i]);
         n_aln += (int64_t)S.regs.size();
     });
     g_stats[6] = n_aln;
-    int64_t tot = 0;
-    for (auto &l : lines) tot += (int64_t)l.size();
-    if (tot + 1 > paf_cap) return -3;
+    if (cols) {
+        cols->n_rows = n_aln;
+        if (n_aln > cols->cap) return -3;
+        int64_t k = 0;
+        for (int i = 0; i < n; ++i)
+            for (const Reg &r : rs[i].regs) {
+                cols->read_idx[k] = i; cols->qs[k] = r.qs; cols->qe[k] = r.qe; cols->rev[k] = (int32_t)r.rev; cols->rid[k] = r.rid;
+                cols->rs[k] = r.rs; cols->re[k] = r.re; cols->mlen[k] = r.mlen; cols->blen[k] = r.blen; cols->mapq[k] = (int32_t)r.mapq;
+                cols->nm[k] = r.has_p ? r.blen - r.mlen + r.n_ambi : -1;
+                cols->as[k] = r.has_p ? r.dp_score : -1;
+                cols->primary[k] = r.id == r.parent;
+                ++k;
+            }
+    }
     int64_t w = 0;
-    for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
-    paf[w] = 0;
+    if (paf) {
+        int64_t tot = 0;
+        for (auto &l : lines) tot += (int64_t)l.size();
+        if (tot + 1 > paf_cap) return -3;
+        for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
+        paf[w] = 0;
+    }
+    wt.stop_into(g_stats[23]);
+    whole.stop_into(g_stats[24]);
     return w;
+}
+
+extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                                 const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap) {
+    return mpn_map_batch_ex(idx, opt, n, names, seqs, seq_off, seq_len, nullptr, nullptr, nullptr, paf, paf_cap, nullptr);
 }

@@ -10,7 +10,7 @@
 
 namespace mpn {
 
-thread_local int64_t g_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local int64_t g_stats[32] = {0};
 
 static int grid_1d(int64_t n, int block, int cap = 256 * 16) {
     int64_t g = (n + block - 1) / block;
@@ -64,7 +64,9 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     int64_t n_mz = 0;
     DevBuf<int64_t> mz_off;
     DevBuf<u128> mz;
+    EvTimer ev(st);
     if (sketch_device(d_seqs, d_off, d_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st)) return -1;
+    ev.stop_into(g_stats[10]);
     g_stats[1] += n_mz;
     const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
     DevBuf<int32_t> occ;
@@ -93,19 +95,23 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || F.alloc(n_a) || P.alloc(n_a) || T.alloc(n_a) || V.alloc(n_a) ||
         o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n))
         return -1;
+    ev.stop_into(g_stats[11]);
     if (n_a > 0) {
         hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
                            pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, o.anchors.p);
         MPN_HIP_CHECK(hipGetLastError());
+        ev.stop_into(g_stats[11]);
         hipLaunchKernelGGL(seg_sort_kernel, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n);
         MPN_HIP_CHECK(hipGetLastError());
     }
+    ev.stop_into(g_stats[12]);
     ChainParams cp;
     cp.max_dist_x = opt->max_gap; cp.max_dist_y = opt->max_gap; cp.bw = opt->bw; cp.max_skip = opt->max_chain_skip;
     cp.max_iter = opt->max_chain_iter; cp.min_cnt = opt->min_cnt; cp.min_sc = opt->min_chain_score;
     const int g = std::max(1, std::min(n, 256 * 32));
     hipLaunchKernelGGL(chain_dp_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p);
     MPN_HIP_CHECK(hipGetLastError());
+    ev.stop_into(g_stats[13]);
     hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);
     MPN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(chain_sort_ends_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(256), 0, st, o.u.p, Utmp.p,
@@ -116,6 +122,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p,
                        o.u.p, o.n_ends.p, o.chained.p, o.n_chain.p, o.n_chained.p);
     MPN_HIP_CHECK(hipGetLastError());
+    ev.stop_into(g_stats[14]);
     MPN_HIP_CHECK(hipStreamSynchronize(st));
     return 0;
 }
@@ -320,6 +327,6 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     return 0;
 }
 
-void mpn_map_last_stats(int64_t stats[8]) { memcpy(stats, g_stats, sizeof(g_stats)); }
+void mpn_map_last_stats(int64_t stats[32]) { memcpy(stats, g_stats, sizeof(g_stats)); }
 
 }  // extern "C"

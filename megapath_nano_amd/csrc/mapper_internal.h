@@ -2,6 +2,7 @@
 #pragma once
 #include "mpn_common.h"
 
+#include <chrono>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -46,6 +47,31 @@ struct HostChains {
     std::vector<u128> b;
 };
 
-extern thread_local int64_t g_stats[8];
+extern thread_local int64_t g_stats[32];
+
+// HIP-event timer for a group of launches on one stream; accumulate() syncs on the stop event
+struct EvTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    explicit EvTimer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    void stop_into(int64_t &acc) {
+        (void)hipEventRecord(b, st);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        acc += (int64_t)(ms * 1e6);
+        (void)hipEventRecord(a, st);
+    }
+    ~EvTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+struct WallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void stop_into(int64_t &acc) {
+        auto t1 = std::chrono::steady_clock::now();
+        acc += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+        t0 = t1;
+    }
+};
 
 }  // namespace mpn

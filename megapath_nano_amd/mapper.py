@@ -19,6 +19,13 @@ class MapOpt(ct.Structure):
                 ('seed', ct.c_uint32), ('host_threads', ct.c_int32)]
 
 
+COL_NAMES = ('read_idx', 'qs', 'qe', 'rev', 'rid', 'rs', 're', 'mlen', 'blen', 'mapq', 'nm', 'as_', 'primary')
+
+
+class AlnCols(ct.Structure):
+    _fields_ = [('cap', ct.c_int64), ('n_rows', ct.c_int64)] + [(n, ct.c_void_p) for n in COL_NAMES]
+
+
 _bound = False
 
 
@@ -48,6 +55,9 @@ def _bind():
         if hasattr(lib, 'mpn_map_batch'):
             lib.mpn_map_batch.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, ct.c_int64]
             lib.mpn_map_batch.restype = ct.c_int64
+        lib.mpn_map_batch_ex.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P,
+                                         ct.c_int64, ct.POINTER(AlnCols)]
+        lib.mpn_map_batch_ex.restype = ct.c_int64
         lib.mpn_map_last_stats.argtypes = [P]
         lib.mpn_map_last_stats.restype = None
         _bound = True
@@ -179,8 +189,64 @@ def map_batch(idx, opt, names, seqs):
         return out.raw[:r].decode()
 
 
+class PackedReads:
+    """Reads packed for mpn_map_batch_ex; optionally also resident in HBM (torch uint8/int64/int32 tensors)."""
+
+    def __init__(self, names, seqs, device=None):
+        self.n = len(seqs)
+        self.names = list(names)
+        self.buf, self.off, self.lens = pack_seqs(seqs)
+        self.cnames = (ct.c_char_p * self.n)(*[x.encode() for x in self.names])
+        self.bases = int(self.lens.astype(np.int64).sum())
+        self.dev = None
+        if device is not None:
+            import torch
+            self.dev = (torch.from_numpy(self.buf).to(device), torch.from_numpy(self.off).to(device),
+                        torch.from_numpy(self.lens).to(device))
+            torch.cuda.synchronize(device)
+
+
+def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True):
+    """-> (paf text or None, dict of int32 column arrays or None)"""
+    lib = _bind()
+    n = packed.n
+    d = [0, 0, 0] if packed.dev is None else [t.data_ptr() for t in packed.dev]
+    paf_cap = packed.bases * 4 + 4096 * n + 4096 if want_paf else 0
+    rows_cap = max(64, n * 4)
+    while True:
+        out = ct.create_string_buffer(paf_cap) if want_paf else None
+        cols = AlnCols()
+        arrs = {}
+        if want_cols:
+            cols.cap = rows_cap
+            for c in COL_NAMES:
+                arrs[c] = np.zeros(rows_cap, dtype=np.int32)
+                setattr(cols, c, arrs[c].ctypes.data)
+        r = lib.mpn_map_batch_ex(idx.h, ct.byref(opt), n, packed.cnames, packed.buf.ctypes.data, packed.off.ctypes.data,
+                                 packed.lens.ctypes.data, d[0], d[1], d[2], out, paf_cap, ct.byref(cols) if want_cols else None)
+        if r == -3:
+            if want_cols and cols.n_rows > rows_cap:
+                rows_cap = int(cols.n_rows) + 16
+            else:
+                paf_cap = paf_cap * 4 + 4096
+            continue
+        if r < 0:
+            raise _ffi.MpnError(f'mpn_map_batch_ex rc={r}: {_ffi.last_error()}')
+        paf = out.raw[:r].decode() if want_paf else None
+        if want_cols:
+            arrs = {k: v[:cols.n_rows] for k, v in arrs.items()}
+        return paf, (arrs if want_cols else None)
+
+
+STAT_NAMES = {0: 'bases', 1: 'minimizers', 2: 'anchors', 3: 'chains', 4: 'dp_jobs', 5: 'dp_cells', 6: 'alignments',
+              7: 'dp_rounds', 8: 'second_pass_jobs', 10: 'ev_sketch_ns', 11: 'ev_seed_ns', 12: 'ev_sort_ns',
+              13: 'ev_chain_dp_ns', 14: 'ev_chain_bt_ns', 15: 'ev_ext_dp_ns', 25: 'ev_ext_bt_ns', 26: 'ev_ext_ztest_ns',
+              16: 'wall_h2d_ns', 17: 'wall_seed_chain_ns', 18: 'wall_d2h_chains_ns', 19: 'wall_host_hits_ns',
+              20: 'wall_host_plan_ns', 21: 'wall_ext_stage_ns', 22: 'wall_host_stitch_ns', 23: 'wall_host_final_ns',
+              24: 'wall_total_ns'}
+
+
 def last_stats():
-    s = np.zeros(8, dtype=np.int64)
+    s = np.zeros(32, dtype=np.int64)
     _bind().mpn_map_last_stats(s.ctypes.data)
-    return dict(bases=int(s[0]), minimizers=int(s[1]), anchors=int(s[2]), chain_evals=int(s[3]), dp_jobs=int(s[4]),
-                dp_cells=int(s[5]), alignments=int(s[6]), kernel_ns=int(s[7]))
+    return {name: int(s[i]) for i, name in STAT_NAMES.items()}

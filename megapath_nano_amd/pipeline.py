@@ -1,0 +1,57 @@
+"""Integer-coded fast path of the reference's step 3 (`step_placement_to_species`,
+/root/reference/bin/megapath_nano.py:1253-1310): Align (:1262) -> Reassign (:1281) -> best alignment per read
+(:1287) -> aligned bp per species (:1289) -> reads per name (:3664-3667), without going through DataFrames.
+The DataFrame-level mirrors (aligner.Align, reassignment.Reassign) call the same C-ABI entry points; this module is
+what bench.py times and what a multi-GPU run executes per rank.
+"""
+import random
+
+import numpy as np
+
+from . import mapper
+from .reassignment import ReassignPlan
+
+
+class Taxonomy:
+    """Per target sequence: dense species-name code (reassignment.py:69-71) and dense species_tax_id code."""
+
+    def __init__(self, name_code, n_names, species_code, n_species):
+        self.name_code = np.asarray(name_code, dtype=np.int32)
+        self.species_code = np.asarray(species_code, dtype=np.int32)
+        self.n_names, self.n_species = int(n_names), int(n_species)
+
+
+def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_threshold=0.0, min_alignment_score=0,
+                     allreduce=None, rng=None, reassign=True):
+    """One step of the hot path for one batch of reads.  Returns dict(read_count, aligned_bp, n_rows, n_relations)."""
+    _, c = mapper.map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True)
+    keep = c['as_'] >= min_alignment_score                                   # aligner.py:311-312
+    read_idx = c['read_idx'][keep]
+    rid = c['rid'][keep]
+    score = c['as_'][keep]
+    aligned_bp = (c['re'][keep] - c['rs'][keep]).astype(np.int64)
+    n_rows = len(read_idx)
+    rnd = rng if rng is not None else random
+    tiebreak = np.fromiter((rnd.random() for _ in range(n_rows)), dtype=np.float64, count=n_rows)  # aligner.py:334-335
+    read_count = np.zeros(tax.n_names, dtype=np.int64)
+    bp = np.zeros(tax.n_species, dtype=np.int64)
+    nrel = 0
+    if n_rows:
+        plan = ReassignPlan(read_idx, tax.name_code[rid], score, tiebreak, aligned_bp, tax.species_code[rid], tax.n_names,
+                            tax.n_species)
+        try:
+            all_count, u_count, n_multi = plan.counts()
+            if allreduce is not None:
+                allreduce(all_count), allreduce(u_count), allreduce(n_multi)
+            rank = np.arange(tax.n_names, dtype=np.int32)
+            if not reassign:  # --no-reassignment: an empty relation leaves every name untouched
+                error_rate = -1.0
+            _, _, _, read_count, bp, nrel = plan.apply(all_count, u_count, rank, error_rate, ratio, as_threshold)
+        finally:
+            plan.close()
+    elif allreduce is not None:
+        z = np.zeros(tax.n_names, dtype=np.int64)
+        allreduce(z), allreduce(z.copy()), allreduce(np.zeros(1, dtype=np.int64))
+    if allreduce is not None:
+        allreduce(read_count), allreduce(bp)                                 # the taxon-count all-reduce
+    return dict(read_count=read_count, aligned_bp=bp, n_rows=n_rows, n_relations=nrel)
