@@ -26,7 +26,7 @@ namespace mpn {
 int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32_t *seq_len, DevBuf<uint8_t> &d_seqs,
                 DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st);
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
-                      const int32_t *d_len, SeedChainOut &o, hipStream_t st);
+                      const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st);
 int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st);
 
 static const int PARENT_UNSET = -1, PARENT_TMP_PRI = -2;
@@ -632,8 +632,8 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
         const ExtRes &e = res[job];
         const ExtJob &j = jobs[job];
         *n = e.n_cigar;
-        if (j.flag & EZ_REV_CIGAR) return cig_pool + (j.cig_off - (j.qlen + j.tlen + 2));
-        return cig_pool + (j.cig_off - e.n_cigar);
+        (void)j;
+        return cig_pool + e.cig_pos;
     };
     bool has_r2 = false;
     int32_t rs = pl.rs, qs = pl.qs, rs1, qs1, re1, qe1, dropped = 0;
@@ -794,18 +794,31 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
         order[cls].push_back(j);
     }
     g_stats[4] += nj; g_stats[5] += cells;
-    DevBuf<ExtJob> d_jobs;
-    DevBuf<uint8_t> P;
-    DevBuf<int32_t> OFF, d_order;
-    DevBuf<int8_t> gstate;
-    DevBuf<uint32_t> CIG;
-    DevBuf<ExtRes> d_res;
+    static PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_gap, pool_redo, pool_compact, pool_used;
+    static PoolBuf pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     std::vector<int32_t> flat;
     int base[5];
     for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
-    if (d_jobs.upload(jobs.data(), nj, st) || P.alloc((size_t)p_tot) || OFF.alloc((size_t)row_tot * 2) || gstate.alloc((size_t)state_tot) ||
-        CIG.alloc((size_t)cig_tot) || d_res.alloc(nj) || d_order.upload(flat.data(), flat.size(), st))
+    if (pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || pool_P.ensure((size_t)p_tot) || pool_OFF.ensure((size_t)row_tot * 2 * 4) ||
+        pool_state.ensure((size_t)state_tot) || pool_CIG.ensure((size_t)cig_tot * 4) || pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
+        pool_order.ensure(flat.size() * 4) || pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
+        pool_used.ensure(16))
         return -1;
+    struct View { ExtJob *jobs; uint8_t *P; int32_t *OFF; int8_t *state; uint32_t *CIG; ExtRes *res; int32_t *order; };
+    View d{pool_jobs.as<ExtJob>(), pool_P.as<uint8_t>(), pool_OFF.as<int32_t>(), pool_state.as<int8_t>(), pool_CIG.as<uint32_t>(),
+           pool_res.as<ExtRes>(), pool_order.as<int32_t>()};
+    MPN_HIP_CHECK(hipMemsetAsync(pool_used.p, 0, 16, st));
+    uint32_t *d_compact = pool_compact.as<uint32_t>();
+    unsigned long long *d_used = pool_used.as<unsigned long long>();
+    MPN_HIP_CHECK(hipMemcpyAsync(d.jobs, jobs.data(), (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(d.order, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, st));
+    struct { ExtJob *p; } d_jobs{d.jobs};
+    struct { uint8_t *p; } P{d.P};
+    struct { int32_t *p; } OFF{d.OFF};
+    struct { int8_t *p; } gstate{d.state};
+    struct { uint32_t *p; } CIG{d.CIG};
+    struct { ExtRes *p; } d_res{d.res};
+    struct { int32_t *p; } d_order{d.order};
     ExtParams prm;
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
@@ -821,21 +834,23 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
     for (int c = 0; c < 5; ++c)
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
     ev.stop_into(g_stats[15]);
-    hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_res.p);
+    hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.stop_into(g_stats[25]);
     // z-drop test of the gap-fill CIGARs; flagged jobs are recomputed with the exact maximum
     std::vector<int32_t> gap;
     for (int j = 0; j < nj; ++j) if ((jobs[j].flag & EZ_APPROX_MAX)) gap.push_back(j);
     if (!gap.empty()) {
-        DevBuf<int32_t> d_gap;
-        if (d_gap.upload(gap.data(), gap.size(), st)) return -1;
+        if (pool_gap.ensure(gap.size() * 4)) return -1;
+        struct { int32_t *p; } d_gap{pool_gap.as<int32_t>()};
+        MPN_HIP_CHECK(hipMemcpyAsync(d_gap.p, gap.data(), gap.size() * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(ext_ztest_kernel, dim3(((int)gap.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_gap.p, (int)gap.size(), prm,
                            d_reads, d_read_off, d_read_len, idx->d_seq4.p, idx->d_seq_off.p, CIG.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.stop_into(g_stats[26]);
-        if (d_res.download(res.data(), nj, st)) return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(hipStreamSynchronize(st));
+        memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
         std::vector<int32_t> redo[5];
         std::vector<int32_t> redo_flat;
         for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; }
@@ -844,21 +859,30 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
         for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }
         g_stats[8] += (int64_t)redo_flat.size();
         if (!redo_flat.empty()) {
-            DevBuf<int32_t> d_redo;
-            if (d_jobs.upload(jobs.data(), nj, st) || d_redo.upload(redo_flat.data(), redo_flat.size(), st)) return -1;
+            if (pool_redo.ensure(redo_flat.size() * 4)) return -1;
+            struct { int32_t *p; } d_redo{pool_redo.as<int32_t>()};
+            MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
+            MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, redo_flat.data(), redo_flat.size() * 4, hipMemcpyHostToDevice, st));
             EvTimer ev2(st);
             for (int c = 0; c < 5; ++c)
                 if (launch_dp(d_redo.p + rbase[c], (int)redo[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
             ev2.stop_into(g_stats[15]);
             hipLaunchKernelGGL(ext_bt_kernel, dim3(((int)redo_flat.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p,
-                               (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_res.p);
+                               (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
             MPN_HIP_CHECK(hipGetLastError());
             ev2.stop_into(g_stats[25]);
         }
     }
-    cig.resize((size_t)cig_tot);
-    if (d_res.download(res.data(), nj, st) || CIG.download(cig.data(), (size_t)cig_tot, st)) return -1;
+    MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync((char *)pin_res.p + (size_t)nj * sizeof(ExtRes), d_used, 8, hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
+    unsigned long long used = 0;
+    memcpy(&used, (char *)pin_res.p + (size_t)nj * sizeof(ExtRes), 8);
+    if (pin_cig.ensure((size_t)used * 4 + 16)) return -1;
+    if (used) MPN_HIP_CHECK(hipMemcpyAsync(pin_cig.p, d_compact, (size_t)used * 4, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    cig.assign((const uint32_t *)pin_cig.p, (const uint32_t *)pin_cig.p + used);
     return 0;
 }
 
@@ -887,7 +911,7 @@ static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<Ex
         std::vector<uint32_t> csub;
         if (run_job_group(idx, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
         const int64_t base = (int64_t)cig.size();
-        for (int k = 0; k < hi - lo; ++k) { sub[k].cig_off += base; jobs[lo + k] = sub[k]; res[lo + k] = rsub[k]; }
+        for (int k = 0; k < hi - lo; ++k) { rsub[k].cig_pos += base; jobs[lo + k] = sub[k]; res[lo + k] = rsub[k]; }
         cig.insert(cig.end(), csub.begin(), csub.end());
         lo = hi;
     }
@@ -927,7 +951,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     HostChains h;
     {
         SeedChainOut o;
-        if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, o, st)) return -1;
+        if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
         wt.stop_into(g_stats[17]);
         if (download_chains(n, o, h, st)) return -1;
         wt.stop_into(g_stats[18]);

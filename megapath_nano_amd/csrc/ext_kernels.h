@@ -33,6 +33,7 @@ struct ExtJob {
 
 struct ExtRes {
     int32_t max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar, r_done, bt_i, bt_j, do_bt, zcode;
+    int64_t cig_pos;  // start of the ops in the compact pool (forward order)
 };
 
 struct ExtParams {
@@ -232,13 +233,14 @@ __global__ __launch_bounds__(64) void ext_dp_kernel(const ExtJob *__restrict__ j
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
 __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                     const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
-                                                    uint32_t *__restrict__ CIG, ExtRes *__restrict__ res) {
+                                                    uint32_t *__restrict__ CIG, uint32_t *__restrict__ COMPACT,
+                                                    unsigned long long *__restrict__ compact_used, ExtRes *__restrict__ res) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
     const int jid = order[k];
     const ExtJob jb = jobs[jid];
     ExtRes r = res[jid];
-    if (!r.do_bt) { return; }
+    if (!r.do_bt) { res[jid].cig_pos = 0; return; }
     const int n_col = jb.n_col, n_r = jb.qlen + jb.tlen - 1;
     const uint8_t *p = P + jb.p_off;
     const int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
@@ -271,7 +273,12 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     MPN_FLUSH();
 #undef MPN_PUSHOP
 #undef MPN_FLUSH
+    // hand the ops over in forward order through a compact pool, so that only used entries travel to the host
+    const unsigned long long pos = n ? atomicAdd(compact_used, (unsigned long long)n) : 0ULL;
+    const uint32_t *src = rev_cigar ? cbeg : cend - n;
+    for (int q = 0; q < n; ++q) COMPACT[pos + q] = src[q];
     res[jid].n_cigar = n;
+    res[jid].cig_pos = (int64_t)pos;
 }
 
 // z-drop test of a finished gap-fill CIGAR (minimap2 mm_test_zdrop without the inversion probe): one lane per job

@@ -25,86 +25,116 @@ __device__ __forceinline__ uint64_t hash64m(uint64_t key, uint64_t mask) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// (w,k)-minimizers, one lane per sequence: the window automaton of minimap2's sketch (ring of the last w
-// non-symmetric k-mers; ties to the newest; identical minima all reported) is inherently sequential per
-// sequence, so parallelism comes from the batch.  The ring lives in LDS as [slot][thread] (conflict-free).
-// FILL=false counts, FILL=true writes at mz_off[i].
+// (w,k)-minimizers, one lane per CHUNK of a sequence.  minimap2's sketch is a sequential window automaton
+// (ring of the last w non-symmetric k-mers; ties go to the newest; identical minima are all reported; the run
+// length l since the last ambiguous base gates the output).  Its state at position p0 depends only on the last
+// w + k - 1 window elements and on min(l, w + k), so a lane reconstructs it exactly by replaying a short
+// warm-up [p0 - D, p0) from the reset state without emitting: if the warm-up holds an ambiguous base the
+// automaton was reset there anyway; otherwise l reached w + k inside the warm-up, i.e. it is saturated in the
+// true run as well (for even k, where symmetric k-mers do not advance l, D is doubled until that holds).
+// The ring lives in LDS as [slot][thread] (conflict-free).  FILL=false counts, FILL=true writes.
 template <bool FILL>
-__global__ __launch_bounds__(64) void sketch_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
-                                                    const int32_t *__restrict__ seq_len, int n, int w, int k,
-                                                    const int64_t *__restrict__ mz_off, int64_t *__restrict__ mz_cnt,
-                                                    u128 *__restrict__ mz, uint32_t rid_base) {
+__global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
+                                                          const int32_t *__restrict__ seq_len, int n,
+                                                          const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
+                                                          const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
+                                                          int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base) {
     extern __shared__ __attribute__((aligned(16))) uint64_t ring[];  // bx[w][64] then by[w][64]
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * blockDim.x + tid;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + tid;
     uint64_t *bx = ring, *by = ring + (size_t)w * blockDim.x;
-    if (i >= n) return;
+    if (c >= n_chunks) return;
+    int lo = 0, hi = n;  // last read with chunk_off[read] <= c
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
+    const int i = lo;
     const uint8_t *s = seqs + seq_off[i];
     const int len = seq_len[i];
+    const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
     const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
-    uint64_t kmer0 = 0, kmer1 = 0, minx = ~0ULL, miny = ~0ULL;
-    int l = 0, buf_pos = 0, min_pos = 0;
-    int64_t cnt = 0;
-    u128 *out = FILL ? mz + mz_off[i] : nullptr;
+    const int lsat = w + k;
     const uint32_t rid = rid_base + (uint32_t)i;
-#define MPN_PUSH(X, Y) do { if (FILL) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } while (0)
-    for (int j = 0; j < w; ++j) bx[j * blockDim.x + tid] = ~0ULL, by[j * blockDim.x + tid] = ~0ULL;
-    for (int p = 0; p < len; ++p) {
-        const int c = nt4_code(s[p]);
-        uint64_t ix = ~0ULL, iy = ~0ULL;
-        if (c < 4) {
-            const int kmer_span = l + 1 < k ? l + 1 : k;
-            kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
-            kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
-            if (kmer0 == kmer1) continue;
-            const int z = kmer0 < kmer1 ? 0 : 1;
-            ++l;
-            if (l >= k) {
-                ix = hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
-                iy = (uint64_t)rid << 32 | (uint32_t)p << 1 | (uint32_t)z;
-            }
-        } else l = 0;
-        bx[buf_pos * blockDim.x + tid] = ix, by[buf_pos * blockDim.x + tid] = iy;
-        if (l == w + k - 1 && minx != ~0ULL) {
-            for (int j = buf_pos + 1; j < w; ++j) {
-                uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
-                if (minx == x && y != miny) MPN_PUSH(x, y);
-            }
-            for (int j = 0; j < buf_pos; ++j) {
-                uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
-                if (minx == x && y != miny) MPN_PUSH(x, y);
-            }
-        }
-        if (ix <= minx) {
-            if (l >= w + k && minx != ~0ULL) MPN_PUSH(minx, miny);
-            minx = ix, miny = iy, min_pos = buf_pos;
-        } else if (buf_pos == min_pos) {
-            if (l >= w + k - 1 && minx != ~0ULL) MPN_PUSH(minx, miny);
-            minx = ~0ULL;
-            for (int j = buf_pos + 1; j < w; ++j) {
-                uint64_t x = bx[j * blockDim.x + tid];
-                if (minx >= x) minx = x, miny = by[j * blockDim.x + tid], min_pos = j;
-            }
-            for (int j = 0; j <= buf_pos; ++j) {
-                uint64_t x = bx[j * blockDim.x + tid];
-                if (minx >= x) minx = x, miny = by[j * blockDim.x + tid], min_pos = j;
-            }
-            if (l >= w + k - 1 && minx != ~0ULL) {
+    int64_t cnt = 0;
+    u128 *out = FILL ? mz + mz_off[i] + chunk_rel[c] : nullptr;
+#define MPN_PUSH(X, Y) do { if (emit) { if (FILL) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } } while (0)
+    int D = w + k + 8;
+    for (;;) {
+        const int ps = max(0, p0 - D);
+        uint64_t kmer0 = 0, kmer1 = 0, minx = ~0ULL, miny = ~0ULL;
+        int l = 0, buf_pos = 0, min_pos = 0;
+        bool saw_n = false, redo = false;
+        for (int j = 0; j < w; ++j) bx[j * blockDim.x + tid] = ~0ULL, by[j * blockDim.x + tid] = ~0ULL;
+        for (int p = ps; p < p1; ++p) {
+            if (p == p0 && ps > 0 && !saw_n && l < lsat) { redo = true; break; }  // warm-up too short (even k only)
+            const bool emit = p >= p0;
+            const int cc = nt4_code(s[p]);
+            uint64_t ix = ~0ULL, iy = ~0ULL;
+            if (cc < 4) {
+                const int kmer_span = l + 1 < k ? l + 1 : k;
+                kmer0 = (kmer0 << 2 | (uint64_t)cc) & mask;
+                kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)cc) << shift1;
+                if (kmer0 == kmer1) continue;
+                const int z = kmer0 < kmer1 ? 0 : 1;
+                if (l < lsat) ++l;
+                if (l >= k) {
+                    ix = hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+                    iy = (uint64_t)rid << 32 | (uint32_t)p << 1 | (uint32_t)z;
+                }
+            } else { l = 0; if (!emit) saw_n = true; }
+            bx[buf_pos * blockDim.x + tid] = ix, by[buf_pos * blockDim.x + tid] = iy;
+            if (l == w + k - 1 && minx != ~0ULL) {
                 for (int j = buf_pos + 1; j < w; ++j) {
                     uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
-                    if (minx == x && miny != y) MPN_PUSH(x, y);
+                    if (minx == x && y != miny) MPN_PUSH(x, y);
                 }
-                for (int j = 0; j <= buf_pos; ++j) {
+                for (int j = 0; j < buf_pos; ++j) {
                     uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
-                    if (minx == x && miny != y) MPN_PUSH(x, y);
+                    if (minx == x && y != miny) MPN_PUSH(x, y);
                 }
             }
+            if (ix <= minx) {
+                if (l >= w + k && minx != ~0ULL) MPN_PUSH(minx, miny);
+                minx = ix, miny = iy, min_pos = buf_pos;
+            } else if (buf_pos == min_pos) {
+                if (l >= w + k - 1 && minx != ~0ULL) MPN_PUSH(minx, miny);
+                minx = ~0ULL;
+                for (int j = buf_pos + 1; j < w; ++j) {
+                    uint64_t x = bx[j * blockDim.x + tid];
+                    if (minx >= x) minx = x, miny = by[j * blockDim.x + tid], min_pos = j;
+                }
+                for (int j = 0; j <= buf_pos; ++j) {
+                    uint64_t x = bx[j * blockDim.x + tid];
+                    if (minx >= x) minx = x, miny = by[j * blockDim.x + tid], min_pos = j;
+                }
+                if (l >= w + k - 1 && minx != ~0ULL) {
+                    for (int j = buf_pos + 1; j < w; ++j) {
+                        uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
+                        if (minx == x && miny != y) MPN_PUSH(x, y);
+                    }
+                    for (int j = 0; j <= buf_pos; ++j) {
+                        uint64_t x = bx[j * blockDim.x + tid], y = by[j * blockDim.x + tid];
+                        if (minx == x && miny != y) MPN_PUSH(x, y);
+                    }
+                }
+            }
+            if (++buf_pos == w) buf_pos = 0;
         }
-        if (++buf_pos == w) buf_pos = 0;
+        if (redo) { D *= 2; cnt = 0; continue; }
+        if (p1 == len && minx != ~0ULL) { const bool emit = true; MPN_PUSH(minx, miny); }
+        break;
     }
-    if (minx != ~0ULL) MPN_PUSH(minx, miny);
 #undef MPN_PUSH
-    if (!FILL) mz_cnt[i] = cnt;
+    if (!FILL) chunk_cnt[c] = (int32_t)cnt;
+}
+
+// per sequence (one lane): offsets of its chunks' minimizers relative to the sequence start, and the total
+__global__ __launch_bounds__(256) void sketch_chunk_prefix_kernel(const int64_t *__restrict__ chunk_off, int n,
+                                                                  const int32_t *__restrict__ chunk_cnt,
+                                                                  int32_t *__restrict__ chunk_rel, int64_t *__restrict__ mz_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t run = 0;
+    for (int64_t c = chunk_off[i]; c < chunk_off[i + 1]; ++c) { chunk_rel[c] = run; run += chunk_cnt[c]; }
+    mz_cnt[i] = run;
 }
 
 // exclusive scan of n int64 by ONE block (n is the number of reads of a batch: small); out[n] = total

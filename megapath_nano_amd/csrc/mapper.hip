@@ -17,26 +17,40 @@ static int grid_1d(int64_t n, int block, int cap = 256 * 16) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// sketch a batch that is already on the device; fills mz_off (device, n+1) and allocates mz
-int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len, int n, int k, int w,
+// sketch a batch that is already on the device; fills mz_off (device, n+1) and allocates mz.
+// h_len: host copy of the sequence lengths (chunk table).
+int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len, const int32_t *h_len, int n, int k, int w,
                   uint32_t rid_base, DevBuf<int64_t> &mz_off, DevBuf<u128> &mz, int64_t *n_mz, hipStream_t st) {
-    DevBuf<int64_t> cnt;
-    if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1)) return -1;
+    const int C = 256;
+    std::vector<int64_t> chunk_off((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) chunk_off[i + 1] = chunk_off[i] + (h_len[i] + C - 1) / C;
+    const int64_t n_chunks = chunk_off[n];
+    DevBuf<int64_t> cnt, d_chunk_off;
+    DevBuf<int32_t> chunk_cnt, chunk_rel;
+    if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1) || d_chunk_off.upload(chunk_off.data(), (size_t)n + 1, st) ||
+        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks))
+        return -1;
     const size_t lds = (size_t)2 * w * 64 * sizeof(uint64_t);
-    if (n > 0) {
-        hipLaunchKernelGGL(sketch_kernel<false>, dim3((n + 63) / 64), dim3(64), lds, st, d_seqs, d_off, d_len, n, w, k,
-                           (const int64_t *)nullptr, cnt.p, (u128 *)nullptr, rid_base);
+    const unsigned grid = (unsigned)((n_chunks + 63) / 64);
+    if (n_chunks > 0) {
+        hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(grid), dim3(64), lds, st, d_seqs, d_off, d_len, n,
+                           (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, (const int64_t *)nullptr, (const int32_t *)nullptr,
+                           chunk_cnt.p, (u128 *)nullptr, rid_base);
         MPN_HIP_CHECK(hipGetLastError());
     }
+    hipLaunchKernelGGL(sketch_chunk_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)d_chunk_off.p, n,
+                       (const int32_t *)chunk_cnt.p, chunk_rel.p, cnt.p);
+    MPN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, cnt.p, mz_off.p, n);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t total = 0;
     MPN_HIP_CHECK(hipMemcpyAsync(&total, mz_off.p + n, 8, hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(hipStreamSynchronize(st));
     if (mz.alloc((size_t)total)) return -1;
-    if (n > 0 && total > 0) {
-        hipLaunchKernelGGL(sketch_kernel<true>, dim3((n + 63) / 64), dim3(64), lds, st, d_seqs, d_off, d_len, n, w, k,
-                           (const int64_t *)mz_off.p, (int64_t *)nullptr, mz.p, rid_base);
+    if (n_chunks > 0 && total > 0) {
+        hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(grid), dim3(64), lds, st, d_seqs, d_off, d_len, n,
+                           (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, (const int64_t *)mz_off.p, (const int32_t *)chunk_rel.p,
+                           (int32_t *)nullptr, mz.p, rid_base);
         MPN_HIP_CHECK(hipGetLastError());
     }
     *n_mz = total;
@@ -60,12 +74,12 @@ int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32
 
 // seeds -> sorted anchors -> chains for a batch resident on the device
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
-                      const int32_t *d_len, SeedChainOut &o, hipStream_t st) {
+                      const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st) {
     int64_t n_mz = 0;
     DevBuf<int64_t> mz_off;
     DevBuf<u128> mz;
     EvTimer ev(st);
-    if (sketch_device(d_seqs, d_off, d_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st)) return -1;
+    if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st)) return -1;
     ev.stop_into(g_stats[10]);
     g_stats[1] += n_mz;
     const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
@@ -238,7 +252,7 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
     DevBuf<int64_t> mz_off;
     DevBuf<u128> mz;
     int64_t n_mz = 0;
-    if (sketch_device(d_seqs.p, d_off.p, d_len.p, n_seq, k, w, 0, mz_off, mz, &n_mz, st)) return fail();
+    if (sketch_device(d_seqs.p, d_off.p, d_len.p, lens, n_seq, k, w, 0, mz_off, mz, &n_mz, st)) return fail();
     std::vector<u128> h((size_t)n_mz);
     if (mz.download(h.data(), (size_t)n_mz, st)) return fail();
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: sync failed"); return fail(); }
@@ -296,7 +310,7 @@ int64_t mpn_sketch_batch(int32_t n, const char *seqs, const int64_t *seq_off, co
     DevBuf<u128> d_mz;
     int64_t bases = 0, n_mz = 0;
     if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
-    if (sketch_device(d_seqs.p, d_off.p, d_len.p, n, k, w, 0, d_mz_off, d_mz, &n_mz, st)) return -1;
+    if (sketch_device(d_seqs.p, d_off.p, d_len.p, seq_len, n, k, w, 0, d_mz_off, d_mz, &n_mz, st)) return -1;
     if (d_mz_off.download(mz_off, (size_t)n + 1, st)) return -1;
     if (n_mz <= cap && d_mz.download((u128 *)mz, (size_t)n_mz, st)) return -1;
     MPN_HIP_CHECK(hipStreamSynchronize(st));
@@ -315,7 +329,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
     g_stats[0] = bases;
     SeedChainOut o;
-    if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, o, st)) return -1;
+    if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
     HostChains h;
     if (download_chains(n, o, h, st)) return -1;
     for (int i = 0; i < n; ++i) { n_anchor[i] = h.anchor_off[i + 1] - h.anchor_off[i]; rep_len[i] = h.rep_len[i]; }

@@ -65,6 +65,24 @@ struct EvTimer {
     ~EvTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
+// Grow-only device / pinned-host scratch that survives across calls (hipMalloc of multi-GB scratch per batch costs
+// more than the kernels that use it).  One pool per process; the mapper entry points are not re-entrant.
+struct PoolBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned_host = false;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 4096;
+        if (pinned_host) MPN_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        else MPN_HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
 struct WallTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void stop_into(int64_t &acc) {
