@@ -1,0 +1,105 @@
+"""CPU tests (no GPU): host-side logic of the mirrors -- minimap2 argv parsing, FASTA/FASTQ readers, species-name
+rule, shard balancing -- and the N>1 plumbing with world_size-2 gloo processes."""
+import gzip
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_species_name_rule_matches_reference_lambda():
+    from megapath_nano_amd.reassignment import species_name
+    ref = lambda x: " ".join(x.split(" ", 2)[0:2]) if ' sp. ' not in x else " ".join(x.split(" ", 3)[0:3])  # noqa: E731
+    for d in ['Escherichia coli strain K-12 substr. MG1655, complete genome', 'Bacillus sp. X1(2014) chromosome', 'Plasmid',
+              'A b', 'Candidatus Pelagibacter sp. HTCC7211 x', '']:
+        assert species_name(d, 'species') == ref(d)
+        assert species_name(d, 'strain') == d
+
+
+def test_parse_aligner_options(libmpn):
+    from megapath_nano_amd.aligner import parse_aligner_options
+    opt, k, w = parse_aligner_options(['-t', '64', '-I', '0G', '-N', '50', '-p', '1', '-x', 'map-ont', '--split-prefix', 'tmp'], False)
+    assert (opt.best_n, opt.pri_ratio, opt.with_cigar, k, w) == (50, 1.0, 1, 15, 10)
+    opt, k, w = parse_aligner_options(['-t8', '-x', 'map-ont'], True)
+    assert (opt.best_n, round(opt.pri_ratio, 3), opt.with_cigar) == (5, 0.8, 0)
+    opt, k, w = parse_aligner_options(['-k15', '-w15', '-A1', '-B4', '-O1', '-E2', '-s50', '-z50', '-N', '1000', '-p', '0'], False)
+    assert (k, w, opt.a, opt.b, opt.q, opt.e, opt.min_dp_max, opt.zdrop, opt.best_n, opt.pri_ratio) == (15, 15, 1, 4, 1, 2, 50, 50, 1000, 0.0)
+    with pytest.raises(ValueError):
+        parse_aligner_options(['-x', 'sr'], False)
+
+
+def test_read_fastx(tmp_path):
+    from megapath_nano_amd.aligner import read_fastx
+    fa = tmp_path / 'a.fna.gz'
+    with gzip.open(fa, 'wb') as f:
+        f.write(b'>s1 desc\nACGT\nAC\n>s2\nTTTT\n')
+    with gzip.open(fa, 'ab') as f:  # concatenated gzip members, as `cat *.fna.gz` into the FIFO (aligner.py:209-217)
+        f.write(b'>s3\nGG\n')
+    assert read_fastx(str(fa)) == [('s1', b'ACGTAC'), ('s2', b'TTTT'), ('s3', b'GG')]
+    fq = tmp_path / 'r.fq'
+    fq.write_bytes(b'@r1 x\nACGT\n+\nIIII\n@r2\nAC\nGT\n+r2\n@@\n@I\n')
+    assert read_fastx(str(fq)) == [('r1', b'ACGT'), ('r2', b'ACGT')]
+
+
+def test_shard_bounds_balance_bases():
+    from megapath_nano_amd.dist import shard_bounds
+    rng = np.random.default_rng(0)
+    lens = rng.integers(200, 50000, size=1000)
+    for world in (1, 2, 3, 8):
+        b = shard_bounds(lens, world)
+        assert b[0][0] == 0 and b[-1][1] == len(lens) and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sums = [int(lens[lo:hi].sum()) for lo, hi in b]
+        assert max(sums) - min(sums) <= 2 * int(lens.max())
+    assert shard_bounds([], 4) == [(0, 0)] * 4
+
+
+GLOO_WORKER = textwrap.dedent('''
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    from megapath_nano_amd import dist as mdist
+    rank, world, local = mdist.init_from_env(backend='gloo')
+    ar = mdist.make_allreduce(None)
+    # two-shard decomposition of the counters around the reassignment pass: the oracle stands in for the HIP
+    # kernels here (CPU test of the orchestration only)
+    sys.path.insert(0, os.path.join(%r, 'tests'))
+    from reassign_cases import community, SPECIES
+    from oracle import reassign_oracle as ro
+    table = community(5, 600, [50, 0, 2, 1, 30, 0, 0, 0, 0, 0, 0, 0], {0: [(2, 0.5), (3, 0.3)], 2: [(0, 0.9)], 3: [(0, 0.9)]})
+    reads = sorted(set(table['read_id']))
+    lo, hi = mdist.shard_bounds([1] * len(reads), world)[rank]
+    mine = set(reads[lo:hi])
+    keep = [i for i, r in enumerate(table['read_id']) if r in mine]
+    part = {k: [v[i] for i in keep] for k, v in table.items()}
+    res = ro.reassign_oracle(part, SPECIES)
+    names = sorted({ro.species_name(d, 'species') for _, d in SPECIES})
+    code = {n: i for i, n in enumerate(names)}
+    local_counts = np.zeros(len(names), dtype=np.int64)
+    for n, c in ro.read_count_by_name(part, res['rows']).items():
+        local_counts[code[n]] += c
+    total = local_counts.copy()
+    ar(total)
+    mdist.barrier()
+    with open(os.path.join(os.environ['MPN_TEST_OUT'], f'rank{rank}.json'), 'w') as f:
+        json.dump(dict(rank=rank, local=int(local_counts.sum()), total=[int(x) for x in total], n_reads=len(reads)), f)
+''')
+
+
+def test_gloo_world2_count_allreduce(tmp_path, oracle_built):
+    script = tmp_path / 'worker.py'
+    script.write_text(GLOO_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MPN_TEST_OUT=str(tmp_path))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    lines = [json.load(open(tmp_path / f'rank{r}.json')) for r in range(2)]
+    assert sorted(l['rank'] for l in lines) == [0, 1]
+    assert lines[0]['total'] == lines[1]['total']
+    assert sum(lines[0]['total']) == lines[0]['n_reads'] == lines[0]['local'] + lines[1]['local']
