@@ -98,11 +98,18 @@ def main():
     import torch
     from megapath_nano_amd import dist as mdist, mapper
     from megapath_nano_amd.pipeline import align_and_assign
-    rank, world, local = mdist.init_from_env()
+    # MPN_DIST_BACKEND=gloo + MPN_SINGLE_DEVICE=1 rehearses the N>1 code path on a one-GPU box (all ranks on cuda:0,
+    # counters reduced over gloo); the driver's real runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get('MPN_DIST_BACKEND') or None
+    single = os.environ.get('MPN_SINGLE_DEVICE') == '1'
+    if single:
+        os.environ['LOCAL_RANK_SAVED'] = os.environ.get('LOCAL_RANK', '0')
+    rank, world, local = mdist.init_from_env(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
-    device = torch.device('cuda', local if world > 1 else 0)
+    device = torch.device('cuda', 0 if (world == 1 or single) else local)
     torch.cuda.set_device(device)
+    red_device = None if backend == 'gloo' else device
     from megapath_nano_amd import build
     if rank == 0:
         build.build()
@@ -115,7 +122,7 @@ def main():
     opt_kw = dict(best_n=50, pri_ratio=1.0)  # megapath_nano.py:1270  -N 50 -p 1 -x map-ont
     opt = mapper.default_opt(**opt_kw)
     opt.mid_occ = idx.mid_occ()
-    allreduce = mdist.make_allreduce(device)
+    allreduce = mdist.make_allreduce(red_device)
     rnd = random.Random(12345 + rank)
 
     total = args.warmup + args.steps
@@ -141,10 +148,11 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        rd = red_device if red_device is not None else 'cpu'
+        t = torch.tensor([dt], dtype=torch.float64, device=rd)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        b = torch.tensor([sum(batches[s][0].bases for s in range(args.warmup, total))], dtype=torch.int64, device=device)
+        b = torch.tensor([sum(batches[s][0].bases for s in range(args.warmup, total))], dtype=torch.int64, device=rd)
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         bases = int(b.item())
     else:

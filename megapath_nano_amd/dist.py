@@ -17,7 +17,7 @@ def init_from_env(backend=None):
         import torch
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+        if backend == 'nccl' and os.environ.get('MPN_SINGLE_DEVICE') != '1':
             torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if not dist.is_initialized():
