@@ -81,6 +81,15 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
                          int64_t *chain_off, uint64_t *u, int64_t u_cap, int64_t *anchor_off, uint64_t *b,
                          int64_t b_cap);
 
+/* ---- stage: the banded dual-affine extension DP on arbitrary pairs of 0..4 code strings (parity tests) -------
+ * flag bits as in ksw2: 0x02 approximate max, 0x08 right-align gaps, 0x40 extension only, 0x80 reversed CIGAR.
+ * force_kernel: 0 = dispatch as mpn_map_batch does, 1 = single-wave LDS kernel, 2 = register kernel where
+ * eligible, 3 = workgroup kernel.  out9[i*9..] = max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar. */
+int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t *qcodes, const int64_t *q_off, const int32_t *q_len,
+                     const uint8_t *tcodes, const int64_t *t_off, const int32_t *t_len, const int32_t *w, const int32_t *zdrop,
+                     const int32_t *end_bonus, const int32_t *flag, int32_t force_kernel, int32_t *out9, uint32_t *cigar_pool,
+                     int64_t cigar_cap, int64_t *cig_off);
+
 /* ---- product call: map a batch of reads, PAF text out ----------------------------------------------------
  * names: n NUL-terminated read names.  paf receives the lines of all reads in input order (NUL terminated).
  * Returns the number of bytes written, or negative error (-3: paf_cap too small). */

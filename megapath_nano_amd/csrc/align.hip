@@ -759,17 +759,23 @@ static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *nam
 }
 
 // run one group of DP jobs on the GPU (its scratch fits the budget)
-static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vector<ExtJob> &jobs, const uint8_t *d_reads,
-                    const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res, std::vector<uint32_t> &cig,
-                    hipStream_t st) {
+static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel
+
+static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
+                         const uint8_t *d_reads, const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res,
+                         std::vector<uint32_t> &cig, hipStream_t st) {
     const int nj = (int)jobs.size();
     res.assign(nj, ExtRes());
     if (nj == 0) return 0;
     // scratch layout + size classes (LDS need)
     int64_t p_tot = 0, row_tot = 0, cig_tot = 0, state_tot = 0;
-    std::vector<int32_t> order[5];
+    std::vector<int32_t> order[5];   // first pass through the LDS-state kernel, by LDS size class
+    std::vector<int32_t> wg_order[5];   // large windows: workgroup-per-window kernel, by LDS size class
+    std::vector<int32_t> reg_order[2];  // first pass through the register-resident kernel (gap fills, tlen <= 256 / 512)
+    std::vector<int8_t> use_wg(nj, 0);
+    std::vector<int8_t> lds_cls(nj, 0);
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
-    size_t lds_need_max[5] = {0, 0, 0, 0, 0};
+    size_t lds_need_max[5] = {0, 0, 0, 0, 0}, reg_lds_max[2] = {64, 64};
     int64_t cells = 0;
     for (int j = 0; j < nj; ++j) {
         ExtJob &jb = jobs[j];
@@ -791,14 +797,25 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
             jb.state_mode = 1; jb.state_off = state_tot; state_tot += (int64_t)((stateb + 15) & ~(size_t)15);
             lds_need_max[4] = std::max(lds_need_max[4], seqb);
         } else { jb.state_mode = 0; lds_need_max[cls] = std::max(lds_need_max[cls], seqb + stateb); }
-        order[cls].push_back(j);
+        lds_cls[j] = (int8_t)cls;
+        const bool reg_ok = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
+        use_wg[j] = (int8_t)(g_force_kernel == 3 || (g_force_kernel == 0 && n_col - 1 > 128));
+        if (g_force_kernel == 1) use_wg[j] = 0;
+        if (reg_ok && (g_force_kernel == 0 || g_force_kernel == 2)) {
+            const int rc = jb.tlen <= 256 ? 0 : 1;
+            reg_order[rc].push_back(j);
+            reg_lds_max[rc] = std::max(reg_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
+        } else if (use_wg[j]) wg_order[cls].push_back(j);
+        else order[cls].push_back(j);
     }
     g_stats[4] += nj; g_stats[5] += cells;
     static PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_gap, pool_redo, pool_compact, pool_used;
     static PoolBuf pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     std::vector<int32_t> flat;
-    int base[5];
+    int base[5], reg_base[2], wg_base[5];
     for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
+    for (int c = 0; c < 5; ++c) { wg_base[c] = (int)flat.size(); flat.insert(flat.end(), wg_order[c].begin(), wg_order[c].end()); }
+    for (int c = 0; c < 2; ++c) { reg_base[c] = (int)flat.size(); flat.insert(flat.end(), reg_order[c].begin(), reg_order[c].end()); }
     if (pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || pool_P.ensure((size_t)p_tot) || pool_OFF.ensure((size_t)row_tot * 2 * 4) ||
         pool_state.ensure((size_t)state_tot) || pool_CIG.ensure((size_t)cig_tot * 4) || pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
         pool_order.ensure(flat.size() * 4) || pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
@@ -826,13 +843,36 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
         if (cnt == 0) return 0;
         if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ext_dp_kernel, dim3(cnt), dim3(64), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len,
-                           idx->d_seq4.p, idx->d_seq_off.p, P.p, OFF.p, gstate.p, d_res.p);
+                           d_ref4, d_ref_off, P.p, OFF.p, gstate.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        return 0;
+    };
+    auto launch_wg = [&](const int32_t *ord, int cnt, size_t lds) -> int {
+        if (cnt == 0) return 0;
+        if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ext_dp_wg_kernel<256>, dim3(cnt), dim3(256), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len,
+                           d_ref4, d_ref_off, P.p, OFF.p, gstate.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
         return 0;
     };
     EvTimer ev(st);
+    // the few large windows go first: they are the long pole of the launch sequence
+    for (int c = 4; c >= 0; --c)
+        if (launch_wg(d_order.p + wg_base[c], (int)wg_order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
     for (int c = 0; c < 5; ++c)
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+    if (!reg_order[0].empty()) {
+        hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3((unsigned)reg_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
+                           d_order.p + reg_base[0], (int)reg_order[0].size(), prm, d_reads, d_read_off, d_read_len, d_ref4,
+                           d_ref_off, P.p, OFF.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    if (!reg_order[1].empty()) {
+        hipLaunchKernelGGL(ext_dp_reg_kernel<8>, dim3((unsigned)reg_order[1].size()), dim3(64), reg_lds_max[1], st, d_jobs.p,
+                           d_order.p + reg_base[1], (int)reg_order[1].size(), prm, d_reads, d_read_off, d_read_len, d_ref4,
+                           d_ref_off, P.p, OFF.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
     ev.stop_into(g_stats[15]);
     hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());
@@ -845,18 +885,19 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
         struct { int32_t *p; } d_gap{pool_gap.as<int32_t>()};
         MPN_HIP_CHECK(hipMemcpyAsync(d_gap.p, gap.data(), gap.size() * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(ext_ztest_kernel, dim3(((int)gap.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_gap.p, (int)gap.size(), prm,
-                           d_reads, d_read_off, d_read_len, idx->d_seq4.p, idx->d_seq_off.p, CIG.p, d_res.p);
+                           d_reads, d_read_off, d_read_len, d_ref4, d_ref_off, CIG.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.stop_into(g_stats[26]);
         MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(hipStreamSynchronize(st));
         memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
-        std::vector<int32_t> redo[5];
+        std::vector<int32_t> redo[5], redo_wg[5];
         std::vector<int32_t> redo_flat;
         for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; }
-        for (int c = 0; c < 5; ++c) for (int j : order[c]) if ((res[j].zcode) && !(jobs[j].flag & EZ_APPROX_MAX) && !(jobs[j].flag & EZ_EXTZ_ONLY)) redo[c].push_back(j);
-        int rbase[5];
+        for (int j : gap) if (res[j].zcode) (use_wg[j] ? redo_wg : redo)[(int)lds_cls[j]].push_back(j);
+        int rbase[5], rwbase[5];
         for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }
+        for (int c = 0; c < 5; ++c) { rwbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo_wg[c].begin(), redo_wg[c].end()); }
         g_stats[8] += (int64_t)redo_flat.size();
         if (!redo_flat.empty()) {
             if (pool_redo.ensure(redo_flat.size() * 4)) return -1;
@@ -866,6 +907,8 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
             EvTimer ev2(st);
             for (int c = 0; c < 5; ++c)
                 if (launch_dp(d_redo.p + rbase[c], (int)redo[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+            for (int c = 0; c < 5; ++c)
+                if (launch_wg(d_redo.p + rwbase[c], (int)redo_wg[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
             ev2.stop_into(g_stats[15]);
             hipLaunchKernelGGL(ext_bt_kernel, dim3(((int)redo_flat.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p,
                                (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
@@ -887,10 +930,10 @@ static int run_job_group(const mpn_index *idx, const mpn_map_opt *opt, std::vect
 }
 
 // run all DP jobs of one round, in groups whose direction scratch stays under the budget
-static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<ExtJob> &jobs, const uint8_t *d_reads,
-                    const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res, std::vector<uint32_t> &cig,
-                    hipStream_t st) {
-    const int64_t budget = (int64_t)16 << 30;  // bytes of direction codes per group
+static int run_jobs(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
+                    const uint8_t *d_reads, const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res,
+                    std::vector<uint32_t> &cig, hipStream_t st) {
+    const int64_t budget = (int64_t)40 << 30;  // bytes of direction codes per group
     const int nj = (int)jobs.size();
     res.assign(nj, ExtRes());
     cig.clear();
@@ -909,7 +952,7 @@ static int run_jobs(const mpn_index *idx, const mpn_map_opt *opt, std::vector<Ex
         std::vector<ExtJob> sub(jobs.begin() + lo, jobs.begin() + hi);
         std::vector<ExtRes> rsub;
         std::vector<uint32_t> csub;
-        if (run_job_group(idx, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
+        if (run_job_group(d_ref4, d_ref_off, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
         const int64_t base = (int64_t)cig.size();
         for (int k = 0; k < hi - lo; ++k) { rsub[k].cig_pos += base; jobs[lo + k] = sub[k]; res[lo + k] = rsub[k]; }
         cig.insert(cig.end(), csub.begin(), csub.end());
@@ -990,10 +1033,10 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     if (opt->with_cigar) {
         for (int round = 0; round < 64; ++round) {
             wt.stop_into(g_stats[23]);
-            // plan (serial append into one job list keeps job ids deterministic)
-            JobSink sink;
-            bool any = false;
-            for (int i = 0; i < n; ++i) {
+            // plan: every read fills its own job list in parallel; lists are concatenated in read order, so job ids
+            // do not depend on the thread schedule
+            std::vector<JobSink> sinks(n);
+            parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
                 S.pending.clear(); S.plans.clear();
                 for (int k = 0; k < (int)S.regs.size(); ++k) {
@@ -1002,16 +1045,33 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
                     if (r.cnt == 0) { r.aligned = 1; continue; }
                     S.pending.push_back(k);
                     S.plans.emplace_back();
-                    plan_align(opt, idx, i, seq_len[i], r, S.n_a, S.a.data(), S.plans.back(), sink);
-                    any = true;
+                    plan_align(opt, idx, i, seq_len[i], r, S.n_a, S.a.data(), S.plans.back(), sinks[i]);
                 }
+            });
+            JobSink sink;
+            std::vector<int> job_base(n, 0);
+            {
+                size_t tot = 0;
+                for (int i = 0; i < n; ++i) { job_base[i] = (int)tot; tot += sinks[i].jobs.size(); }
+                sink.jobs.resize(tot);
             }
+            bool any = !sink.jobs.empty();
+            for (int i = 0; i < n && !any; ++i) any = !rs[i].pending.empty();
+            parallel_for(n, n_threads, [&](int i, int) {
+                const int base = job_base[i];
+                if (!sinks[i].jobs.empty()) memcpy(&sink.jobs[base], sinks[i].jobs.data(), sinks[i].jobs.size() * sizeof(ExtJob));
+                for (Plan &pl : rs[i].plans) {
+                    if (pl.left_job >= 0) pl.left_job += base;
+                    if (pl.right_job >= 0) pl.right_job += base;
+                    for (Seg &sg : pl.segs) if (sg.job >= 0) sg.job += base;
+                }
+            });
             wt.stop_into(g_stats[20]);
             if (!any) break;
             ++g_stats[7];
             std::vector<ExtRes> res;
             std::vector<uint32_t> cig;
-            if (run_jobs(idx, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
+            if (run_jobs(idx->d_seq4.p, idx->d_seq_off.p, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
             wt.stop_into(g_stats[21]);
             parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
@@ -1078,4 +1138,51 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
 extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                                  const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap) {
     return mpn_map_batch_ex(idx, opt, n, names, seqs, seq_off, seq_len, nullptr, nullptr, nullptr, paf, paf_cap, nullptr);
+}
+
+// stage entry point for the parity tests: the DP kernels on arbitrary (query, target) code pairs
+extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t *qcodes, const int64_t *q_off, const int32_t *q_len,
+                                const uint8_t *tcodes, const int64_t *t_off, const int32_t *t_len, const int32_t *w,
+                                const int32_t *zdrop, const int32_t *end_bonus, const int32_t *flag, int32_t force_kernel,
+                                int32_t *out9, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *cig_off) {
+    hipStream_t st = 0;
+    if (n <= 0) return 0;
+    int64_t qtot = 0, ttot = 0;
+    for (int i = 0; i < n; ++i) { qtot = std::max<int64_t>(qtot, q_off[i] + q_len[i]); ttot = std::max<int64_t>(ttot, t_off[i] + t_len[i]); }
+    std::vector<uint8_t> ascii((size_t)qtot + 16, 'N');
+    for (int64_t i = 0; i < qtot; ++i) ascii[(size_t)i] = (uint8_t)"ACGTN"[qcodes[i] > 4 ? 4 : qcodes[i]];
+    DevBuf<uint8_t> d_reads, d_ref;
+    DevBuf<int64_t> d_qoff, d_toff;
+    DevBuf<int32_t> d_qlen;
+    if (d_reads.upload(ascii.data(), ascii.size(), st) || d_ref.upload(tcodes, (size_t)ttot, st) || d_qoff.upload(q_off, n, st) ||
+        d_qlen.upload(q_len, n, st) || d_toff.upload(t_off, n, st))
+        return -1;
+    std::vector<ExtJob> jobs(n);
+    for (int i = 0; i < n; ++i) {
+        ExtJob &j = jobs[i];
+        memset(&j, 0, sizeof(j));
+        j.read = i; j.rid = i; j.rev = 0; j.qs = 0; j.qlen = q_len[i]; j.ts = 0; j.tlen = t_len[i]; j.reversed = 0;
+        j.w = w[i]; j.zdrop = zdrop[i]; j.end_bonus = end_bonus[i]; j.flag = flag[i];
+    }
+    std::vector<ExtRes> res;
+    std::vector<uint32_t> cig;
+    g_force_kernel = force_kernel;
+    // no second pass here: the caller asks for exactly one DP per pair
+    mpn_map_opt o2 = *opt;
+    o2.zdrop = 0x3fffffff;
+    const int rc = run_jobs(d_ref.p, d_toff.p, &o2, jobs, d_reads.p, d_qoff.p, d_qlen.p, res, cig, st);
+    g_force_kernel = 0;
+    if (rc) return rc;
+    int64_t used = 0;
+    for (int i = 0; i < n; ++i) {
+        const ExtRes &e = res[i];
+        int32_t *o = out9 + (size_t)i * 9;
+        o[0] = e.max; o[1] = e.zdropped; o[2] = e.max_q; o[3] = e.max_t; o[4] = e.mqe; o[5] = e.mqe_t; o[6] = e.score; o[7] = e.reach_end;
+        o[8] = e.n_cigar;
+        cig_off[i] = used;
+        if (used + e.n_cigar > cigar_cap) return -3;
+        if (e.n_cigar) memcpy(cigar_pool + used, cig.data() + e.cig_pos, (size_t)e.n_cigar * 4);
+        used += e.n_cigar;
+    }
+    return 0;
 }

@@ -547,8 +547,11 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                                                              const int32_t *__restrict__ P, int32_t *__restrict__ T,
                                                              int32_t *__restrict__ V, uint64_t *__restrict__ U,
                                                              const int32_t *__restrict__ n_ends, u128 *__restrict__ B,
+                                                             uint64_t *__restrict__ Uc, unsigned long long *__restrict__ used,
+                                                             int64_t *__restrict__ u_pos, int64_t *__restrict__ b_pos,
                                                              int32_t *__restrict__ n_chain, int64_t *__restrict__ n_chained) {
     __shared__ int s_k, s_nv;
+    __shared__ unsigned long long s_up, s_bp;
     const int lane = threadIdx.x;
     for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
         const int64_t base = anchor_off[read];
@@ -557,7 +560,6 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
         const int32_t *f = F + base, *p = P + base;
         int32_t *t = T + base, *v = V + base;
         uint64_t *u = U + base;
-        u128 *b = B + base;
         const int n_u = n_ends[read];
         for (int64_t i = lane; i < n; i += 64) t[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -579,16 +581,24 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
             s_k = k; s_nv = n_v;
             n_chain[read] = k;
             n_chained[read] = n_v;
+            // compact pools: only chains that survived travel to the host
+            s_up = k ? atomicAdd(&used[0], (unsigned long long)k) : 0ULL;
+            s_bp = n_v ? atomicAdd(&used[1], (unsigned long long)n_v) : 0ULL;
+            u_pos[read] = (int64_t)s_up;
+            b_pos[read] = (int64_t)s_bp;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         const int k = s_k;
+        u128 *b = B + s_bp;
+        uint64_t *uc = Uc + s_up;
         int off = 0;
         for (int c = 0; c < k; ++c) {
             const int ni = (int32_t)u[c];
             for (int j = lane; j < ni; j += 64) b[off + j] = a[v[off + (ni - j - 1)]];
             off += ni;
         }
+        for (int c = lane; c < k; c += 64) uc[c] = u[c];
         __syncthreads();
     }
 }

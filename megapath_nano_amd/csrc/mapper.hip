@@ -107,7 +107,8 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<int32_t> F, P, T, V;
     DevBuf<uint64_t> Utmp;
     if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || F.alloc(n_a) || P.alloc(n_a) || T.alloc(n_a) || V.alloc(n_a) ||
-        o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n))
+        o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
+        o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(2) || o.used.zero(st))
         return -1;
     ev.stop_into(g_stats[11]);
     if (n_a > 0) {
@@ -131,10 +132,11 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(chain_sort_ends_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(256), 0, st, o.u.p, Utmp.p,
                        o.anchor_off.p, o.n_ends.p, n);
     MPN_HIP_CHECK(hipGetLastError());
-    // chained anchors reuse the sort scratch
+    // chained anchors and surviving chains go to compact pools that reuse the sort scratch
     o.chained.p = tmp.p; o.chained.n = tmp.n; tmp.p = nullptr; tmp.n = 0;
+    o.u_compact.p = Utmp.p; o.u_compact.n = Utmp.n; Utmp.p = nullptr; Utmp.n = 0;
     hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p,
-                       o.u.p, o.n_ends.p, o.chained.p, o.n_chain.p, o.n_chained.p);
+                       o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.stop_into(g_stats[14]);
     MPN_HIP_CHECK(hipStreamSynchronize(st));
@@ -158,21 +160,19 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st) {
     for (int i = 0; i < n; ++i) { h.chain_off[i + 1] = h.chain_off[i] + h.n_chain[i]; h.b_off[i + 1] = h.b_off[i] + h.n_chained[i]; }
     h.u.resize((size_t)h.chain_off[n]);
     h.b.resize((size_t)h.b_off[n]);
-    // one copy per read would be latency bound; copy everything when dense enough, else per read
-    const int64_t n_a = h.anchor_off[n];
-    std::vector<uint64_t> u_all;
-    std::vector<u128> b_all;
-    if (n_a > 0) {
-        u_all.resize((size_t)n_a);
-        b_all.resize((size_t)n_a);
-        if (o.u.download(u_all.data(), (size_t)n_a, st) || o.chained.download(b_all.data(), (size_t)n_a, st)) return -1;
-        MPN_HIP_CHECK(hipStreamSynchronize(st));
-    }
+    std::vector<int64_t> u_pos(n), b_pos(n);
+    unsigned long long used[2] = {0, 0};
+    if (o.u_pos.download(u_pos.data(), n, st) || o.b_pos.download(b_pos.data(), n, st) || o.used.download(used, 2, st)) return -1;
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<uint64_t> u_all((size_t)used[0]);
+    std::vector<u128> b_all((size_t)used[1]);
+    if (o.u_compact.download(u_all.data(), (size_t)used[0], st) || o.chained.download(b_all.data(), (size_t)used[1], st)) return -1;
+    MPN_HIP_CHECK(hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) {
         const int nc = h.n_chain[i];
         if (nc == 0) continue;
-        const uint64_t *u = &u_all[(size_t)h.anchor_off[i]];
-        const u128 *b = &b_all[(size_t)h.anchor_off[i]];
+        const uint64_t *u = &u_all[(size_t)u_pos[i]];
+        const u128 *b = &b_all[(size_t)b_pos[i]];
         std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w(nc);
         int64_t k = 0;
         for (int c = 0; c < nc; ++c) { w[c] = {{b[k].x, (uint64_t)k << 32 | (uint32_t)c}, c}; k += (int32_t)u[c]; }

@@ -58,6 +58,8 @@ def _bind():
         lib.mpn_map_batch_ex.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P,
                                          ct.c_int64, ct.POINTER(AlnCols)]
         lib.mpn_map_batch_ex.restype = ct.c_int64
+        lib.mpn_ext_dp_batch.argtypes = [ct.POINTER(MapOpt), ct.c_int32, P, P, P, P, P, P, P, P, P, P, ct.c_int32, P, P, ct.c_int64, P]
+        lib.mpn_ext_dp_batch.restype = ct.c_int
         lib.mpn_map_last_stats.argtypes = [P]
         lib.mpn_map_last_stats.restype = None
         _bound = True
@@ -236,6 +238,31 @@ def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True):
         if want_cols:
             arrs = {k: v[:cols.n_rows] for k, v in arrs.items()}
         return paf, (arrs if want_cols else None)
+
+
+def ext_dp_batch(opt, queries, targets, w, zdrop, end_bonus, flag, force_kernel=0):
+    """DP stage on (query, target) pairs of 0..4 codes -> list of dicts like the oracle's mmo_extd2 result."""
+    lib = _bind()
+    n = len(queries)
+    qbuf, qoff, qlen = pack_seqs([np.asarray(q, dtype=np.uint8) for q in queries])
+    tbuf, toff, tlen = pack_seqs([np.asarray(t, dtype=np.uint8) for t in targets])
+    arr = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.int32), (n,)))  # noqa: E731
+    w, zdrop, end_bonus, flag = arr(w), arr(zdrop), arr(end_bonus), arr(flag)
+    out = np.zeros((n, 9), dtype=np.int32)
+    cap = int(qlen.astype(np.int64).sum() + tlen.astype(np.int64).sum()) + 4 * n
+    pool = np.zeros(cap, dtype=np.uint32)
+    coff = np.zeros(n, dtype=np.int64)
+    rc = lib.mpn_ext_dp_batch(ct.byref(opt), n, qbuf.ctypes.data, qoff.ctypes.data, qlen.ctypes.data, tbuf.ctypes.data,
+                              toff.ctypes.data, tlen.ctypes.data, w.ctypes.data, zdrop.ctypes.data, end_bonus.ctypes.data,
+                              flag.ctypes.data, force_kernel, out.ctypes.data, pool.ctypes.data, cap, coff.ctypes.data)
+    _ffi.check(rc, 'mpn_ext_dp_batch')
+    keys = ('max', 'zdropped', 'max_q', 'max_t', 'mqe', 'mqe_t', 'score', 'reach_end', 'n_cigar')
+    res = []
+    for i in range(n):
+        d = {k: int(out[i, j]) for j, k in enumerate(keys)}
+        d['cigar'] = [int(x) for x in pool[coff[i]:coff[i] + d['n_cigar']]]
+        res.append(d)
+    return res
 
 
 STAT_NAMES = {0: 'bases', 1: 'minimizers', 2: 'anchors', 3: 'chains', 4: 'dp_jobs', 5: 'dp_cells', 6: 'alignments',

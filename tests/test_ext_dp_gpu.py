@@ -1,0 +1,102 @@
+"""GPU parity tests (-m gpu) of the three extension-DP kernels (single-wave LDS, register-resident, workgroup) against
+the oracle's mmo_extd2 on seeded pairs: global / approximate-max / extension-only / right-aligned modes, band clipping,
+z-drop, ambiguous bases, small to large windows.  Bit-exact on scores, end points and CIGAR."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+APPROX, RIGHT, EXTZ, REV = 0x02, 0x08, 0x40, 0x80
+
+
+def mutate(rng, s, rate):
+    out = []
+    for c in s:
+        r = rng.random()
+        if r < rate * 0.4:
+            out.append(int((c + rng.integers(1, 4)) % 4))
+        elif r < rate * 0.7:
+            out.append(int(c))
+            out.extend(rng.integers(0, 4, size=int(rng.integers(1, 4))).tolist())
+        elif r < rate:
+            continue
+        else:
+            out.append(int(c))
+    return np.array(out if out else [0], dtype=np.uint8)
+
+
+def make_pairs(seed, sizes, tail=False, ambig=False, big_indel=False):
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for L in sizes:
+        t = rng.integers(0, 4, size=L).astype(np.uint8)
+        q = mutate(rng, t, 0.12)
+        if big_indel and L > 400:
+            cut = int(rng.integers(100, L - 200))
+            q = np.concatenate([q[:cut], rng.integers(0, 4, size=int(rng.integers(30, 120))).astype(np.uint8), q[cut:]])
+        if tail:  # unrelated sequence after the homologous part: the extension must stop (z-drop)
+            q = np.concatenate([q, rng.integers(0, 4, size=int(rng.integers(300, 900))).astype(np.uint8)])
+            t = np.concatenate([t, rng.integers(0, 4, size=int(rng.integers(300, 900))).astype(np.uint8)])
+        if ambig:
+            q[rng.integers(0, len(q), size=max(1, len(q) // 50))] = 4
+            t[rng.integers(0, len(t), size=max(1, len(t) // 60))] = 4
+        qs.append(q)
+        ts.append(t)
+    return qs, ts
+
+
+def check(opt, qs, ts, w, zdrop, end_bonus, flag, kernels):
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    want = [mb.extd2(q, t, w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag) for q, t in zip(qs, ts)]
+    for k in kernels:
+        got = mapper.ext_dp_batch(opt, qs, ts, w, zdrop, end_bonus, flag, force_kernel=k)
+        for i, (g, e) in enumerate(zip(got, want)):
+            keys = ['zdropped', 'n_cigar', 'cigar', 'score'] if flag & APPROX else \
+                ['max', 'zdropped', 'max_q', 'max_t', 'mqe', 'mqe_t', 'score', 'reach_end', 'n_cigar', 'cigar']
+            for key in keys:
+                if key == 'score' and e['zdropped']:
+                    continue
+                assert g[key] == e[key], (k, i, len(qs[i]), len(ts[i]), key, g[key] if key != 'cigar' else g[key][:6],
+                                          e[key] if key != 'cigar' else e[key][:6])
+
+
+@pytest.fixture(scope='module')
+def opt(libmpn, oracle_built):
+    from megapath_nano_amd import mapper
+    return mapper.default_opt()
+
+
+def test_gap_fill_windows_all_kernels(opt):
+    qs, ts = make_pairs(1, [30, 64, 65, 128, 200, 230, 256, 257, 300, 400, 511])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 0])
+    qs, ts = make_pairs(2, [220, 260, 310], ambig=True)
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3])
+    qs, ts = make_pairs(3, [450, 500], big_indel=True)
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3])
+
+
+def test_exact_global_mode(opt):
+    qs, ts = make_pairs(4, [50, 180, 260, 420, 700])
+    check(opt, qs, ts, 751, 400, -1, 0, [1, 3])
+    qs, ts = make_pairs(5, [300, 600], big_indel=True)  # z-drop inside a global fill
+    check(opt, qs, ts, 751, 50, -1, 0, [1, 3])
+
+
+def test_extension_modes_with_zdrop(opt):
+    qs, ts = make_pairs(6, [40, 150, 400, 900], tail=True)
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 0])
+    check(opt, qs, ts, 751, 400, -1, EXTZ | RIGHT | REV, [1, 3, 0])
+    check(opt, qs, ts, 751, 400, 50, EXTZ, [1, 3])  # end bonus: reach_end path
+    qs, ts = make_pairs(7, [300, 500])
+    check(opt, qs, ts, 751, 400, 10, EXTZ, [1, 3])
+
+
+def test_band_clipping_and_large_windows(opt):
+    qs, ts = make_pairs(8, [600, 1500])
+    check(opt, qs, ts, 100, 400, -1, 0, [1, 3])       # narrow band: cells outside the previous band
+    check(opt, qs, ts, 20, 400, -1, APPROX, [1, 2, 3])
+    qs, ts = make_pairs(9, [3000, 5200], tail=True)
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 0])
+    qs, ts = make_pairs(10, [14000])                  # state arrays in the global scratch
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3])
