@@ -57,6 +57,8 @@ def check(opt, qs, ts, w, zdrop, end_bonus, flag, kernels):
             for key in keys:
                 if key == 'score' and e['zdropped']:
                     continue
+                if key in ('mqe', 'score') and g[key] < -10**8 and e[key] < -10**8:
+                    continue  # both 'never set' (the two sides use different -inf constants)
                 assert g[key] == e[key], (k, i, len(qs[i]), len(ts[i]), key, g[key] if key != 'cigar' else g[key][:6],
                                           e[key] if key != 'cigar' else e[key][:6])
 
