@@ -90,7 +90,7 @@ def main():
     ap.add_argument('--genomes', type=int, default=100)
     ap.add_argument('--genome-len', type=int, default=2000000)
     ap.add_argument('--strain-pairs', type=int, default=2)
-    ap.add_argument('--reads-per-step', type=int, default=16384)
+    ap.add_argument('--reads-per-step', type=int, default=32768)
     ap.add_argument('--mean-len', type=int, default=8000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

@@ -18,6 +18,8 @@
 #include <thread>
 #include <atomic>
 #include <functional>
+#include <mutex>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -28,6 +30,8 @@ int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
                       const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st);
 int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st);
+
+const char *get_error();
 
 static const int PARENT_UNSET = -1, PARENT_TMP_PRI = -2;
 static const uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
@@ -759,6 +763,16 @@ static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *nam
 }
 
 // run one group of DP jobs on the GPU (its scratch fits the budget)
+// per-worker resources: a stream, a device arena, grow-only scratch pools and pinned staging buffers
+struct Slot {
+    hipStream_t st = nullptr;
+    Arena arena;
+    PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_gap, pool_redo, pool_compact, pool_used;
+    PoolBuf pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
+};
+static Slot g_slots[4];
+static thread_local Slot *tl_slot = &g_slots[0];
+
 static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel
 
 static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
@@ -809,8 +823,10 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         else order[cls].push_back(j);
     }
     g_stats[4] += nj; g_stats[5] += cells;
-    static PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_gap, pool_redo, pool_compact, pool_used;
-    static PoolBuf pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
+    Slot &SL = *tl_slot;
+    PoolBuf &pool_jobs = SL.pool_jobs, &pool_P = SL.pool_P, &pool_OFF = SL.pool_OFF, &pool_order = SL.pool_order, &pool_state = SL.pool_state,
+            &pool_CIG = SL.pool_CIG, &pool_res = SL.pool_res, &pool_gap = SL.pool_gap, &pool_redo = SL.pool_redo,
+            &pool_compact = SL.pool_compact, &pool_used = SL.pool_used, &pin_res = SL.pin_res, &pin_cig = SL.pin_cig;
     std::vector<int32_t> flat;
     int base[5], reg_base[2], wg_base[5];
     for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
@@ -965,32 +981,21 @@ static int run_jobs(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_m
 
 using namespace mpn;
 
-extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
-                                    const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
-                                    const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
-    hipStream_t st = 0;
-    memset(g_stats, 0, sizeof(g_stats));
-    if (cols) cols->n_rows = 0;
-    if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; return 0; }
-    struct Borrowed {  // device views of the reads: owned uploads or the caller's resident buffers
-        DevBuf<uint8_t> seqs; DevBuf<int64_t> off; DevBuf<int32_t> len;
-        const uint8_t *p = nullptr; const int64_t *po = nullptr; const int32_t *pl = nullptr;
-    } dv;
-    int64_t bases = 0;
-    WallTimer whole, wt;
-    if (r_seqs && r_off && r_len) {
-        dv.p = (const uint8_t *)r_seqs; dv.po = r_off; dv.pl = r_len;
-        for (int i = 0; i < n; ++i) bases += seq_len[i];
-    } else {
-        if (upload_seqs(n, seqs, seq_off, seq_len, dv.seqs, dv.off, dv.len, &bases, st)) return -1;
-        dv.p = dv.seqs.p; dv.po = dv.off.p; dv.pl = dv.len.p;
-    }
-    struct { const uint8_t *p; } d_seqs{dv.p};
-    struct { const int64_t *p; } d_off{dv.po};
-    struct { const int32_t *p; } d_len{dv.pl};
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
-    wt.stop_into(g_stats[16]);
-    g_stats[0] = bases;
+// One contiguous range [lo, hi) of the batch through the whole path, on the calling worker's stream and arena.
+// Fills rs[lo..hi), rep_len[lo..hi) and lines[lo..hi) (PAF text, only if want_paf).
+static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *const *names, const char *seqs,
+                     const int64_t *seq_off_all, const int32_t *seq_len_all, const uint8_t *d_seqs_p, const int64_t *d_off_all,
+                     const int32_t *d_len_all, int lo, int hi, int n_threads, hipStream_t st, std::vector<ReadState> &rs_all,
+                     std::vector<int32_t> &rep_len_all, std::vector<std::string> &lines_all, bool want_paf) {
+    const int n = hi - lo;
+    if (n <= 0) return 0;
+    const int64_t *seq_off = seq_off_all + lo;
+    const int32_t *seq_len = seq_len_all + lo;
+    struct { const uint8_t *p; } d_seqs{d_seqs_p};
+    struct { const int64_t *p; } d_off{d_off_all + lo};
+    struct { const int32_t *p; } d_len{d_len_all + lo};
+    ReadState *rs = rs_all.data() + lo;
+    WallTimer wt;
     HostChains h;
     {
         SeedChainOut o;
@@ -999,10 +1004,8 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         if (download_chains(n, o, h, st)) return -1;
         wt.stop_into(g_stats[18]);
     }
-    g_stats[3] = (int64_t)h.u.size();
-    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, (int)std::thread::hardware_concurrency());
-    if (n_threads < 1) n_threads = 1;
-    std::vector<ReadState> rs(n);
+    g_stats[3] += (int64_t)h.u.size();
+    for (int i = 0; i < n; ++i) rep_len_all[lo + i] = h.rep_len[i];
     // hits from chains
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
@@ -1010,7 +1013,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         if (nc == 0) return;
         const int qlen = seq_len[i];
         S.a.assign(h.b.begin() + h.b_off[i], h.b.begin() + h.b_off[i + 1]);
-        uint32_t hash = names && names[i] ? x31_hash(names[i]) : 0;
+        uint32_t hash = names && names[lo + i] ? x31_hash(names[lo + i]) : 0;
         hash ^= wang32((uint32_t)qlen) + wang32(opt->seed);
         hash = wang32(hash);
         gen_regs(hash, qlen, nc, &h.u[h.chain_off[i]], S.a.data(), S.regs);
@@ -1090,7 +1093,6 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     }
     wt.stop_into(g_stats[23]);
     // rank, MAPQ, text
-    std::vector<std::string> lines(n);
     std::atomic<int64_t> n_aln(0);
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
@@ -1104,10 +1106,104 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
             set_sam_pri(S.regs);
         }
         set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
-        if (paf) write_paf(idx, opt, names && names[i] ? names[i] : "*", qlen, S.regs, h.rep_len[i], lines[i]);
+        if (want_paf) write_paf(idx, opt, names && names[lo + i] ? names[lo + i] : "*", qlen, S.regs, h.rep_len[i], lines_all[lo + i]);
         n_aln += (int64_t)S.regs.size();
+        // the per-read scratch is no longer needed
+        std::vector<u128>().swap(S.a);
+        std::vector<uint8_t>().swap(S.q4[0]);
+        std::vector<uint8_t>().swap(S.q4[1]);
     });
-    g_stats[6] = n_aln;
+    g_stats[6] += n_aln;
+    wt.stop_into(g_stats[23]);
+    return 0;
+}
+
+extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                                    const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
+                                    const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
+    hipStream_t st0 = 0;
+    memset(g_stats, 0, sizeof(g_stats));
+    if (cols) cols->n_rows = 0;
+    if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; return 0; }
+    struct Borrowed {  // device views of the reads: owned uploads or the caller's resident buffers
+        DevBuf<uint8_t> seqs; DevBuf<int64_t> off; DevBuf<int32_t> len;
+        const uint8_t *p = nullptr; const int64_t *po = nullptr; const int32_t *pl = nullptr;
+    } dv;
+    int64_t bases = 0;
+    WallTimer whole, wt;
+    if (r_seqs && r_off && r_len) {
+        dv.p = (const uint8_t *)r_seqs; dv.po = r_off; dv.pl = r_len;
+        for (int i = 0; i < n; ++i) bases += seq_len[i];
+    } else {
+        if (upload_seqs(n, seqs, seq_off, seq_len, dv.seqs, dv.off, dv.len, &bases, st0)) return -1;
+        dv.p = dv.seqs.p; dv.po = dv.off.p; dv.pl = dv.len.p;
+    }
+    MPN_HIP_CHECK(hipStreamSynchronize(st0));
+    wt.stop_into(g_stats[16]);
+    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, (int)std::thread::hardware_concurrency());
+    if (n_threads < 1) n_threads = 1;
+    // sub-batches of ~48 Mbp run through a small pool of workers, each with its own HIP stream and device arena, so
+    // that the host phases of one sub-batch overlap the GPU phases of another
+    std::vector<int> cut{0};
+    {
+        int64_t target = 48000000;
+        if (const char *e = getenv("MPN_SUB_BATCH_BP")) target = std::max<int64_t>(1000, atoll(e));
+        int64_t acc = 0;
+        for (int i = 0; i < n; ++i) {
+            acc += seq_len[i];
+            if (acc >= target && i + 1 < n) { cut.push_back(i + 1); acc = 0; }
+        }
+        cut.push_back(n);
+    }
+    const int n_sub = (int)cut.size() - 1;
+    int n_workers = 4;
+    if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(4, atoi(e)));
+    n_workers = std::min(n_workers, n_sub);
+    int dev = 0;
+    MPN_HIP_CHECK(hipGetDevice(&dev));
+    std::vector<ReadState> rs(n);
+    std::vector<int32_t> rep_len(n, 0);
+    std::vector<std::string> lines(paf ? n : 0);
+    std::atomic<int> next(0), failed(0);
+    std::mutex mu;
+    int64_t tot_stats[32] = {0};
+    std::string err;
+    auto worker = [&](int wid) {
+        if (hipSetDevice(dev) != hipSuccess) { failed = 1; return; }
+        Slot &S = g_slots[wid];
+        if (!S.st && hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
+        tl_slot = &S;
+        tl_arena = &S.arena;
+        memset(g_stats, 0, sizeof(g_stats));
+        for (;;) {
+            const int sb = next.fetch_add(1);
+            if (sb >= n_sub || failed) break;
+            S.arena.reset();
+            if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1],
+                          std::max(1, n_threads / n_workers), S.st, rs, rep_len, lines, paf != nullptr)) {
+                std::lock_guard<std::mutex> g(mu);
+                err = get_error();
+                failed = 1;
+                break;
+            }
+        }
+        tl_arena = nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        for (int k = 0; k < 32; ++k) tot_stats[k] += g_stats[k];
+    };
+    {
+        std::vector<std::thread> th;
+        for (int wdx = 0; wdx < n_workers; ++wdx) th.emplace_back(worker, wdx);
+        for (auto &t : th) t.join();
+    }
+    if (failed) { set_error("%s", err.empty() ? "worker failed" : err.c_str()); return -1; }
+    {
+        const int64_t h2d = g_stats[16];
+        memcpy(g_stats, tot_stats, sizeof(tot_stats));
+        g_stats[16] = h2d;
+        g_stats[0] = bases;
+    }
+    int64_t n_aln = g_stats[6];
     if (cols) {
         cols->n_rows = n_aln;
         if (n_aln > cols->cap) return -3;
@@ -1130,7 +1226,6 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
         paf[w] = 0;
     }
-    wt.stop_into(g_stats[23]);
     whole.stop_into(g_stats[24]);
     return w;
 }

@@ -133,8 +133,8 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
                        o.anchor_off.p, o.n_ends.p, n);
     MPN_HIP_CHECK(hipGetLastError());
     // chained anchors and surviving chains go to compact pools that reuse the sort scratch
-    o.chained.p = tmp.p; o.chained.n = tmp.n; tmp.p = nullptr; tmp.n = 0;
-    o.u_compact.p = Utmp.p; o.u_compact.n = Utmp.n; Utmp.p = nullptr; Utmp.n = 0;
+    o.chained.p = tmp.p; o.chained.n = tmp.n; o.chained.owned = tmp.owned; tmp.p = nullptr; tmp.n = 0;
+    o.u_compact.p = Utmp.p; o.u_compact.n = Utmp.n; o.u_compact.owned = Utmp.owned; Utmp.p = nullptr; Utmp.n = 0;
     hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p,
                        o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p);
     MPN_HIP_CHECK(hipGetLastError());
@@ -284,11 +284,14 @@ int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
     if (f <= 0.f) return INT32_MAX;
     const int64_t n = idx->n_keys;
     if (n == 0) return 1;
+    std::lock_guard<std::mutex> g(idx->mu);
+    for (auto &kv : idx->mid_occ_cache) if (kv.first == f) return kv.second;
     std::vector<uint32_t> a((size_t)n);
     for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (uint32_t)(idx->h_key_off[(size_t)i + 1] - idx->h_key_off[(size_t)i]);
     int64_t kk = (int64_t)(uint32_t)((1. - (double)f) * (double)n);
     if (kk >= n) kk = n - 1;
     std::nth_element(a.begin(), a.begin() + kk, a.end());
+    idx->mid_occ_cache.push_back({f, (int32_t)(a[(size_t)kk] + 1)});
     return (int32_t)(a[(size_t)kk] + 1);
 }
 

@@ -3,6 +3,7 @@
 #include "mpn_common.h"
 
 #include <chrono>
+#include <mutex>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -26,6 +27,8 @@ struct mpn_index {
     mpn::DevBuf<int64_t> key_off;
     mpn::DevBuf<uint8_t> d_seq4;      // device: one code per base (extension kernel)
     mpn::DevBuf<int64_t> d_seq_off;
+    mutable std::mutex mu;
+    mutable std::vector<std::pair<float, int32_t>> mid_occ_cache;
 };
 
 namespace mpn {

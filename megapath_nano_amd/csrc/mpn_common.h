@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 namespace mpn {
 
@@ -18,20 +19,50 @@ void set_error(const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// ---- grow-only device arena ---------------------------------------------------------------
+// hipMalloc/hipFree per batch cost more than the kernels they serve (and hipFree synchronises the device, which would
+// serialise the pipelined workers).  A worker thread points tl_arena at its slot's arena; every DevBuf it creates then
+// bump-allocates from chunks that persist across calls.  reset() rewinds; nothing is freed until process exit.
+struct Arena {
+    struct Chunk { void *p; size_t cap; };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, off = 0;
+    void reset() { cur = 0; off = 0; }
+    void *take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (; cur < chunks.size(); ++cur, off = 0)
+            if (off + bytes <= chunks[cur].cap) { void *r = (char *)chunks[cur].p + off; off += bytes; return r; }
+        Chunk c;
+        c.cap = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
+        if (hipMalloc(&c.p, c.cap) != hipSuccess) { mpn::set_error("arena: hipMalloc of %zu bytes failed", c.cap); return nullptr; }
+        chunks.push_back(c);
+        cur = chunks.size() - 1;
+        off = bytes;
+        return c.p;
+    }
+};
+extern thread_local Arena *tl_arena;
+
 // ---- device buffer with RAII (host-side plumbing) --------------------------------------
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
     int alloc(size_t count) {
         release();
         n = count;
         if (count == 0) count = 1;
+        if (tl_arena) {
+            p = (T *)tl_arena->take(count * sizeof(T));
+            owned = false;
+            return p ? 0 : -1;
+        }
         MPN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
         return 0;
     }

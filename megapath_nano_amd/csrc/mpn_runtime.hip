@@ -13,6 +13,7 @@ void set_error(const char *fmt, ...) {
     g_err = buf;
 }
 const char *get_error() { return g_err.c_str(); }
+thread_local Arena *tl_arena = nullptr;
 }  // namespace mpn
 
 extern "C" const char *mpn_last_error(void) { return mpn::get_error(); }

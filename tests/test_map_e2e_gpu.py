@@ -85,3 +85,22 @@ def test_mapping_lands_on_truth(world):
         if same and int(f[7]) < r['end'] and int(f[8]) > r['start'] and f[4] == r['strand']:
             ok += 1
     assert ok >= tot * 0.9, (ok, tot)
+
+
+def test_pipelined_workers_are_deterministic(world, monkeypatch):
+    """The batch is cut into sub-batches that run through 1..4 worker threads (own stream + arena each):
+    the PAF must not depend on the cut or on the number of workers, and must equal the unsplit result."""
+    from megapath_nano_amd import mapper
+    gen, reads, gidx, _ = world
+    gopt = mapper.default_opt(best_n=50, pri_ratio=1.0)
+    names = [r['name'] for r in reads]
+    seqs = [r['seq'] for r in reads]
+    monkeypatch.setenv('MPN_SUB_BATCH_BP', '1000000000')
+    monkeypatch.setenv('MPN_PIPE_WORKERS', '1')
+    base = mapper.map_batch(gidx, gopt, names, seqs)
+    assert base.count('\n') > len(reads) // 2
+    for sb, w in (('20000', '1'), ('20000', '4'), ('7000', '3'), ('150000', '2')):
+        monkeypatch.setenv('MPN_SUB_BATCH_BP', sb)
+        monkeypatch.setenv('MPN_PIPE_WORKERS', w)
+        for _ in range(2):
+            assert mapper.map_batch(gidx, gopt, names, seqs) == base, (sb, w)
