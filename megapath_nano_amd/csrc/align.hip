@@ -784,7 +784,8 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
     // scratch layout + size classes (LDS need)
     int64_t p_tot = 0, row_tot = 0, cig_tot = 0, state_tot = 0;
     std::vector<int32_t> order[5];   // first pass through the LDS-state kernel, by LDS size class
-    std::vector<int32_t> wg_order[5];   // large windows: workgroup-per-window kernel, by LDS size class
+    std::vector<int32_t> wg_order[3][5];  // large windows: workgroup-per-window kernel, by threads (256/512/1024) and LDS class
+    std::vector<int8_t> wg_nt(nj, 0);
     std::vector<int32_t> reg_order[2];  // first pass through the register-resident kernel (gap fills, tlen <= 256 / 512)
     std::vector<int8_t> use_wg(nj, 0);
     std::vector<int8_t> lds_cls(nj, 0);
@@ -815,11 +816,12 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         const bool reg_ok = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
         use_wg[j] = (int8_t)(g_force_kernel == 3 || (g_force_kernel == 0 && n_col - 1 > 128));
         if (g_force_kernel == 1) use_wg[j] = 0;
+        wg_nt[j] = (int8_t)(n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2);
         if (reg_ok && (g_force_kernel == 0 || g_force_kernel == 2)) {
             const int rc = jb.tlen <= 256 ? 0 : 1;
             reg_order[rc].push_back(j);
             reg_lds_max[rc] = std::max(reg_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
-        } else if (use_wg[j]) wg_order[cls].push_back(j);
+        } else if (use_wg[j]) { wg_nt[j] = (int8_t)(n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2); wg_order[(int)wg_nt[j]][cls].push_back(j); }
         else order[cls].push_back(j);
     }
     g_stats[4] += nj; g_stats[5] += cells;
@@ -828,9 +830,10 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
             &pool_CIG = SL.pool_CIG, &pool_res = SL.pool_res, &pool_gap = SL.pool_gap, &pool_redo = SL.pool_redo,
             &pool_compact = SL.pool_compact, &pool_used = SL.pool_used, &pin_res = SL.pin_res, &pin_cig = SL.pin_cig;
     std::vector<int32_t> flat;
-    int base[5], reg_base[2], wg_base[5];
+    int base[5], reg_base[2], wg_base[3][5];
     for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
-    for (int c = 0; c < 5; ++c) { wg_base[c] = (int)flat.size(); flat.insert(flat.end(), wg_order[c].begin(), wg_order[c].end()); }
+    for (int t = 0; t < 3; ++t)
+        for (int c = 0; c < 5; ++c) { wg_base[t][c] = (int)flat.size(); flat.insert(flat.end(), wg_order[t][c].begin(), wg_order[t][c].end()); }
     for (int c = 0; c < 2; ++c) { reg_base[c] = (int)flat.size(); flat.insert(flat.end(), reg_order[c].begin(), reg_order[c].end()); }
     if (pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || pool_P.ensure((size_t)p_tot) || pool_OFF.ensure((size_t)row_tot * 2 * 4) ||
         pool_state.ensure((size_t)state_tot) || pool_CIG.ensure((size_t)cig_tot * 4) || pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
@@ -863,18 +866,24 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         MPN_HIP_CHECK(hipGetLastError());
         return 0;
     };
-    auto launch_wg = [&](const int32_t *ord, int cnt, size_t lds) -> int {
+    auto launch_wg = [&](int ntc, const int32_t *ord, int cnt, size_t lds) -> int {
         if (cnt == 0) return 0;
-        if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ext_dp_wg_kernel<256>, dim3(cnt), dim3(256), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len,
-                           d_ref4, d_ref_off, P.p, OFF.p, gstate.p, d_res.p);
+#define MPN_WG_LAUNCH(NT)                                                                                                             \
+        do {                                                                                                                          \
+            if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(ext_dp_wg_kernel<NT>, dim3(cnt), dim3(NT), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len, \
+                               d_ref4, d_ref_off, P.p, OFF.p, gstate.p, d_res.p);                                                    \
+        } while (0)
+        if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
+#undef MPN_WG_LAUNCH
         MPN_HIP_CHECK(hipGetLastError());
         return 0;
     };
     EvTimer ev(st);
     // the few large windows go first: they are the long pole of the launch sequence
-    for (int c = 4; c >= 0; --c)
-        if (launch_wg(d_order.p + wg_base[c], (int)wg_order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+    for (int t = 2; t >= 0; --t)
+        for (int c = 4; c >= 0; --c)
+            if (launch_wg(t, d_order.p + wg_base[t][c], (int)wg_order[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
     for (int c = 0; c < 5; ++c)
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
     if (!reg_order[0].empty()) {
@@ -907,13 +916,14 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(hipStreamSynchronize(st));
         memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
-        std::vector<int32_t> redo[5], redo_wg[5];
+        std::vector<int32_t> redo[5], redo_wg[3][5];
         std::vector<int32_t> redo_flat;
         for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; }
-        for (int j : gap) if (res[j].zcode) (use_wg[j] ? redo_wg : redo)[(int)lds_cls[j]].push_back(j);
-        int rbase[5], rwbase[5];
+        for (int j : gap) if (res[j].zcode) { if (use_wg[j]) redo_wg[(int)wg_nt[j]][(int)lds_cls[j]].push_back(j); else redo[(int)lds_cls[j]].push_back(j); }
+        int rbase[5], rwbase[3][5];
         for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }
-        for (int c = 0; c < 5; ++c) { rwbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo_wg[c].begin(), redo_wg[c].end()); }
+        for (int t = 0; t < 3; ++t)
+            for (int c = 0; c < 5; ++c) { rwbase[t][c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo_wg[t][c].begin(), redo_wg[t][c].end()); }
         g_stats[8] += (int64_t)redo_flat.size();
         if (!redo_flat.empty()) {
             if (pool_redo.ensure(redo_flat.size() * 4)) return -1;
@@ -923,8 +933,9 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
             EvTimer ev2(st);
             for (int c = 0; c < 5; ++c)
                 if (launch_dp(d_redo.p + rbase[c], (int)redo[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
-            for (int c = 0; c < 5; ++c)
-                if (launch_wg(d_redo.p + rwbase[c], (int)redo_wg[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+            for (int t = 0; t < 3; ++t)
+                for (int c = 0; c < 5; ++c)
+                    if (launch_wg(t, d_redo.p + rwbase[t][c], (int)redo_wg[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
             ev2.stop_into(g_stats[15]);
             hipLaunchKernelGGL(ext_bt_kernel, dim3(((int)redo_flat.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p,
                                (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
