@@ -171,6 +171,15 @@ def main():
         'ext_dp_kernel': (st['ev_ext_dp_ns'], st['dp_cells']),                                         # 1 direction byte per cell out (+ windows in)
         'ext_bt_kernel': (st['ev_ext_bt_ns'], 0),
     }
+    # HBM traffic of the DP kernels from the PMC passes of the same command (profiles/r01/pmc_summary.json; separate
+    # rocprofv3 --pmc runs, FETCH_SIZE+WRITE_SIZE in KiB), scaled to this run's reads per step
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))
+        tb = sum(v.get('hbm_bytes_per_step', 0) for k, v in pm['kernels'].items() if k.startswith('ext_dp'))
+        traffic = tb * args.reads_per_step / pm.get('reads_per_step', 32768)
+    except Exception:
+        pass
     dom = max(kern, key=lambda k: kern[k][0])
     dom_ns, dom_bytes = kern[dom]
     achieved = dom_bytes / max(dom_ns, 1) if dom_ns else 0.0  # bytes/ns == GB/s
@@ -199,8 +208,9 @@ def main():
         },
         'roofline': {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
-            'note': 'integer DP / byte work; dominant kernel by HIP-event time per step on rank 0',
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic if dom == 'ext_dp_kernel' else None,
+            'note': 'integer DP / byte work; dominant kernel family by HIP-event time per step on rank 0 (ext_dp_kernel = the three '
+                    'extension-DP kernels; event times overlap across the pipelined streams); achieved/traffic are bytes per STEP',
             'kernel_ms_per_step': {k: round(v[0] / 1e6, 2) for k, v in kern.items()},
             'device_ms_per_step': round(dev_ns / 1e6, 2),
             'dp_gcups': round(st['dp_cells'] / max(st['ev_ext_dp_ns'], 1), 1),
