@@ -1132,6 +1132,9 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
 extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
                                     const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
                                     const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
+    // the worker slots (streams, arenas, pools) are process-wide: concurrent callers take turns
+    static std::mutex call_mu;
+    std::lock_guard<std::mutex> call_guard(call_mu);
     hipStream_t st0 = 0;
     memset(g_stats, 0, sizeof(g_stats));
     if (cols) cols->n_rows = 0;

@@ -104,3 +104,25 @@ def test_pipelined_workers_are_deterministic(world, monkeypatch):
         monkeypatch.setenv('MPN_PIPE_WORKERS', w)
         for _ in range(2):
             assert mapper.map_batch(gidx, gopt, names, seqs) == base, (sb, w)
+
+
+def test_hard_reads_match_oracle(world):
+    """z-drop + second exact pass + split hits, chimeras, inversions, long-join windows, a 60 kb read, N runs."""
+    from map_cases import hard_reads
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, _, gidx, oidx = world
+    reads = hard_reads(gen)
+    names = [r['name'] for r in reads]
+    for best_n, pri in ((5, 0.8), (50, 1.0)):
+        gopt = mapper.default_opt(best_n=best_n, pri_ratio=pri)
+        oopt = mb.default_opt(best_n=best_n, pri_ratio=pri)
+        got = split_by_read(mapper.map_batch(gidx, gopt, names, [r['seq'] for r in reads]), names)
+        st = mapper.last_stats()
+        want = oracle_paf(oidx, oopt, reads)
+        for r, g, w in zip(reads, got, want):
+            assert g == w, r['name']
+        text = ''.join(want)
+        assert 'zd:i:' in text, 'no split hit in the hard set'
+        assert st['dp_rounds'] >= 2 and st['second_pass_jobs'] >= 1, st
+    assert text.count('\n') >= len(reads)
