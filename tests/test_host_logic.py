@@ -103,3 +103,28 @@ def test_gloo_world2_count_allreduce(tmp_path, oracle_built):
     assert sorted(l['rank'] for l in lines) == [0, 1]
     assert lines[0]['total'] == lines[1]['total']
     assert sum(lines[0]['total']) == lines[0]['n_reads'] == lines[0]['local'] + lines[1]['local']
+
+
+def test_human_decoy_classification_rules():
+    """megapath_nano.py:1135-1200 on a hand-made table: human first, then decoy on the rest, microbe = remainder."""
+    import pandas as pd
+    from megapath_nano_amd.filters import human_and_decoy_classify
+    rows = [
+        # read, len, assembly, AS, tiebreak
+        ('h_abs', 5000, 'HUMAN', 1200, .1),      # AS >= 1000
+        ('h_pct', 600, 'HUMAN', 650, .2),        # AS*100/len >= 100
+        ('h_low', 5000, 'HUMAN', 300, .3),       # below both thresholds: not human
+        ('h_low', 5000, 'DECOY', 1500, .4),      # ... but decoy
+        ('both', 3000, 'HUMAN', 2000, .5), ('both', 3000, 'DECOY', 2500, .6),   # human wins (filtered first)
+        ('m1', 4000, 'MIC1', 3000, .7), ('m1', 4000, 'MIC2', 3000, .8),         # tie -> tiebreaker picks MIC2
+        ('m2', 4000, 'MIC1', 900, .9), ('m2', 4000, 'DECOY', 100, .05),         # weak decoy hit stays microbe
+    ]
+    al = pd.DataFrame(rows, columns=['read_id', 'read_length', 'assembly_id', 'alignment_score', 'alignment_score_tiebreaker'])
+    reads = pd.DataFrame({'read_id': ['h_abs', 'h_pct', 'h_low', 'both', 'm1', 'm2', 'unaligned'],
+                          'read_length': [5000, 600, 5000, 3000, 4000, 4000, 777]})
+    out = human_and_decoy_classify(al, pd.DataFrame({'assembly_id': ['HUMAN']}), pd.DataFrame({'assembly_id': ['DECOY']}), reads)
+    assert sorted(out['human_read_id_list']['read_id']) == ['both', 'h_abs', 'h_pct']
+    assert sorted(out['decoy_read_id_list']['read_id']) == ['h_low']
+    assert sorted(out['microbe_read_id_list']['read_id']) == ['m1', 'm2', 'unaligned']
+    mb = out['microbe_best_align_list'].set_index('read_id')
+    assert mb.loc['m1', 'assembly_id'] == 'MIC2' and mb.loc['m2', 'assembly_id'] == 'MIC1'
