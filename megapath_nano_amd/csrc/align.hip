@@ -775,7 +775,7 @@ static thread_local Slot *tl_slot = &g_slots[0];
 
 static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel
 
-static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
+static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
                          const uint8_t *d_reads, const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res,
                          std::vector<uint32_t> &cig, hipStream_t st) {
     const int nj = (int)jobs.size();
@@ -862,7 +862,7 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         if (cnt == 0) return 0;
         if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ext_dp_kernel, dim3(cnt), dim3(64), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len,
-                           d_ref4, d_ref_off, P.p, OFF.p, gstate.p, d_res.p);
+                           rv, P.p, OFF.p, gstate.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
         return 0;
     };
@@ -872,7 +872,7 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         do {                                                                                                                          \
             if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL(ext_dp_wg_kernel<NT>, dim3(cnt), dim3(NT), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len, \
-                               d_ref4, d_ref_off, P.p, OFF.p, gstate.p, d_res.p);                                                    \
+                               rv, P.p, OFF.p, gstate.p, d_res.p);                                                    \
         } while (0)
         if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
 #undef MPN_WG_LAUNCH
@@ -888,14 +888,12 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
     if (!reg_order[0].empty()) {
         hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3((unsigned)reg_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
-                           d_order.p + reg_base[0], (int)reg_order[0].size(), prm, d_reads, d_read_off, d_read_len, d_ref4,
-                           d_ref_off, P.p, OFF.p, d_res.p);
+                           d_order.p + reg_base[0], (int)reg_order[0].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
     }
     if (!reg_order[1].empty()) {
         hipLaunchKernelGGL(ext_dp_reg_kernel<8>, dim3((unsigned)reg_order[1].size()), dim3(64), reg_lds_max[1], st, d_jobs.p,
-                           d_order.p + reg_base[1], (int)reg_order[1].size(), prm, d_reads, d_read_off, d_read_len, d_ref4,
-                           d_ref_off, P.p, OFF.p, d_res.p);
+                           d_order.p + reg_base[1], (int)reg_order[1].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
     }
     ev.stop_into(g_stats[15]);
@@ -910,7 +908,7 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
         struct { int32_t *p; } d_gap{pool_gap.as<int32_t>()};
         MPN_HIP_CHECK(hipMemcpyAsync(d_gap.p, gap.data(), gap.size() * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(ext_ztest_kernel, dim3(((int)gap.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_gap.p, (int)gap.size(), prm,
-                           d_reads, d_read_off, d_read_len, d_ref4, d_ref_off, CIG.p, d_res.p);
+                           d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.stop_into(g_stats[26]);
         MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
@@ -957,7 +955,7 @@ static int run_job_group(const uint8_t *d_ref4, const int64_t *d_ref_off, const 
 }
 
 // run all DP jobs of one round, in groups whose direction scratch stays under the budget
-static int run_jobs(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
+static int run_jobs(const RefView &rv, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
                     const uint8_t *d_reads, const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res,
                     std::vector<uint32_t> &cig, hipStream_t st) {
     const int64_t budget = (int64_t)40 << 30;  // bytes of direction codes per group
@@ -979,7 +977,7 @@ static int run_jobs(const uint8_t *d_ref4, const int64_t *d_ref_off, const mpn_m
         std::vector<ExtJob> sub(jobs.begin() + lo, jobs.begin() + hi);
         std::vector<ExtRes> rsub;
         std::vector<uint32_t> csub;
-        if (run_job_group(d_ref4, d_ref_off, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
+        if (run_job_group(rv, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
         const int64_t base = (int64_t)cig.size();
         for (int k = 0; k < hi - lo; ++k) { rsub[k].cig_pos += base; jobs[lo + k] = sub[k]; res[lo + k] = rsub[k]; }
         cig.insert(cig.end(), csub.begin(), csub.end());
@@ -1085,7 +1083,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             ++g_stats[7];
             std::vector<ExtRes> res;
             std::vector<uint32_t> cig;
-            if (run_jobs(idx->d_seq4.p, idx->d_seq_off.p, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
+            if (run_jobs(RefView{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns}, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
             wt.stop_into(g_stats[21]);
             parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
@@ -1260,10 +1258,15 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
     for (int i = 0; i < n; ++i) { qtot = std::max<int64_t>(qtot, q_off[i] + q_len[i]); ttot = std::max<int64_t>(ttot, t_off[i] + t_len[i]); }
     std::vector<uint8_t> ascii((size_t)qtot + 16, 'N');
     for (int64_t i = 0; i < qtot; ++i) ascii[(size_t)i] = (uint8_t)"ACGTN"[qcodes[i] > 4 ? 4 : qcodes[i]];
-    DevBuf<uint8_t> d_reads, d_ref;
-    DevBuf<int64_t> d_qoff, d_toff;
+    DevBuf<uint8_t> d_reads;
+    DevBuf<uint32_t> d_ref;
+    DevBuf<int64_t> d_qoff, d_toff, d_ns, d_ne;
+    std::vector<uint32_t> words;
+    std::vector<int64_t> ns, ne;
+    pack_2bit(tcodes, ttot, words, ns, ne);
     DevBuf<int32_t> d_qlen;
-    if (d_reads.upload(ascii.data(), ascii.size(), st) || d_ref.upload(tcodes, (size_t)ttot, st) || d_qoff.upload(q_off, n, st) ||
+    if (d_reads.upload(ascii.data(), ascii.size(), st) || d_ref.upload(words.data(), words.size(), st) || d_ns.upload(ns.data(), ns.size(), st) ||
+        d_ne.upload(ne.data(), ne.size(), st) || d_qoff.upload(q_off, n, st) ||
         d_qlen.upload(q_len, n, st) || d_toff.upload(t_off, n, st))
         return -1;
     std::vector<ExtJob> jobs(n);
@@ -1279,7 +1282,7 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
     // no second pass here: the caller asks for exactly one DP per pair
     mpn_map_opt o2 = *opt;
     o2.zdrop = 0x3fffffff;
-    const int rc = run_jobs(d_ref.p, d_toff.p, &o2, jobs, d_reads.p, d_qoff.p, d_qlen.p, res, cig, st);
+    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, jobs, d_reads.p, d_qoff.p, d_qlen.p, res, cig, st);
     g_force_kernel = 0;
     if (rc) return rc;
     int64_t used = 0;

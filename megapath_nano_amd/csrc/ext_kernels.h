@@ -65,7 +65,7 @@ __device__ __forceinline__ bool ext_apply_zdrop(ExtApply &ez, int32_t H, int r, 
 __global__ __launch_bounds__(64) void ext_dp_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                     ExtParams prm, const uint8_t *__restrict__ reads,
                                                     const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                    const uint8_t *__restrict__ ref4, const int64_t *__restrict__ ref_off,
+                                                    RefView rv,
                                                     uint8_t *__restrict__ P, int32_t *__restrict__ OFF, int8_t *__restrict__ gstate,
                                                     ExtRes *__restrict__ res) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(64) void ext_dp_kernel(const ExtJob *__restrict__ j
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];
         for (int i = lane; i < qlen; i += 64) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
-        const uint8_t *tp = ref4 + ref_off[jb.rid] + jb.ts;
-        for (int i = lane; i < tlen; i += 64) ts_[i] = tp[jb.reversed ? tlen - 1 - i : i];
+        const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
+        for (int i = lane; i < tlen; i += 64) ts_[i] = (uint8_t)ref_code(rv, g0 + (jb.reversed ? tlen - 1 - i : i));
         for (int i = lane; i < tlen; i += 64) {
             u[i] = v[i] = x[i] = y[i] = (int8_t)-qe;
             x2[i] = y2[i] = (int8_t)-qe2;
@@ -238,7 +238,7 @@ template <int T>
 __global__ __launch_bounds__(64) void ext_dp_reg_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                         ExtParams prm, const uint8_t *__restrict__ reads,
                                                         const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                        const uint8_t *__restrict__ ref4, const int64_t *__restrict__ ref_off,
+                                                        RefView rv,
                                                         uint8_t *__restrict__ P, int32_t *__restrict__ OFF, ExtRes *__restrict__ res) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -261,11 +261,11 @@ __global__ __launch_bounds__(64) void ext_dp_reg_kernel(const ExtJob *__restrict
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];
         for (int i = lane; i < qlen; i += 64) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
-        const uint8_t *tp = ref4 + ref_off[jb.rid] + jb.ts;
+        const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
 #pragma unroll
         for (int k = 0; k < T; ++k) {
             const int t = k * 64 + lane;
-            TS[k] = t < tlen ? (int)tp[jb.reversed ? tlen - 1 - t : t] : 4;
+            TS[k] = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
             U[k] = V[k] = X[k] = Y[k] = -qe;
             X2[k] = Y2[k] = -qe2;
         }
@@ -365,7 +365,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void ext_dp_wg_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                        ExtParams prm, const uint8_t *__restrict__ reads,
                                                        const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                       const uint8_t *__restrict__ ref4, const int64_t *__restrict__ ref_off,
+                                                       RefView rv,
                                                        uint8_t *__restrict__ P, int32_t *__restrict__ OFF, int8_t *__restrict__ gstate,
                                                        ExtRes *__restrict__ res) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -394,9 +394,9 @@ __global__ __launch_bounds__(NT) void ext_dp_wg_kernel(const ExtJob *__restrict_
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];
         for (int i = tid; i < qlen; i += NT) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
-        const uint8_t *tp = ref4 + ref_off[jb.rid] + jb.ts;
+        const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
         for (int i = tid; i < tlen; i += NT) {
-            ts_[i] = tp[jb.reversed ? tlen - 1 - i : i];
+            ts_[i] = (uint8_t)ref_code(rv, g0 + (jb.reversed ? tlen - 1 - i : i));
             u[i] = v[i] = x[i] = y[i] = (int8_t)-qe;
             x2[i] = y2[i] = (int8_t)-qe2;
             if (!approx) H[i] = NEG_INF;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
 __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                        ExtParams prm, const uint8_t *__restrict__ reads,
                                                        const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                       const uint8_t *__restrict__ ref4, const int64_t *__restrict__ ref_off,
+                                                       RefView rv,
                                                        const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
@@ -592,14 +592,14 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
     const int64_t roff = read_off[jb.read];
     const int32_t rlen = read_len[jb.read];
-    const uint8_t *tp = ref4 + ref_off[jb.rid] + jb.ts;
+    const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
     for (int c = 0; c < r.n_cigar; ++c) {
         const uint32_t op = cig[c] & 0xf, len = cig[c] >> 4;
         if (op == 0) {
             for (uint32_t l = 0; l < len; ++l) {
-                const int ct = tp[i + l], cq = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + j + l);
-                score += (ct == 4 || cq == 4) ? -(int)(-prm.sc_n) : ct == cq ? prm.sc_mch : prm.sc_mis;
+                const int ct = ref_code(rv, g0 + i + l), cq = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + j + l);
+                score += (ct == 4 || cq == 4) ? prm.sc_n : ct == cq ? prm.sc_mch : prm.sc_mis;
                 if (score < mx) {
                     const int li = i + (int)l - max_i, lj = j + (int)l - max_j, diff = li > lj ? li - lj : lj - li;
                     const int z = mx - score - diff * prm.e;

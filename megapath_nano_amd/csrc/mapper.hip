@@ -12,6 +12,18 @@ namespace mpn {
 
 thread_local int64_t g_stats[32] = {0};
 
+void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne) {
+    words.assign((size_t)(n + 15) / 16 + 1, 0u);
+    ns.clear(); ne.clear();
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t c = codes[i];
+        if (c > 3) {
+            if (!ne.empty() && ne.back() == i) ne.back() = i + 1;
+            else { ns.push_back(i); ne.push_back(i + 1); }
+        } else words[(size_t)(i >> 4)] |= (uint32_t)c << (2 * (int)(i & 15));
+    }
+}
+
 static int grid_1d(int64_t n, int block, int cap = 256 * 16) {
     int64_t g = (n + block - 1) / block;
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
@@ -269,9 +281,17 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
     idx->n_mz = n_mz;
     idx->h_key_off = key_off;
     if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(key_off.data(), key_off.size(), st) ||
-        idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq4.upload(idx->seq4.data(), idx->seq4.size(), st) ||
-        idx->d_seq_off.upload(off.data(), off.size(), st))
+        idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq_off.upload(off.data(), off.size(), st))
         return fail();
+    {
+        std::vector<uint32_t> words;
+        std::vector<int64_t> ns, ne;
+        pack_2bit(idx->seq4.data(), total, words, ns, ne);
+        idx->n_nruns = (int32_t)ns.size();
+        if (idx->d_seq2.upload(words.data(), words.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
+            idx->d_nrun_e.upload(ne.data(), ne.size(), st))
+            return fail();
+    }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
     return idx;
 }

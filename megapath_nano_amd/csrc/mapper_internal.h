@@ -25,8 +25,9 @@ struct mpn_index {
     int64_t n_keys = 0, n_mz = 0;
     mpn::DevBuf<uint64_t> keys, pos;
     mpn::DevBuf<int64_t> key_off;
-    mpn::DevBuf<uint8_t> d_seq4;      // device: one code per base (extension kernel)
-    mpn::DevBuf<int64_t> d_seq_off;
+    mpn::DevBuf<uint32_t> d_seq2;     // device: targets packed 2 bits per base
+    mpn::DevBuf<int64_t> d_seq_off, d_nrun_s, d_nrun_e;  // + ambiguous-base runs (concatenated coordinates)
+    int32_t n_nruns = 0;
     mutable std::mutex mu;
     mutable std::vector<std::pair<float, int32_t>> mid_occ_cache;
 };
@@ -52,6 +53,9 @@ struct HostChains {
 };
 
 extern thread_local int64_t g_stats[32];
+
+// 2-bit packing of 0..4 codes (N -> 0 + run list)
+void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne);
 
 // HIP-event timer for a group of launches on one stream; accumulate() syncs on the stop event
 struct EvTimer {
