@@ -239,10 +239,13 @@ __global__ __launch_bounds__(256) void seed_fill_kernel(const u128 *__restrict__
 // Segmented LSD radix sort, one workgroup (256 threads) per segment, 8-bit digits, stable.
 // Keys are the 96 bits (x, low 32 bits of y) of 16-byte records; a pass whose digit is constant over the
 // segment costs only its histogram.  Ranks inside a 256-element tile come from ballot-based multisplit.
+template <int NY>
 __device__ __forceinline__ uint32_t sort_digit(const u128 &r, int pass) {
-    return pass < 4 ? (uint32_t)(r.y >> (8 * pass)) & 0xff : (uint32_t)(r.x >> (8 * (pass - 4))) & 0xff;
+    return pass < NY ? (uint32_t)(r.y >> (8 * pass)) & 0xff : (uint32_t)(r.x >> (8 * (pass - NY))) & 0xff;
 }
 
+// NY = 4: anchors, key (x, low 32 bits of y).  NY = 8: index records, key (x, y).
+template <int NY>
 __global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, u128 *__restrict__ tmp,
                                                        const int64_t *__restrict__ seg_off, int n_seg) {
     __shared__ uint32_t hist[256];
@@ -255,10 +258,10 @@ __global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, 
         const int64_t n = seg_off[seg + 1] - base;
         if (n < 2) continue;
         u128 *src = data + base, *dst = tmp + base;
-        for (int pass = 0; pass < 12; ++pass) {
+        for (int pass = 0; pass < NY + 8; ++pass) {
             hist[tid] = 0;
             __syncthreads();
-            for (int64_t i = tid; i < n; i += 256) atomicAdd(&hist[sort_digit(src[i], pass)], 1u);
+            for (int64_t i = tid; i < n; i += 256) atomicAdd(&hist[sort_digit<NY>(src[i], pass)], 1u);
             __syncthreads();
             if (tid == 0) s_skip = 0;
             __syncthreads();
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, 
                 const bool act = i < n;
                 u128 r;
                 uint32_t dg = 0;
-                if (act) { r = src[i]; dg = sort_digit(r, pass); }
+                if (act) { r = src[i]; dg = sort_digit<NY>(r, pass); }
                 wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
                 __syncthreads();
                 // lanes of this wave holding the same digit
@@ -601,6 +604,71 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
         for (int c = lane; c < k; c += 64) uc[c] = u[c];
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GPU index build: minimizers (hash<<8|span, position) -> records (hash, position), MSD partition by the top
+// bits of the hash into buckets, segmented radix sort of every bucket by (hash, position), then key/offset arrays.
+__global__ __launch_bounds__(256) void idx_bucket_hist_kernel(const u128 *__restrict__ mz, int64_t n, int shift, unsigned long long *__restrict__ hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&hist[(mz[i].x >> 8) >> shift], 1ULL);
+}
+
+__global__ __launch_bounds__(256) void idx_bucket_scatter_kernel(const u128 *__restrict__ mz, int64_t n, int shift,
+                                                                 unsigned long long *__restrict__ cursor, u128 *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        u128 r = mz[i];
+        r.x >>= 8;  // drop the span: the key is the hash
+        const unsigned long long p = atomicAdd(&cursor[r.x >> shift], 1ULL);
+        out[p] = r;
+    }
+}
+
+// boundaries of equal-key runs: per block of 2048 records the number of run starts
+__global__ __launch_bounds__(256) void idx_flag_count_kernel(const u128 *__restrict__ rec, int64_t n, int64_t *__restrict__ block_cnt) {
+    __shared__ int s[256];
+    const int64_t base = (int64_t)blockIdx.x * 2048;
+    int c = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < n && (i == 0 || rec[i].x != rec[i - 1].x)) ++c;
+    }
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 128; d; d >>= 1) { if (threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void idx_emit_kernel(const u128 *__restrict__ rec, int64_t n, const int64_t *__restrict__ block_off,
+                                                       uint64_t *__restrict__ keys, int64_t *__restrict__ key_off,
+                                                       uint64_t *__restrict__ pos) {
+    __shared__ int s[256];
+    const int64_t base = (int64_t)blockIdx.x * 2048;
+    // thread t owns records base + t*8 .. +8 (contiguous, so that local order = global order)
+    int flags = 0, c = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + (int64_t)threadIdx.x * 8 + k;
+        if (i < n) {
+            pos[i] = rec[i].y;
+            if (i == 0 || rec[i].x != rec[i - 1].x) { flags |= 1 << k; ++c; }
+        }
+    }
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int64_t o = block_off[blockIdx.x] + s[threadIdx.x] - c;
+    for (int k = 0; k < 8; ++k)
+        if (flags >> k & 1) {
+            const int64_t i = base + (int64_t)threadIdx.x * 8 + k;
+            keys[o] = rec[i].x;
+            key_off[o] = i;
+            ++o;
+        }
 }
 
 }  // namespace mpn

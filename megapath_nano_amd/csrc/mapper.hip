@@ -128,7 +128,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
                            pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, o.anchors.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.stop_into(g_stats[11]);
-        hipLaunchKernelGGL(seg_sort_kernel, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n);
+        hipLaunchKernelGGL(seg_sort_kernel<4>, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n);
         MPN_HIP_CHECK(hipGetLastError());
     }
     ev.stop_into(g_stats[12]);
@@ -260,29 +260,46 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
     if (d_seqs.upload((const uint8_t *)cat.data(), (size_t)total + 16, st) || d_off.upload(off.data(), n_seq, st) ||
         d_len.upload(lens, n_seq, st))
         return fail();
-    // GPU sketch of every target, then (round 1) a host sort by (hash, position) and CSR build
+    // GPU sketch of every target
     DevBuf<int64_t> mz_off;
     DevBuf<u128> mz;
     int64_t n_mz = 0;
     if (sketch_device(d_seqs.p, d_off.p, d_len.p, lens, n_seq, k, w, 0, mz_off, mz, &n_mz, st)) return fail();
-    std::vector<u128> h((size_t)n_mz);
-    if (mz.download(h.data(), (size_t)n_mz, st)) return fail();
-    if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: sync failed"); return fail(); }
-    for (auto &r : h) r.x >>= 8;
-    std::sort(h.begin(), h.end(), [](const u128 &a, const u128 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
-    std::vector<uint64_t> keys, pos((size_t)n_mz);
-    std::vector<int64_t> key_off;
-    for (int64_t i = 0; i < n_mz; ++i) {
-        if (i == 0 || h[i].x != h[i - 1].x) { keys.push_back(h[i].x); key_off.push_back(i); }
-        pos[(size_t)i] = h[i].y;
-    }
-    key_off.push_back(n_mz);
-    idx->n_keys = (int64_t)keys.size();
+    // sort by (hash, position) on the GPU: MSD partition on the top bits of the hash, then one workgroup per bucket
     idx->n_mz = n_mz;
-    idx->h_key_off = key_off;
-    if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(key_off.data(), key_off.size(), st) ||
-        idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq_off.upload(off.data(), off.size(), st))
-        return fail();
+    {
+        const int hbits = 2 * k, bbits = std::min(12, hbits), shift = hbits - bbits, nb = 1 << bbits;
+        DevBuf<unsigned long long> hist, cursor;
+        DevBuf<int64_t> bucket_cnt, bucket_off, block_cnt, block_off;
+        DevBuf<u128> rec, tmp;
+        if (hist.alloc(nb) || hist.zero(st) || cursor.alloc((size_t)nb + 1) || bucket_off.alloc((size_t)nb + 1) || rec.alloc((size_t)n_mz) ||
+            tmp.alloc((size_t)n_mz))
+            return fail();
+        const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n_mz + 255) / 256, 256 * 16));
+        if (n_mz > 0) hipLaunchKernelGGL(idx_bucket_hist_kernel, dim3(g), dim3(256), 0, st, mz.p, n_mz, shift, hist.p);
+        hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)hist.p, bucket_off.p, nb);
+        if (hipMemcpyAsync(cursor.p, bucket_off.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail();
+        if (n_mz > 0) {
+            hipLaunchKernelGGL(idx_bucket_scatter_kernel, dim3(g), dim3(256), 0, st, mz.p, n_mz, shift, cursor.p, rec.p);
+            hipLaunchKernelGGL(seg_sort_kernel<8>, dim3(nb), dim3(256), 0, st, rec.p, tmp.p, (const int64_t *)bucket_off.p, nb);
+        }
+        const int64_t n_blocks = (n_mz + 2047) / 2048;
+        if (block_cnt.alloc((size_t)n_blocks + 1) || block_off.alloc((size_t)n_blocks + 1)) return fail();
+        if (n_blocks > 0) hipLaunchKernelGGL(idx_flag_count_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_cnt.p);
+        hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, block_cnt.p, block_off.p, (int)n_blocks);
+        int64_t n_keys = 0;
+        if (hipMemcpyAsync(&n_keys, block_off.p + n_blocks, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: key count failed: %s", hipGetErrorString(hipGetLastError())); return fail(); }
+        idx->n_keys = n_keys;
+        if (idx->keys.alloc((size_t)n_keys) || idx->key_off.alloc((size_t)n_keys + 1) || idx->pos.alloc((size_t)n_mz)) return fail();
+        if (n_blocks > 0) hipLaunchKernelGGL(idx_emit_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_off.p, idx->keys.p,
+                                             idx->key_off.p, idx->pos.p);
+        if (hipMemcpyAsync(idx->key_off.p + n_keys, &n_mz, 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail();
+        idx->h_key_off.resize((size_t)n_keys + 1);
+        if (idx->key_off.download(idx->h_key_off.data(), (size_t)n_keys + 1, st)) return fail();
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("mpn_index_build: GPU sort failed"); return fail(); }
+        if (idx->d_seq_off.upload(off.data(), off.size(), st)) return fail();
+    }
     {
         std::vector<uint32_t> words;
         std::vector<int64_t> ns, ne;
