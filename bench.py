@@ -87,9 +87,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--genomes', type=int, default=100)
-    ap.add_argument('--genome-len', type=int, default=2000000)
-    ap.add_argument('--strain-pairs', type=int, default=2)
+    ap.add_argument('--genomes', type=int, default=250)
+    ap.add_argument('--genome-len', type=int, default=4000000)
+    ap.add_argument('--strain-pairs', type=int, default=10)
     ap.add_argument('--reads-per-step', type=int, default=32768)
     ap.add_argument('--mean-len', type=int, default=8000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -201,7 +201,8 @@ def main():
             'workload': f'configs[2] scaled: {args.reads_per_step} synthetic ONT-like reads/step/GPU (Gamma lengths, mean '
                         f'{args.mean_len} bp, 12% errors; in-repo stand-in for badread) from a 10-member community incl. a '
                         f'99%-identity strain pair, vs a resident index of {args.genomes} synthetic genomes x '
-                        f'{args.genome_len} bp (NOT full RefSeq: round-1 index build sorts on the host), '
+                        f'{args.genome_len} bp incl. {args.strain_pairs} 99%-identity strain copies (a scaled stand-in for the full RefSeq '
+                        f'bacterial index: genomes are generated on the host per rank), '
                         f'-N 50 -p 1 -x map-ont -c, reassignment on',
             'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': args.genomes, 'index_bp': args.genomes * args.genome_len,
             'index_build_s': round(index_s, 2), 'parallelism': f'reads sharded over {world} GPU(s), index replicated',
