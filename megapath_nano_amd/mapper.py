@@ -241,7 +241,7 @@ def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True):
 
 
 def ext_dp_batch(opt, queries, targets, w, zdrop, end_bonus, flag, force_kernel=0):
-    """DP stage on (query, target) pairs of 0..4 codes -> list of dicts like the oracle's mmo_extd2 result."""
+    """DP stage on (query, target) pairs of 0..4 codes -> list of dicts (max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar, cigar)."""
     lib = _bind()
     n = len(queries)
     qbuf, qoff, qlen = pack_seqs([np.asarray(q, dtype=np.uint8) for q in queries])
