@@ -787,6 +787,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
     std::vector<int32_t> wg_order[3][5];  // large windows: workgroup-per-window kernel, by threads (256/512/1024) and LDS class
     std::vector<int8_t> wg_nt(nj, 0);
     std::vector<int32_t> reg_order[2];  // first pass through the register-resident kernel (gap fills, tlen <= 256 / 512)
+    std::vector<int32_t> strip_order[2];  // ... through the systolic strip kernel when the band never clips
     std::vector<int8_t> use_wg(nj, 0);
     std::vector<int8_t> lds_cls(nj, 0);
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
@@ -799,7 +800,12 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         n_col = std::min(n_col, w + 1) + 1;
         jb.n_col = n_col;
         const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
-        jb.p_off = p_tot; p_tot += n_r * n_col;
+        const bool reg_elig = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
+        const bool strip = reg_elig && w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
+        jb.layout = strip ? 1 : 0;
+        jb.qstride = (jb.qlen + 3) & ~3;
+        // (a strip window keeps room for the anti-diagonal layout of a possible exact second pass)
+        jb.p_off = p_tot; p_tot += (std::max<int64_t>(strip ? (int64_t)jb.tlen * jb.qstride : 0, n_r * n_col) + 15) & ~(int64_t)15;
         jb.row_off = row_tot; row_tot += n_r;
         cig_tot += jb.qlen + jb.tlen + 2; jb.cig_off = cig_tot;
         cells += n_r * n_col;
@@ -817,7 +823,11 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         use_wg[j] = (int8_t)(g_force_kernel == 3 || (g_force_kernel == 0 && n_col - 1 > 128));
         if (g_force_kernel == 1) use_wg[j] = 0;
         wg_nt[j] = (int8_t)(n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2);
-        if (reg_ok && (g_force_kernel == 0 || g_force_kernel == 2)) {
+        if (jb.layout == 1) {
+            const int rc = jb.tlen <= 256 ? 0 : 1;
+            strip_order[rc].push_back(j);
+            reg_lds_max[rc] = std::max(reg_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
+        } else if (reg_ok && (g_force_kernel == 0 || g_force_kernel == 2)) {
             const int rc = jb.tlen <= 256 ? 0 : 1;
             reg_order[rc].push_back(j);
             reg_lds_max[rc] = std::max(reg_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
@@ -830,11 +840,12 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
             &pool_CIG = SL.pool_CIG, &pool_res = SL.pool_res, &pool_gap = SL.pool_gap, &pool_redo = SL.pool_redo,
             &pool_compact = SL.pool_compact, &pool_used = SL.pool_used, &pin_res = SL.pin_res, &pin_cig = SL.pin_cig;
     std::vector<int32_t> flat;
-    int base[5], reg_base[2], wg_base[3][5];
+    int base[5], reg_base[2], wg_base[3][5], strip_base[2];
     for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
     for (int t = 0; t < 3; ++t)
         for (int c = 0; c < 5; ++c) { wg_base[t][c] = (int)flat.size(); flat.insert(flat.end(), wg_order[t][c].begin(), wg_order[t][c].end()); }
     for (int c = 0; c < 2; ++c) { reg_base[c] = (int)flat.size(); flat.insert(flat.end(), reg_order[c].begin(), reg_order[c].end()); }
+    for (int c = 0; c < 2; ++c) { strip_base[c] = (int)flat.size(); flat.insert(flat.end(), strip_order[c].begin(), strip_order[c].end()); }
     if (pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || pool_P.ensure((size_t)p_tot) || pool_OFF.ensure((size_t)row_tot * 2 * 4) ||
         pool_state.ensure((size_t)state_tot) || pool_CIG.ensure((size_t)cig_tot * 4) || pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
         pool_order.ensure(flat.size() * 4) || pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
@@ -886,6 +897,16 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
             if (launch_wg(t, d_order.p + wg_base[t][c], (int)wg_order[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
     for (int c = 0; c < 5; ++c)
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+    if (!strip_order[0].empty()) {
+        hipLaunchKernelGGL(ext_dp_strip_kernel<4>, dim3((unsigned)strip_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
+                           d_order.p + strip_base[0], (int)strip_order[0].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    if (!strip_order[1].empty()) {
+        hipLaunchKernelGGL(ext_dp_strip_kernel<8>, dim3((unsigned)strip_order[1].size()), dim3(64), reg_lds_max[1], st, d_jobs.p,
+                           d_order.p + strip_base[1], (int)strip_order[1].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
     if (!reg_order[0].empty()) {
         hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3((unsigned)reg_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
                            d_order.p + reg_base[0], (int)reg_order[0].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
@@ -916,7 +937,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
         std::vector<int32_t> redo[5], redo_wg[3][5];
         std::vector<int32_t> redo_flat;
-        for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; }
+        for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; jobs[j].layout = 0; }
         for (int j : gap) if (res[j].zcode) { if (use_wg[j]) redo_wg[(int)wg_nt[j]][(int)lds_cls[j]].push_back(j); else redo[(int)lds_cls[j]].push_back(j); }
         int rbase[5], rwbase[3][5];
         for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }

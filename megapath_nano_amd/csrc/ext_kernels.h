@@ -29,6 +29,8 @@ struct ExtJob {
     int32_t n_col;
     int32_t state_mode;  // 0: state arrays in LDS, 1: in global scratch
     int64_t state_off;
+    int32_t layout;      // direction matrix: 0 = [anti-diagonal][t - band start], 1 = [t][j] rows of qstride bytes (strip kernel)
+    int32_t qstride;
 };
 
 struct ExtRes {
@@ -527,6 +529,114 @@ __global__ __launch_bounds__(NT) void ext_dp_wg_kernel(const ExtJob *__restrict_
     if (tid == 0) res[jid] = out;
 }
 
+// Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 64*S): lane l owns
+// the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l, so after a 63-step
+// ramp every lane computes S cells per step -- no partially filled anti-diagonal tiles.  The left neighbour (t, j-1)
+// of a cell is the lane's own previous step (u, y, y2 kept per row in VGPRs), the upper neighbour (t-1, j) is the
+// previous row of the same step or, for the first row of a strip, the bottom row lane l-1 finished one step earlier
+// (one DPP wave_shr per state).  Query bases ride the same shift.  Same recurrences, boundary rules and direction
+// codes as ext_dp_kernel; directions are written row-major [t][j], four columns per 32-bit store.
+template <int S>
+__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                          ExtParams prm, const uint8_t *__restrict__ reads,
+                                                          const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x;
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    const int qlen = jb.qlen, tlen = jb.tlen;
+    int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    ExtRes out;
+    out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
+    out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
+    if (qlen <= 0 || tlen <= 0 || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
+    uint8_t *qs_ = smem;
+    {
+        const int64_t roff = read_off[jb.read];
+        const int32_t rlen = read_len[jb.read];
+        for (int i = lane; i < qlen; i += 64) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
+    }
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+#define MPN_BND(R) ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2)
+    int UL[S], YL[S], Y2L[S], TS[S];
+    uint32_t DW[S];
+    const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
+    const int t0 = lane * S;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const int t = t0 + k;
+        TS[k] = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
+        UL[k] = MPN_BND(t);   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
+        YL[k] = -qe; Y2L[k] = -qe2;
+        DW[k] = 0;
+    }
+    __syncthreads();
+    const bool right = (jb.flag & EZ_RIGHT) != 0;
+    const int n_lanes = (tlen + S - 1) / S;
+    const int n_steps = qlen + n_lanes - 1;
+    const int qstride = jb.qstride;
+    uint32_t *p32 = reinterpret_cast<uint32_t *>(P + jb.p_off);
+    int out_v = 0, out_x = 0, out_x2 = 0, qb = 4;
+    int32_t col0 = 0, lastrow = 0;  // sum of first-column / last-row differences for the corner score
+    const int last_lane = (tlen - 1) / S, last_k = (tlen - 1) - last_lane * S;
+    for (int step = 0; step < n_steps; ++step) {
+        // bases and bottom-row states move one lane to the right
+        const int q_in = step < qlen ? (int)qs_[step] : 4;
+        qb = wave_shr1(qb, q_in);
+        int v_up = wave_shr1(out_v, 0), x_up = wave_shr1(out_x, 0), x2_up = wave_shr1(out_x2, 0);
+        const int j = step - lane;
+        const bool col_ok = j >= 0 && j < qlen && lane < n_lanes;
+        if (lane == 0) { v_up = MPN_BND(j); x_up = -qe; x2_up = -qe2; }
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int t = t0 + k;
+            const bool act = col_ok && t < tlen;
+            const int sq = TS[k];
+            const int sc = (sq == 4 || qb == 4) ? prm.sc_n : sq == qb ? prm.sc_mch : prm.sc_mis;
+            const int ut = UL[k];
+            int z = sc, a = x_up + v_up, b = YL[k] + ut, a2 = x2_up + v_up, b2 = Y2L[k] + ut, d;
+            if (!right) {
+                d = a > z ? 1 : 0; z = max(z, a);
+                d = b > z ? 2 : d; z = max(z, b);
+                d = a2 > z ? 3 : d; z = max(z, a2);
+                d = b2 > z ? 4 : d; z = max(z, b2);
+            } else {
+                d = z > a ? 0 : 1; z = max(z, a);
+                d = z > b ? d : 2; z = max(z, b);
+                d = z > a2 ? d : 3; z = max(z, a2);
+                d = z > b2 ? d : 4; z = max(z, b2);
+            }
+            z = min(z, (int)prm.sc_mch);
+            const int nu = z - v_up, nv = z - ut;
+            int tmp = z - q; a -= tmp; b -= tmp;
+            tmp = z - q2; a2 -= tmp; b2 -= tmp;
+            if (!right) { d |= a > 0 ? 0x08 : 0; d |= b > 0 ? 0x10 : 0; d |= a2 > 0 ? 0x20 : 0; d |= b2 > 0 ? 0x40 : 0; }
+            else { d |= a >= 0 ? 0x08 : 0; d |= b >= 0 ? 0x10 : 0; d |= a2 >= 0 ? 0x20 : 0; d |= b2 >= 0 ? 0x40 : 0; }
+            if (act) {
+                UL[k] = nu; YL[k] = max(b, 0) - qe; Y2L[k] = max(b2, 0) - qe2;
+                v_up = nv; x_up = max(a, 0) - qe; x2_up = max(a2, 0) - qe2;
+                DW[k] |= (uint32_t)d << (8 * (j & 3));
+                if ((j & 3) == 3 || j == qlen - 1) { p32[((int64_t)t * qstride + (j & ~3)) >> 2] = DW[k]; DW[k] = 0; }
+                if (j == 0) col0 += t == 0 ? z : nu;
+                if (lane == last_lane && k == last_k && j > 0) lastrow += nv;
+            }
+        }
+        out_v = v_up; out_x = x_up; out_x2 = x2_up;
+    }
+#undef MPN_BND
+    int32_t tot = col0 + lastrow;
+    for (int dlt = 32; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
+    out.score = tot;
+    out.r_done = qlen + tlen - 2;
+    out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1;
+    if (lane == 0) res[jid] = out;
+}
+
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
 __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                     const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
@@ -541,6 +651,7 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     const int n_col = jb.n_col, n_r = jb.qlen + jb.tlen - 1;
     const uint8_t *p = P + jb.p_off;
     const int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
+    const bool rowmajor = jb.layout == 1;  // strip kernel: [t][j], band never clips
     const bool rev_cigar = (jb.flag & EZ_REV_CIGAR) != 0;
     // ops are generated last-to-first.  REV_CIGAR keeps that order (write forward from the region start),
     // otherwise they are written back to front so that they read forward.
@@ -554,9 +665,12 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     while (i >= 0 && j >= 0) {
         const int rr = i + j;
         int force_state = -1, tmp;
-        if (i < off[rr]) force_state = 2;
-        if (i > off_end[rr]) force_state = 1;
-        tmp = force_state < 0 ? p[(int64_t)rr * n_col + i - off[rr]] : 0;
+        if (rowmajor) tmp = p[(int64_t)i * jb.qstride + j];
+        else {
+            if (i < off[rr]) force_state = 2;
+            if (i > off_end[rr]) force_state = 1;
+            tmp = force_state < 0 ? p[(int64_t)rr * n_col + i - off[rr]] : 0;
+        }
         if (state == 0) state = tmp & 7;
         else if (!(tmp >> (state + 2) & 1)) state = 0;
         if (state == 0) state = tmp & 7;

@@ -71,11 +71,14 @@ def opt(libmpn, oracle_built):
 
 def test_gap_fill_windows_all_kernels(opt):
     qs, ts = make_pairs(1, [30, 64, 65, 128, 200, 230, 256, 257, 300, 400, 511])
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 0])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 0])
     qs, ts = make_pairs(2, [220, 260, 310], ambig=True)
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4])
     qs, ts = make_pairs(3, [450, 500], big_indel=True)
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4])
+    qs, ts = make_pairs(11, [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 512])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 4])
+    check(opt, qs, ts, 751, 400, -1, APPROX | RIGHT, [1, 4])
 
 
 def test_exact_global_mode(opt):
