@@ -335,12 +335,32 @@ struct ChainParams {
 
 __device__ __forceinline__ int ilog2_32(uint32_t v) { return 31 - __clz((int)v); }
 
+// The last CW anchors (coordinates, f, p, v and the per-iteration mark t) are mirrored in an LDS ring and the anchors
+// themselves are fetched / their results written back 64 at a time (one per lane, coalesced, next chunk prefetched),
+// so the sequential loop touches global memory only for predecessors further back than CW.  The lower end of the
+// predecessor range needs no state: a predecessor is in range iff its reference coordinate is within max_dist_x and it
+// is at most max_iter anchors back, and the anchors are sorted.  Single-wave workgroup: LDS accesses of one wave are
+// ordered, so only a compiler/LDS fence separates the phases (a full __syncthreads would also drain the global stores).
+constexpr int CHAIN_CW = 512;
+#define MPN_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return (uint64_t)hi << 32 | lo;
+}
+
 __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
-                                                      int n_reads, ChainParams cp, int32_t *__restrict__ F, int32_t *__restrict__ P,
-                                                      int32_t *__restrict__ T, int32_t *__restrict__ V) {
+                                                      const int32_t *__restrict__ read_order, int n_reads, ChainParams cp,
+                                                      int32_t *__restrict__ F, int32_t *__restrict__ P, int32_t *__restrict__ T,
+                                                      int32_t *__restrict__ V) {
     __shared__ int mark[64];
+    __shared__ uint64_t wx[CHAIN_CW], wy[CHAIN_CW];
+    __shared__ int32_t wf[CHAIN_CW], wp[CHAIN_CW], wt[CHAIN_CW], wv[CHAIN_CW];
+    constexpr int64_t M = CHAIN_CW - 1;
     const int lane = threadIdx.x;
-    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+    for (int ridx = blockIdx.x; ridx < n_reads; ridx += gridDim.x) {
+        const int read = read_order[ridx];
         const int64_t base = anchor_off[read];
         const int64_t n = anchor_off[read + 1] - base;
         if (n == 0) continue;
@@ -352,42 +372,57 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
         for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
         const float avg_qspan = (float)sum / (float)n;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        int64_t st = 0;
+        // chunk registers: lane l holds anchor c0 + l of the current chunk and of the next one; results of the chunk
+        uint64_t cx = lane < n ? a[lane].x : 0, cy = lane < n ? a[lane].y : 0, nx = 0, ny = 0;
+        int32_t rf = 0, rp = -1, rv = 0;
         for (int64_t i = 0; i < n; ++i) {
-            const uint64_t ri = a[i].x;
-            const int32_t qi = (int32_t)a[i].y, q_span = a[i].y >> 32 & 0xff;
+            const int li = (int)(i & 63);
+            if (li == 0) {  // prefetch the next chunk
+                const int64_t k = i + 64 + lane;
+                if (k < n) { nx = a[k].x; ny = a[k].y; }
+            }
+            const uint64_t ri = readlane_u64(cx, li), yi = readlane_u64(cy, li);
+            const int32_t qi = (int32_t)yi, q_span = yi >> 32 & 0xff;
             int32_t max_f = q_span, n_skip = 0;
             int64_t max_j = -1;
-            while (st < i && ri > a[st].x + (uint64_t)cp.max_dist_x) ++st;
-            if (i - st > cp.max_iter) st = i - cp.max_iter;
-            bool broke = false;
-            for (int64_t j0 = i - 1; j0 >= st && !broke; j0 -= 64) {
+            const int64_t win_lo = i - CHAIN_CW;  // anchors j >= win_lo (and < i) are in the LDS ring
+            bool done = false;
+            for (int64_t j0 = i - 1; j0 >= 0 && !done; j0 -= 64) {
                 const int64_t j = j0 - lane;
-                const bool in = j >= st;
+                const bool inw = j >= win_lo;
+                bool in = j >= 0 && i - j <= cp.max_iter;
                 bool cont = true;
                 int32_t sc = NEG_INF, pj = -1, tj = 0;
                 if (in) {
-                    const uint64_t ax = a[j].x, ay = a[j].y;
-                    const int64_t dr = (int64_t)(ri - ax);
-                    const int32_t dq = qi - (int32_t)ay;
-                    pj = p[j]; tj = t[j];
-                    if (!(dr == 0 || dq <= 0) && !(dq > cp.max_dist_y || dq > cp.max_dist_x)) {
-                        const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-                        if (dd <= cp.bw) {
-                            const int32_t min_d = dq < dr ? dq : (int32_t)dr;
-                            int32_t s = min_d > q_span ? q_span : min_d;
-                            const int32_t log_dd = dd ? ilog2_32((uint32_t)dd) : 0;
-                            const int32_t gap_cost = (int)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);
-                            sc = s - gap_cost + f[j];
-                            cont = false;
+                    uint64_t ax, ay;
+                    int32_t fj;
+                    if (inw) { const int sl = (int)(j & M); ax = wx[sl]; ay = wy[sl]; pj = wp[sl]; tj = wt[sl]; fj = wf[sl]; }
+                    else { ax = a[j].x; ay = a[j].y; pj = p[j]; tj = t[j]; fj = f[j]; }
+                    if (ri > ax + (uint64_t)cp.max_dist_x) in = false;  // out of range: so is everything before it
+                    else {
+                        const int64_t dr = (int64_t)(ri - ax);
+                        const int32_t dq = qi - (int32_t)ay;
+                        if (!(dr == 0 || dq <= 0) && !(dq > cp.max_dist_y || dq > cp.max_dist_x)) {
+                            const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+                            if (dd <= cp.bw) {
+                                const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+                                int32_t s = min_d > q_span ? q_span : min_d;
+                                const int32_t log_dd = dd ? ilog2_32((uint32_t)dd) : 0;
+                                const int32_t gap_cost = (int)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);
+                                sc = s - gap_cost + fj;
+                                cont = false;
+                            }
                         }
                     }
                 }
+                if (!in) pj = -1;
+                // the range ends inside (or right after) this tile if any lane fell out of it
+                if (__ballot(!in)) done = true;
                 // marks made by earlier lanes of this tile (p[j'] == my j)
                 mark[lane] = 0;
-                __syncthreads();
+                MPN_LDS_FENCE();
                 if (!cont && pj >= 0 && j0 - pj < 64 && j0 - pj >= 0) mark[(int)(j0 - pj)] = 1;
-                __syncthreads();
+                MPN_LDS_FENCE();
                 const bool tmark = (tj == (int32_t)i) || mark[lane];
                 // running maximum before each lane (sequential order = lane order)
                 const int incl = wave_scan_max(cont ? NEG_INF : sc);
@@ -414,18 +449,33 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                     max_f = best;
                     max_j = j0 - wl;
                 }
-                if (elig && pj >= 0) t[pj] = (int32_t)i;
-                if (brk < 64) broke = true;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                bool gmark = false;
+                if (elig && pj >= 0) {
+                    if (pj >= win_lo) wt[(int)(pj & M)] = (int32_t)i;
+                    else { t[pj] = (int32_t)i; gmark = true; }
+                }
+                if (brk < 64) done = true;
+                // a mark that went to global memory must be visible to the later tiles of this anchor
+                if (__ballot(gmark)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                MPN_LDS_FENCE();
             }
+            int32_t vprev = 0;
+            if (max_j >= 0) vprev = max_j >= win_lo ? wv[(int)(max_j & M)] : v[max_j];
+            const int32_t vi = (max_j >= 0 && vprev > max_f) ? vprev : max_f;
+            if (lane == li) { rf = max_f; rp = (int32_t)max_j; rv = vi; }
             if (lane == 0) {
-                f[i] = max_f;
-                p[i] = (int32_t)max_j;
-                v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+                const int sl = (int)(i & M);
+                wx[sl] = ri; wy[sl] = yi; wf[sl] = max_f; wp[sl] = (int32_t)max_j; wv[sl] = vi; wt[sl] = 0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            MPN_LDS_FENCE();
+            if (li == 63 || i == n - 1) {  // write the chunk back, coalesced; move to the prefetched chunk
+                const int64_t k = (i & ~(int64_t)63) + lane;
+                if (k <= i) { f[k] = rf; p[k] = rp; v[k] = rv; }
+                cx = nx; cy = ny;
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
     }
 }
 
