@@ -766,6 +766,8 @@ static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *nam
 // per-worker resources: a stream, a device arena, grow-only scratch pools and pinned staging buffers
 struct Slot {
     hipStream_t st = nullptr;
+    hipStream_t st2 = nullptr;       // side stream: the few long windows run beside the many short ones
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_gap, pool_redo, pool_compact, pool_used;
     PoolBuf pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
@@ -787,7 +789,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
     std::vector<int32_t> wg_order[3][5];  // large windows: workgroup-per-window kernel, by threads (256/512/1024) and LDS class
     std::vector<int8_t> wg_nt(nj, 0);
     std::vector<int32_t> reg_order[2];  // first pass through the register-resident kernel (gap fills, tlen <= 256 / 512)
-    std::vector<int32_t> strip_order[2];  // ... through the systolic strip kernel when the band never clips
+    std::vector<int32_t> strip_order[3];  // ... through the systolic strip kernel (tlen <= 256 / 512 / 1024) when the band never clips
+    size_t strip_lds_max[3] = {64, 64, 64};
     std::vector<int8_t> use_wg(nj, 0);
     std::vector<int8_t> lds_cls(nj, 0);
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
@@ -800,8 +803,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         n_col = std::min(n_col, w + 1) + 1;
         jb.n_col = n_col;
         const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
-        const bool reg_elig = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
-        const bool strip = reg_elig && w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
+        const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
+                           w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
         jb.layout = strip ? 1 : 0;
         jb.qstride = (jb.qlen + 3) & ~3;
         // (a strip window keeps room for the anti-diagonal layout of a possible exact second pass)
@@ -824,9 +827,9 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         if (g_force_kernel == 1) use_wg[j] = 0;
         wg_nt[j] = (int8_t)(n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2);
         if (jb.layout == 1) {
-            const int rc = jb.tlen <= 256 ? 0 : 1;
+            const int rc = jb.tlen <= 256 ? 0 : jb.tlen <= 512 ? 1 : 2;
             strip_order[rc].push_back(j);
-            reg_lds_max[rc] = std::max(reg_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
+            strip_lds_max[rc] = std::max(strip_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
         } else if (reg_ok && (g_force_kernel == 0 || g_force_kernel == 2)) {
             const int rc = jb.tlen <= 256 ? 0 : 1;
             reg_order[rc].push_back(j);
@@ -835,17 +838,27 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         else order[cls].push_back(j);
     }
     g_stats[4] += nj; g_stats[5] += cells;
+    if (getenv("MPN_DEBUG_JOBS")) {
+        auto summ = [&](const char *nm, const std::vector<int32_t> &v) {
+            int64_t c = 0, mx = 0, ext = 0;
+            for (int j : v) { const int64_t z = ((int64_t)jobs[j].qlen + jobs[j].tlen - 1) * jobs[j].n_col; c += z; mx = std::max(mx, z); ext += (jobs[j].flag & EZ_EXTZ_ONLY) != 0; }
+            if (!v.empty()) fprintf(stderr, "[jobs] %-10s n=%zu cells=%.2fG max=%.1fM ext=%lld\n", nm, v.size(), c / 1e9, mx / 1e6, (long long)ext);
+        };
+        for (int c = 0; c < 5; ++c) { char b[32]; snprintf(b, 32, "lds%d", c); summ(b, order[c]); }
+        for (int t = 0; t < 3; ++t) for (int c = 0; c < 5; ++c) { char b[32]; snprintf(b, 32, "wg%d_%d", 256 << t, c); summ(b, wg_order[t][c]); }
+        summ("reg4", reg_order[0]); summ("reg8", reg_order[1]); summ("strip4", strip_order[0]); summ("strip8", strip_order[1]); summ("strip16", strip_order[2]);
+    }
     Slot &SL = *tl_slot;
     PoolBuf &pool_jobs = SL.pool_jobs, &pool_P = SL.pool_P, &pool_OFF = SL.pool_OFF, &pool_order = SL.pool_order, &pool_state = SL.pool_state,
             &pool_CIG = SL.pool_CIG, &pool_res = SL.pool_res, &pool_gap = SL.pool_gap, &pool_redo = SL.pool_redo,
             &pool_compact = SL.pool_compact, &pool_used = SL.pool_used, &pin_res = SL.pin_res, &pin_cig = SL.pin_cig;
     std::vector<int32_t> flat;
-    int base[5], reg_base[2], wg_base[3][5], strip_base[2];
+    int base[5], reg_base[2], wg_base[3][5], strip_base[3];
     for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
     for (int t = 0; t < 3; ++t)
         for (int c = 0; c < 5; ++c) { wg_base[t][c] = (int)flat.size(); flat.insert(flat.end(), wg_order[t][c].begin(), wg_order[t][c].end()); }
     for (int c = 0; c < 2; ++c) { reg_base[c] = (int)flat.size(); flat.insert(flat.end(), reg_order[c].begin(), reg_order[c].end()); }
-    for (int c = 0; c < 2; ++c) { strip_base[c] = (int)flat.size(); flat.insert(flat.end(), strip_order[c].begin(), strip_order[c].end()); }
+    for (int c = 0; c < 3; ++c) { strip_base[c] = (int)flat.size(); flat.insert(flat.end(), strip_order[c].begin(), strip_order[c].end()); }
     if (pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || pool_P.ensure((size_t)p_tot) || pool_OFF.ensure((size_t)row_tot * 2 * 4) ||
         pool_state.ensure((size_t)state_tot) || pool_CIG.ensure((size_t)cig_tot * 4) || pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
         pool_order.ensure(flat.size() * 4) || pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
@@ -891,22 +904,35 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         return 0;
     };
     EvTimer ev(st);
-    // the few large windows go first: they are the long pole of the launch sequence
-    for (int t = 2; t >= 0; --t)
-        for (int c = 4; c >= 0; --c)
-            if (launch_wg(t, d_order.p + wg_base[t][c], (int)wg_order[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+    // the few large windows are the long pole: they go to a side stream and overlap the short windows below
+    if (!SL.st2) {
+        MPN_HIP_CHECK(hipStreamCreateWithFlags(&SL.st2, hipStreamNonBlocking));
+        MPN_HIP_CHECK(hipEventCreateWithFlags(&SL.ev_a, hipEventDisableTiming));
+        MPN_HIP_CHECK(hipEventCreateWithFlags(&SL.ev_b, hipEventDisableTiming));
+    }
+    MPN_HIP_CHECK(hipEventRecord(SL.ev_a, st));
+    MPN_HIP_CHECK(hipStreamWaitEvent(SL.st2, SL.ev_a, 0));
+    {
+        hipStream_t st_main = st;
+        st = SL.st2;
+        for (int t = 2; t >= 0; --t)
+            for (int c = 4; c >= 0; --c)
+                if (launch_wg(t, d_order.p + wg_base[t][c], (int)wg_order[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
+        st = st_main;
+    }
+    MPN_HIP_CHECK(hipEventRecord(SL.ev_b, SL.st2));
     for (int c = 0; c < 5; ++c)
         if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
-    if (!strip_order[0].empty()) {
-        hipLaunchKernelGGL(ext_dp_strip_kernel<4>, dim3((unsigned)strip_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
-                           d_order.p + strip_base[0], (int)strip_order[0].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
+#define MPN_STRIP_LAUNCH(C, SS)                                                                                                  \
+    if (!strip_order[C].empty()) {                                                                                                \
+        hipLaunchKernelGGL(ext_dp_strip_kernel<SS>, dim3((unsigned)strip_order[C].size()), dim3(64), strip_lds_max[C], st, d_jobs.p, \
+                           d_order.p + strip_base[C], (int)strip_order[C].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p); \
+        MPN_HIP_CHECK(hipGetLastError());                                                                                       \
     }
-    if (!strip_order[1].empty()) {
-        hipLaunchKernelGGL(ext_dp_strip_kernel<8>, dim3((unsigned)strip_order[1].size()), dim3(64), reg_lds_max[1], st, d_jobs.p,
-                           d_order.p + strip_base[1], (int)strip_order[1].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
-    }
+    MPN_STRIP_LAUNCH(2, 16)
+    MPN_STRIP_LAUNCH(1, 8)
+    MPN_STRIP_LAUNCH(0, 4)
+#undef MPN_STRIP_LAUNCH
     if (!reg_order[0].empty()) {
         hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3((unsigned)reg_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
                            d_order.p + reg_base[0], (int)reg_order[0].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
@@ -917,6 +943,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
                            d_order.p + reg_base[1], (int)reg_order[1].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
     }
+    MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
     ev.stop_into(g_stats[15]);
     hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());

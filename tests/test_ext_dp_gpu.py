@@ -76,7 +76,7 @@ def test_gap_fill_windows_all_kernels(opt):
     check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4])
     qs, ts = make_pairs(3, [450, 500], big_indel=True)
     check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4])
-    qs, ts = make_pairs(11, [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 512])
+    qs, ts = make_pairs(11, [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 512, 513, 600, 700])
     check(opt, qs, ts, 751, 400, -1, APPROX, [1, 4])
     check(opt, qs, ts, 751, 400, -1, APPROX | RIGHT, [1, 4])
 
