@@ -806,9 +806,12 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
         const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
                            w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
         jb.layout = strip ? 1 : 0;
-        jb.qstride = (jb.qlen + 3) & ~3;
+        jb.strip_s = jb.tlen <= 256 ? 4 : jb.tlen <= 512 ? 8 : 16;
+        const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
+        jb.qstride = strip_lanes * jb.strip_s;  // row width of the step-major direction matrix
+        const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * jb.qstride;
         // (a strip window keeps room for the anti-diagonal layout of a possible exact second pass)
-        jb.p_off = p_tot; p_tot += (std::max<int64_t>(strip ? (int64_t)jb.tlen * jb.qstride : 0, n_r * n_col) + 15) & ~(int64_t)15;
+        jb.p_off = p_tot; p_tot += (std::max<int64_t>(strip ? strip_bytes : 0, n_r * n_col) + 15) & ~(int64_t)15;
         jb.row_off = row_tot; row_tot += n_r;
         cig_tot += jb.qlen + jb.tlen + 2; jb.cig_off = cig_tot;
         cells += n_r * n_col;
