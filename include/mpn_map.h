@@ -84,7 +84,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
 /* ---- stage: the banded dual-affine extension DP on arbitrary pairs of 0..4 code strings (parity tests) -------
  * flag bits as in ksw2: 0x02 approximate max, 0x08 right-align gaps, 0x40 extension only, 0x80 reversed CIGAR.
  * force_kernel: 0 = dispatch as mpn_map_batch does, 1 = single-wave LDS kernel, 2 = register kernel where
- * eligible, 3 = workgroup kernel, 4 = systolic strip kernel where eligible.  out9[i*9..] = max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar. */
+ * eligible, 3 = workgroup kernel, 4 = systolic strip kernel where eligible, 5 = band-in-registers kernel where the band fits 1024 slots.  out9[i*9..] = max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar. */
 int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t *qcodes, const int64_t *q_off, const int32_t *q_len,
                      const uint8_t *tcodes, const int64_t *t_off, const int32_t *t_len, const int32_t *w, const int32_t *zdrop,
                      const int32_t *end_bonus, const int32_t *flag, int32_t force_kernel, int32_t *out9, uint32_t *cigar_pool,
@@ -121,7 +121,9 @@ int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
  *  [23] host: rank/MAPQ/PAF  [24] whole call
  * device ns measured with HIP events on the stream the kernels run on:
  *  [10] sketch  [11] seed lookup+fill  [12] anchor sort  [13] chain DP  [14] chain ends+backtrack
- *  [15] extension DP kernel  [25] traceback kernel  [26] z-drop test kernel */
+ *  [15] extension DP kernel  [25] traceback kernel  [26] z-drop test kernel
+ *  inside [21], wall ns: [27] host: kernel choice + scratch layout + staging  [28] enqueue  [29] wait for the GPU
+ *  [30] second pass + CIGAR download */
 void mpn_map_last_stats(int64_t stats[32]);
 
 #ifdef __cplusplus

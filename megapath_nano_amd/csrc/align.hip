@@ -626,7 +626,7 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
 
 // returns true if a split remainder was produced in r2
 static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, const uint8_t *qseq_strand[2], Reg &r, Reg &r2,
-                         const u128 *a, const Plan &pl, const std::vector<ExtRes> &res, const std::vector<ExtJob> &jobs,
+                         const u128 *a, const Plan &pl, const ExtRes *res, const ExtJob *jobs,
                          const uint32_t *cig_pool) {
     const int32_t rid = a[r.as].x << 1 >> 33, rev = a[r.as].x >> 63;
     int8_t mat[25];
@@ -762,147 +762,221 @@ static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *nam
     }
 }
 
-// run one group of DP jobs on the GPU (its scratch fits the budget)
 // per-worker resources: a stream, a device arena, grow-only scratch pools and pinned staging buffers
 struct Slot {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;       // side stream: the few long windows run beside the many short ones
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     Arena arena;
-    PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_gap, pool_redo, pool_compact, pool_used;
-    PoolBuf pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
+    PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
+    PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
 };
-static Slot g_slots[4];
+static Slot g_slots[8];
 static thread_local Slot *tl_slot = &g_slots[0];
 
-static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel
+static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel, 4 strip, 5 band
 
-static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
-                         const uint8_t *d_reads, const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res,
-                         std::vector<uint32_t> &cig, hipStream_t st) {
-    const int nj = (int)jobs.size();
-    res.assign(nj, ExtRes());
+static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn) {
+    if (n_threads <= 1 || n < 8192) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back([&, t]() { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+    for (auto &x : th) x.join();
+}
+
+// the second pass of a gap fill whose CIGAR failed the z-drop test: exact maximum, band (or anti-diagonal) layout
+__global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const int32_t *layout, const int32_t *qstride, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    ExtJob &jb = jobs[ids[k]];
+    jb.flag &= ~EZ_APPROX_MAX;
+    jb.layout = layout[k];
+    jb.qstride = qstride[k];
+}
+
+// launch lists: every DP job of a group belongs to exactly one
+enum { L_LDS = 0, L_WG = 5, L_REG = 20, L_STRIP = 22, L_BAND = 25, N_LISTS = 41 };
+
+// Run one group of DP jobs on the GPU (its scratch fits the budget).  jobs[0..nj) are completed in place (scratch
+// offsets, layout); results and CIGAR ops stay in the worker's pinned buffers: *res_out / *cig_out are valid until the
+// worker's next group.
+static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const uint8_t *d_reads,
+                         const int64_t *d_read_off, const int32_t *d_read_len, int n_threads, const ExtRes **res_out,
+                         const uint32_t **cig_out, int64_t *cig_used, hipStream_t st) {
+    *res_out = nullptr; *cig_out = nullptr; *cig_used = 0;
     if (nj == 0) return 0;
-    // scratch layout + size classes (LDS need)
-    int64_t p_tot = 0, row_tot = 0, cig_tot = 0, state_tot = 0;
-    std::vector<int32_t> order[5];   // first pass through the LDS-state kernel, by LDS size class
-    std::vector<int32_t> wg_order[3][5];  // large windows: workgroup-per-window kernel, by threads (256/512/1024) and LDS class
-    std::vector<int8_t> wg_nt(nj, 0);
-    std::vector<int32_t> reg_order[2];  // first pass through the register-resident kernel (gap fills, tlen <= 256 / 512)
-    std::vector<int32_t> strip_order[3];  // ... through the systolic strip kernel (tlen <= 256 / 512 / 1024) when the band never clips
-    size_t strip_lds_max[3] = {64, 64, 64};
-    std::vector<int8_t> use_wg(nj, 0);
-    std::vector<int8_t> lds_cls(nj, 0);
+    WallTimer wt;
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
-    size_t lds_need_max[5] = {0, 0, 0, 0, 0}, reg_lds_max[2] = {64, 64};
-    int64_t cells = 0;
+    struct Acc {
+        size_t lds_need[5] = {0, 0, 0, 0, 0}, reg_lds[2] = {64, 64}, strip_lds[3] = {64, 64, 64}, band_lds[4] = {64, 64, 64, 64};
+        int64_t cells = 0;
+        int too_large = 0, tl_q = 0, tl_t = 0;
+    };
+    const int nt = std::max(1, n_threads);
+    std::vector<Acc> accs(nt);
+    std::vector<int8_t> list_id(nj), band_v(nj), band_c(nj), redo_list(nj);
+    std::vector<int64_t> p_bytes(nj);
+    std::vector<int32_t> st_bytes(nj);
+    // pass A (parallel): kernel choice, direction-matrix layout and scratch needs of every window
+    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int tid) {
+        Acc &A = accs[tid];
+        for (int64_t j = lo; j < hi; ++j) {
+            ExtJob &jb = jobs[j];
+            const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
+            int n_col = std::min(jb.qlen, jb.tlen);
+            n_col = std::min(n_col, w + 1) + 1;
+            jb.n_col = n_col;
+            const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
+            const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
+                               w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
+            const size_t seqb = (size_t)((jb.qlen + 3) & ~3) + (size_t)((jb.tlen + 3) & ~3);
+            // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
+            int bv = n_col <= 128 ? 0 : n_col <= 256 ? 1 : n_col <= 512 ? 2 : n_col <= 1024 ? 3 : -1;
+            if (seqb > lds_cap[3] || !(g_force_kernel == 0 || g_force_kernel == 4 || g_force_kernel == 5)) bv = -1;
+            int bc = 3;
+            for (int c = 0; c < 4; ++c) if (seqb <= lds_cap[c]) { bc = c; break; }
+            band_v[j] = (int8_t)bv; band_c[j] = (int8_t)bc;
+            if (bv >= 0) A.band_lds[bc] = std::max(A.band_lds[bc], seqb);
+            jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
+            jb.strip_s = jb.tlen <= 256 ? 4 : jb.tlen <= 512 ? 8 : 16;
+            const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
+            jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << std::max(bv, 0);  // row width of the direction matrix (layouts 1, 2)
+            const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
+            // (a strip window keeps room for the layout of a possible exact second pass)
+            p_bytes[j] = (std::max<int64_t>(strip ? strip_bytes : 0, bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~(int64_t)15;
+            A.cells += n_r * n_col;
+            const size_t stateb = (size_t)(((size_t)6 * jb.tlen + 3) & ~(size_t)3) + (size_t)4 * jb.tlen;
+            int cls = 4;
+            for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
+            st_bytes[j] = 0;
+            jb.state_mode = 0;
+            int lid;
+            const bool reg_ok = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
+            const bool use_wg = g_force_kernel == 3 || (g_force_kernel != 1 && n_col - 1 > 128);
+            const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
+            redo_list[j] = (int8_t)(bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls);
+            if (strip) { const int rc = jb.tlen <= 256 ? 0 : jb.tlen <= 512 ? 1 : 2; lid = L_STRIP + rc; A.strip_lds[rc] = std::max(A.strip_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
+            else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
+            else if (reg_ok && g_force_kernel == 2) { const int rc = jb.tlen <= 256 ? 0 : 1; lid = L_REG + rc; A.reg_lds[rc] = std::max(A.reg_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
+            else lid = redo_list[j];
+            if (bv < 0) {  // the LDS-state kernels may run this window (now or in the second pass)
+                if (cls == 4) {
+                    if (seqb > lds_cap[3]) { A.too_large = 1; A.tl_q = jb.qlen; A.tl_t = jb.tlen; }
+                    jb.state_mode = 1; st_bytes[j] = (int32_t)((stateb + 15) & ~(size_t)15);
+                    A.lds_need[4] = std::max(A.lds_need[4], seqb);
+                } else A.lds_need[cls] = std::max(A.lds_need[cls], seqb + stateb);
+            }
+            list_id[j] = (int8_t)lid;
+        }
+    });
+    Acc M;
+    for (const Acc &A : accs) {
+        for (int c = 0; c < 5; ++c) M.lds_need[c] = std::max(M.lds_need[c], A.lds_need[c]);
+        for (int c = 0; c < 2; ++c) M.reg_lds[c] = std::max(M.reg_lds[c], A.reg_lds[c]);
+        for (int c = 0; c < 3; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
+        for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
+        M.cells += A.cells;
+        if (A.too_large) { set_error("DP window too large for LDS staging (%d x %d)", A.tl_q, A.tl_t); return -4; }
+    }
+    // pass B (serial, a few adds per window): scratch offsets and the launch lists (stable in job order)
+    int64_t p_tot = 0, row_tot = 0, cig_tot = 0, state_tot = 0;
+    int cnt[N_LISTS] = {0}, base[N_LISTS + 1];
     for (int j = 0; j < nj; ++j) {
         ExtJob &jb = jobs[j];
-        int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
-        int n_col = std::min(jb.qlen, jb.tlen);
-        n_col = std::min(n_col, w + 1) + 1;
-        jb.n_col = n_col;
-        const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
-        const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
-                           w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
-        jb.layout = strip ? 1 : 0;
-        jb.strip_s = jb.tlen <= 256 ? 4 : jb.tlen <= 512 ? 8 : 16;
-        const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
-        jb.qstride = strip_lanes * jb.strip_s;  // row width of the step-major direction matrix
-        const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * jb.qstride;
-        // (a strip window keeps room for the anti-diagonal layout of a possible exact second pass)
-        jb.p_off = p_tot; p_tot += (std::max<int64_t>(strip ? strip_bytes : 0, n_r * n_col) + 15) & ~(int64_t)15;
-        jb.row_off = row_tot; row_tot += n_r;
+        jb.p_off = p_tot; p_tot += p_bytes[j];
+        jb.row_off = row_tot;
+        if (band_v[j] < 0) row_tot += (int64_t)jb.qlen + jb.tlen - 1;  // band limits are stored only by the LDS-state kernels
         cig_tot += jb.qlen + jb.tlen + 2; jb.cig_off = cig_tot;
-        cells += n_r * n_col;
-        const size_t seqb = (size_t)((jb.qlen + 3) & ~3) + (size_t)((jb.tlen + 3) & ~3);
-        const size_t stateb = (size_t)(((size_t)6 * jb.tlen + 3) & ~(size_t)3) + (size_t)4 * jb.tlen;
-        int cls = 4;
-        for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
-        if (cls == 4) {
-            if (seqb > lds_cap[3]) { set_error("DP window too large for LDS staging (%d x %d)", jb.qlen, jb.tlen); return -4; }
-            jb.state_mode = 1; jb.state_off = state_tot; state_tot += (int64_t)((stateb + 15) & ~(size_t)15);
-            lds_need_max[4] = std::max(lds_need_max[4], seqb);
-        } else { jb.state_mode = 0; lds_need_max[cls] = std::max(lds_need_max[cls], seqb + stateb); }
-        lds_cls[j] = (int8_t)cls;
-        const bool reg_ok = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
-        use_wg[j] = (int8_t)(g_force_kernel == 3 || (g_force_kernel == 0 && n_col - 1 > 128));
-        if (g_force_kernel == 1) use_wg[j] = 0;
-        wg_nt[j] = (int8_t)(n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2);
-        if (jb.layout == 1) {
-            const int rc = jb.tlen <= 256 ? 0 : jb.tlen <= 512 ? 1 : 2;
-            strip_order[rc].push_back(j);
-            strip_lds_max[rc] = std::max(strip_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
-        } else if (reg_ok && (g_force_kernel == 0 || g_force_kernel == 2)) {
-            const int rc = jb.tlen <= 256 ? 0 : 1;
-            reg_order[rc].push_back(j);
-            reg_lds_max[rc] = std::max(reg_lds_max[rc], (size_t)((jb.qlen + 15) & ~15));
-        } else if (use_wg[j]) { wg_nt[j] = (int8_t)(n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2); wg_order[(int)wg_nt[j]][cls].push_back(j); }
-        else order[cls].push_back(j);
+        jb.state_off = state_tot; state_tot += st_bytes[j];
+        ++cnt[(int)list_id[j]];
     }
-    g_stats[4] += nj; g_stats[5] += cells;
-    if (getenv("MPN_DEBUG_JOBS")) {
-        auto summ = [&](const char *nm, const std::vector<int32_t> &v) {
-            int64_t c = 0, mx = 0, ext = 0;
-            for (int j : v) { const int64_t z = ((int64_t)jobs[j].qlen + jobs[j].tlen - 1) * jobs[j].n_col; c += z; mx = std::max(mx, z); ext += (jobs[j].flag & EZ_EXTZ_ONLY) != 0; }
-            if (!v.empty()) fprintf(stderr, "[jobs] %-10s n=%zu cells=%.2fG max=%.1fM ext=%lld\n", nm, v.size(), c / 1e9, mx / 1e6, (long long)ext);
-        };
-        for (int c = 0; c < 5; ++c) { char b[32]; snprintf(b, 32, "lds%d", c); summ(b, order[c]); }
-        for (int t = 0; t < 3; ++t) for (int c = 0; c < 5; ++c) { char b[32]; snprintf(b, 32, "wg%d_%d", 256 << t, c); summ(b, wg_order[t][c]); }
-        summ("reg4", reg_order[0]); summ("reg8", reg_order[1]); summ("strip4", strip_order[0]); summ("strip8", strip_order[1]); summ("strip16", strip_order[2]);
-    }
+    base[0] = 0;
+    for (int l = 0; l < N_LISTS; ++l) base[l + 1] = base[l] + cnt[l];
+    g_stats[4] += nj; g_stats[5] += M.cells;
     Slot &SL = *tl_slot;
-    PoolBuf &pool_jobs = SL.pool_jobs, &pool_P = SL.pool_P, &pool_OFF = SL.pool_OFF, &pool_order = SL.pool_order, &pool_state = SL.pool_state,
-            &pool_CIG = SL.pool_CIG, &pool_res = SL.pool_res, &pool_gap = SL.pool_gap, &pool_redo = SL.pool_redo,
-            &pool_compact = SL.pool_compact, &pool_used = SL.pool_used, &pin_res = SL.pin_res, &pin_cig = SL.pin_cig;
-    std::vector<int32_t> flat;
-    int base[5], reg_base[2], wg_base[3][5], strip_base[3];
-    for (int c = 0; c < 5; ++c) { base[c] = (int)flat.size(); flat.insert(flat.end(), order[c].begin(), order[c].end()); }
-    for (int t = 0; t < 3; ++t)
-        for (int c = 0; c < 5; ++c) { wg_base[t][c] = (int)flat.size(); flat.insert(flat.end(), wg_order[t][c].begin(), wg_order[t][c].end()); }
-    for (int c = 0; c < 2; ++c) { reg_base[c] = (int)flat.size(); flat.insert(flat.end(), reg_order[c].begin(), reg_order[c].end()); }
-    for (int c = 0; c < 3; ++c) { strip_base[c] = (int)flat.size(); flat.insert(flat.end(), strip_order[c].begin(), strip_order[c].end()); }
-    if (pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || pool_P.ensure((size_t)p_tot) || pool_OFF.ensure((size_t)row_tot * 2 * 4) ||
-        pool_state.ensure((size_t)state_tot) || pool_CIG.ensure((size_t)cig_tot * 4) || pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
-        pool_order.ensure(flat.size() * 4) || pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
-        pool_used.ensure(16))
+    if (SL.pin_order.ensure((size_t)nj * 4 + 16) || SL.pin_jobs.ensure((size_t)nj * sizeof(ExtJob))) return -1;
+    int32_t *flat = SL.pin_order.as<int32_t>();
+    {
+        int cur[N_LISTS];
+        memcpy(cur, base, sizeof(cur));
+        for (int j = 0; j < nj; ++j) flat[cur[(int)list_id[j]]++] = j;
+    }
+    if (getenv("MPN_DEBUG_JOBS")) {
+        static const char *const fam[] = {"lds", "wg", "reg", "strip", "band"};
+        for (int l = 0; l < N_LISTS; ++l) {
+            if (!cnt[l]) continue;
+            int64_t c = 0, mx = 0, ext = 0;
+            for (int k = base[l]; k < base[l + 1]; ++k) {
+                const ExtJob &jb = jobs[flat[k]];
+                const int64_t z = ((int64_t)jb.qlen + jb.tlen - 1) * jb.n_col;
+                c += z; mx = std::max(mx, z); ext += (jb.flag & EZ_EXTZ_ONLY) != 0;
+            }
+            const int f = l < L_WG ? 0 : l < L_REG ? 1 : l < L_STRIP ? 2 : l < L_BAND ? 3 : 4;
+            fprintf(stderr, "[jobs] %s list %-2d n=%d cells=%.2fG max=%.1fM ext=%lld\n", fam[f], l, cnt[l], c / 1e9, mx / 1e6, (long long)ext);
+        }
+    }
+    if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || SL.pool_P.ensure((size_t)p_tot) || SL.pool_OFF.ensure((size_t)row_tot * 2 * 4 + 16) ||
+        SL.pool_state.ensure((size_t)state_tot + 16) || SL.pool_CIG.ensure((size_t)cig_tot * 4) || SL.pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
+        SL.pool_order.ensure((size_t)nj * 4) || SL.pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || SL.pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
+        SL.pool_used.ensure(16))
         return -1;
-    struct View { ExtJob *jobs; uint8_t *P; int32_t *OFF; int8_t *state; uint32_t *CIG; ExtRes *res; int32_t *order; };
-    View d{pool_jobs.as<ExtJob>(), pool_P.as<uint8_t>(), pool_OFF.as<int32_t>(), pool_state.as<int8_t>(), pool_CIG.as<uint32_t>(),
-           pool_res.as<ExtRes>(), pool_order.as<int32_t>()};
-    MPN_HIP_CHECK(hipMemsetAsync(pool_used.p, 0, 16, st));
-    uint32_t *d_compact = pool_compact.as<uint32_t>();
-    unsigned long long *d_used = pool_used.as<unsigned long long>();
-    MPN_HIP_CHECK(hipMemcpyAsync(d.jobs, jobs.data(), (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(d.order, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, st));
-    struct { ExtJob *p; } d_jobs{d.jobs};
-    struct { uint8_t *p; } P{d.P};
-    struct { int32_t *p; } OFF{d.OFF};
-    struct { int8_t *p; } gstate{d.state};
-    struct { uint32_t *p; } CIG{d.CIG};
-    struct { ExtRes *p; } d_res{d.res};
-    struct { int32_t *p; } d_order{d.order};
+    // the H2D copies leave from pinned memory, so they are truly asynchronous
+    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int) { memcpy(SL.pin_jobs.as<ExtJob>() + lo, jobs + lo, (size_t)(hi - lo) * sizeof(ExtJob)); });
+    wt.stop_into(g_stats[27]);
+    struct { ExtJob *p; } d_jobs{SL.pool_jobs.as<ExtJob>()};
+    struct { uint8_t *p; } P{SL.pool_P.as<uint8_t>()};
+    struct { int32_t *p; } OFF{SL.pool_OFF.as<int32_t>()};
+    struct { int8_t *p; } gstate{SL.pool_state.as<int8_t>()};
+    struct { uint32_t *p; } CIG{SL.pool_CIG.as<uint32_t>()};
+    struct { ExtRes *p; } d_res{SL.pool_res.as<ExtRes>()};
+    struct { int32_t *p; } d_order{SL.pool_order.as<int32_t>()};
+    uint32_t *d_compact = SL.pool_compact.as<uint32_t>();
+    unsigned long long *d_used = SL.pool_used.as<unsigned long long>();
+    MPN_HIP_CHECK(hipMemsetAsync(d_used, 0, 16, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, SL.pin_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(d_order.p, flat, (size_t)nj * 4, hipMemcpyHostToDevice, st));
     ExtParams prm;
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
-    auto launch_dp = [&](const int32_t *ord, int cnt, size_t lds) -> int {
-        if (cnt == 0) return 0;
-        if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ext_dp_kernel, dim3(cnt), dim3(64), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len,
-                           rv, P.p, OFF.p, gstate.p, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
-        return 0;
-    };
-    auto launch_wg = [&](int ntc, const int32_t *ord, int cnt, size_t lds) -> int {
-        if (cnt == 0) return 0;
+    // one launch of launch list `l` over ord[0..n)
+    auto launch_list = [&](int l, const int32_t *ord, int n, hipStream_t s) -> int {
+        if (n == 0) return 0;
+        if (l < L_WG) {
+            const size_t lds = std::max<size_t>(M.lds_need[l - L_LDS], 64);
+            if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ext_dp_kernel, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p,
+                               gstate.p, d_res.p);
+        } else if (l < L_REG) {
+            const int ntc = (l - L_WG) / 5;
+            const size_t lds = std::max<size_t>(M.lds_need[(l - L_WG) % 5], 64);
 #define MPN_WG_LAUNCH(NT)                                                                                                             \
-        do {                                                                                                                          \
-            if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(ext_dp_wg_kernel<NT>, dim3(cnt), dim3(NT), lds, st, d_jobs.p, ord, cnt, prm, d_reads, d_read_off, d_read_len, \
-                               rv, P.p, OFF.p, gstate.p, d_res.p);                                                    \
-        } while (0)
-        if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
+            do {                                                                                                                      \
+                if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL(ext_dp_wg_kernel<NT>, dim3(n), dim3(NT), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, \
+                                   rv, P.p, OFF.p, gstate.p, d_res.p);                                                                \
+            } while (0)
+            if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
 #undef MPN_WG_LAUNCH
+        } else if (l < L_STRIP) {
+            const size_t lds = M.reg_lds[l - L_REG];
+            if (l == L_REG) hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
+            else hipLaunchKernelGGL(ext_dp_reg_kernel<8>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
+        } else if (l < L_BAND) {
+            const size_t lds = M.strip_lds[l - L_STRIP];
+#define MPN_STRIP_LAUNCH(SS) hipLaunchKernelGGL(ext_dp_strip_kernel<SS>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p)
+            if (l == L_STRIP) MPN_STRIP_LAUNCH(4); else if (l == L_STRIP + 1) MPN_STRIP_LAUNCH(8); else MPN_STRIP_LAUNCH(16);
+#undef MPN_STRIP_LAUNCH
+        } else {
+            const int bvar = (l - L_BAND) / 4;
+            const size_t lds = M.band_lds[(l - L_BAND) % 4];
+#define MPN_BAND_LAUNCH(NW, TT)                                                                                                       \
+            do {                                                                                                                      \
+                if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_band_kernel<NW, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL((ext_dp_band_kernel<NW, TT>), dim3(n), dim3(NW * 64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, \
+                                   d_read_len, rv, P.p, d_res.p);                                                                    \
+            } while (0)
+            if (bvar == 0) MPN_BAND_LAUNCH(1, 2); else if (bvar == 1) MPN_BAND_LAUNCH(1, 4); else if (bvar == 2) MPN_BAND_LAUNCH(2, 4); else MPN_BAND_LAUNCH(4, 4);
+#undef MPN_BAND_LAUNCH
+        }
         MPN_HIP_CHECK(hipGetLastError());
         return 0;
     };
@@ -915,131 +989,128 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, std::vector<
     }
     MPN_HIP_CHECK(hipEventRecord(SL.ev_a, st));
     MPN_HIP_CHECK(hipStreamWaitEvent(SL.st2, SL.ev_a, 0));
-    {
-        hipStream_t st_main = st;
-        st = SL.st2;
-        for (int t = 2; t >= 0; --t)
-            for (int c = 4; c >= 0; --c)
-                if (launch_wg(t, d_order.p + wg_base[t][c], (int)wg_order[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
-        st = st_main;
-    }
+    auto on_side = [](int l) { return (l >= L_WG && l < L_REG) || l >= L_BAND + 8; };  // workgroup windows, 512- and 1024-slot bands
+    for (int l = N_LISTS - 1; l >= 0; --l)
+        if (on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], SL.st2)) return -1;
     MPN_HIP_CHECK(hipEventRecord(SL.ev_b, SL.st2));
-    for (int c = 0; c < 5; ++c)
-        if (launch_dp(d_order.p + base[c], (int)order[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
-#define MPN_STRIP_LAUNCH(C, SS)                                                                                                  \
-    if (!strip_order[C].empty()) {                                                                                                \
-        hipLaunchKernelGGL(ext_dp_strip_kernel<SS>, dim3((unsigned)strip_order[C].size()), dim3(64), strip_lds_max[C], st, d_jobs.p, \
-                           d_order.p + strip_base[C], (int)strip_order[C].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p); \
-        MPN_HIP_CHECK(hipGetLastError());                                                                                       \
-    }
-    MPN_STRIP_LAUNCH(2, 16)
-    MPN_STRIP_LAUNCH(1, 8)
-    MPN_STRIP_LAUNCH(0, 4)
-#undef MPN_STRIP_LAUNCH
-    if (!reg_order[0].empty()) {
-        hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3((unsigned)reg_order[0].size()), dim3(64), reg_lds_max[0], st, d_jobs.p,
-                           d_order.p + reg_base[0], (int)reg_order[0].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
-    }
-    if (!reg_order[1].empty()) {
-        hipLaunchKernelGGL(ext_dp_reg_kernel<8>, dim3((unsigned)reg_order[1].size()), dim3(64), reg_lds_max[1], st, d_jobs.p,
-                           d_order.p + reg_base[1], (int)reg_order[1].size(), prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
-    }
+    for (int l = N_LISTS - 1; l >= 0; --l)  // wide before narrow, strips (the bulk) in the middle
+        if (!on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
-    ev.stop_into(g_stats[15]);
+    ev.mark(15);
     hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());
-    ev.stop_into(g_stats[25]);
-    // z-drop test of the gap-fill CIGARs; flagged jobs are recomputed with the exact maximum
-    std::vector<int32_t> gap;
-    for (int j = 0; j < nj; ++j) if ((jobs[j].flag & EZ_APPROX_MAX)) gap.push_back(j);
-    if (!gap.empty()) {
-        if (pool_gap.ensure(gap.size() * 4)) return -1;
-        struct { int32_t *p; } d_gap{pool_gap.as<int32_t>()};
-        MPN_HIP_CHECK(hipMemcpyAsync(d_gap.p, gap.data(), gap.size() * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(ext_ztest_kernel, dim3(((int)gap.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_gap.p, (int)gap.size(), prm,
-                           d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
-        ev.stop_into(g_stats[26]);
-        MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
-        MPN_HIP_CHECK(hipStreamSynchronize(st));
-        memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
-        std::vector<int32_t> redo[5], redo_wg[3][5];
-        std::vector<int32_t> redo_flat;
-        for (int j : gap) if (res[j].zcode) { jobs[j].flag &= ~EZ_APPROX_MAX; jobs[j].layout = 0; }
-        for (int j : gap) if (res[j].zcode) { if (use_wg[j]) redo_wg[(int)wg_nt[j]][(int)lds_cls[j]].push_back(j); else redo[(int)lds_cls[j]].push_back(j); }
-        int rbase[5], rwbase[3][5];
-        for (int c = 0; c < 5; ++c) { rbase[c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo[c].begin(), redo[c].end()); }
-        for (int t = 0; t < 3; ++t)
-            for (int c = 0; c < 5; ++c) { rwbase[t][c] = (int)redo_flat.size(); redo_flat.insert(redo_flat.end(), redo_wg[t][c].begin(), redo_wg[t][c].end()); }
-        g_stats[8] += (int64_t)redo_flat.size();
-        if (!redo_flat.empty()) {
-            if (pool_redo.ensure(redo_flat.size() * 4)) return -1;
-            struct { int32_t *p; } d_redo{pool_redo.as<int32_t>()};
-            MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
-            MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, redo_flat.data(), redo_flat.size() * 4, hipMemcpyHostToDevice, st));
-            EvTimer ev2(st);
-            for (int c = 0; c < 5; ++c)
-                if (launch_dp(d_redo.p + rbase[c], (int)redo[c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
-            for (int t = 0; t < 3; ++t)
-                for (int c = 0; c < 5; ++c)
-                    if (launch_wg(t, d_redo.p + rwbase[t][c], (int)redo_wg[t][c].size(), std::max<size_t>(lds_need_max[c], 64))) return -1;
-            ev2.stop_into(g_stats[15]);
-            hipLaunchKernelGGL(ext_bt_kernel, dim3(((int)redo_flat.size() + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p,
-                               (int)redo_flat.size(), P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
-            MPN_HIP_CHECK(hipGetLastError());
-            ev2.stop_into(g_stats[25]);
+    ev.mark(25);
+    // z-drop test of the gap-fill CIGARs (the kernel skips the other windows); flagged ones are recomputed with the exact maximum
+    hipLaunchKernelGGL(ext_ztest_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, prm, d_reads, d_read_off, d_read_len,
+                       rv, CIG.p, d_res.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    ev.mark(26);
+    ExtRes *h_res = SL.pin_res.as<ExtRes>();
+    unsigned long long *h_used = (unsigned long long *)((char *)SL.pin_res.p + (size_t)nj * sizeof(ExtRes));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 8, hipMemcpyDeviceToHost, st));
+    wt.stop_into(g_stats[28]);
+    MPN_HIP_CHECK(stream_sync(st));
+    wt.stop_into(g_stats[29]);
+    // second pass
+    std::vector<std::vector<int32_t>> redo_t(nt);
+    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int tid) {
+        for (int64_t j = lo; j < hi; ++j) if ((jobs[j].flag & EZ_APPROX_MAX) && h_res[j].zcode) redo_t[tid].push_back((int32_t)j);
+    });
+    std::vector<int32_t> redo;
+    for (auto &v : redo_t) redo.insert(redo.end(), v.begin(), v.end());
+    g_stats[8] += (int64_t)redo.size();
+    if (!redo.empty()) {
+        const int nr = (int)redo.size();
+        std::stable_sort(redo.begin(), redo.end(), [&](int x, int y) { return redo_list[x] < redo_list[y]; });
+        std::vector<int32_t> pack((size_t)nr * 3);
+        for (int k = 0; k < nr; ++k) {
+            ExtJob &jb = jobs[redo[k]];
+            jb.flag &= ~EZ_APPROX_MAX;
+            jb.layout = band_v[redo[k]] >= 0 ? 2 : 0;
+            jb.qstride = 128 << std::max<int>(band_v[redo[k]], 0);
+            pack[k] = redo[k]; pack[nr + k] = jb.layout; pack[2 * nr + k] = jb.qstride;
         }
+        if (SL.pool_redo.ensure((size_t)nr * 12)) return -1;
+        struct { int32_t *p; } d_redo{SL.pool_redo.as<int32_t>()};
+        MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, pack.data(), (size_t)nr * 12, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ext_redo_patch_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, d_jobs.p, d_redo.p, d_redo.p + nr, d_redo.p + 2 * nr, nr);
+        MPN_HIP_CHECK(hipGetLastError());
+        ev.skip();
+        for (int lo = 0; lo < nr;) {
+            int hi = lo;
+            while (hi < nr && redo_list[redo[hi]] == redo_list[redo[lo]]) ++hi;
+            if (launch_list(redo_list[redo[lo]], d_redo.p + lo, hi - lo, st)) return -1;
+            lo = hi;
+        }
+        ev.mark(15);
+        hipLaunchKernelGGL(ext_bt_kernel, dim3((nr + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p, nr, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(25);
+        MPN_HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 8, hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(stream_sync(st));
     }
-    MPN_HIP_CHECK(hipMemcpyAsync(pin_res.p, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipMemcpyAsync((char *)pin_res.p + (size_t)nj * sizeof(ExtRes), d_used, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
-    memcpy(res.data(), pin_res.p, (size_t)nj * sizeof(ExtRes));
-    unsigned long long used = 0;
-    memcpy(&used, (char *)pin_res.p + (size_t)nj * sizeof(ExtRes), 8);
-    if (pin_cig.ensure((size_t)used * 4 + 16)) return -1;
-    if (used) MPN_HIP_CHECK(hipMemcpyAsync(pin_cig.p, d_compact, (size_t)used * 4, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
-    cig.assign((const uint32_t *)pin_cig.p, (const uint32_t *)pin_cig.p + used);
+    ev.resolve();
+    const unsigned long long used = *h_used;
+    if (SL.pin_cig.ensure((size_t)used * 4 + 16)) return -1;
+    if (used) MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_cig.p, d_compact, (size_t)used * 4, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    *res_out = h_res; *cig_out = SL.pin_cig.as<uint32_t>(); *cig_used = (int64_t)used;
+    wt.stop_into(g_stats[30]);
     return 0;
 }
 
-// run all DP jobs of one round, in groups whose direction scratch stays under the budget
-static int run_jobs(const RefView &rv, const mpn_map_opt *opt, std::vector<ExtJob> &jobs,
-                    const uint8_t *d_reads, const int64_t *d_read_off, const int32_t *d_read_len, std::vector<ExtRes> &res,
-                    std::vector<uint32_t> &cig, hipStream_t st) {
+// Run all DP jobs of one round, in groups whose direction scratch stays under the budget.  The usual single group is
+// handed back in place (pinned buffers of the worker); several groups are gathered into res_store / cig_store.
+static int run_jobs(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const uint8_t *d_reads, const int64_t *d_read_off,
+                    const int32_t *d_read_len, int n_threads, std::vector<ExtRes> &res_store, std::vector<uint32_t> &cig_store,
+                    const ExtRes **res_out, const uint32_t **cig_out, hipStream_t st) {
     const int64_t budget = (int64_t)40 << 30;  // bytes of direction codes per group
-    const int nj = (int)jobs.size();
-    res.assign(nj, ExtRes());
-    cig.clear();
-    int lo = 0;
-    while (lo < nj) {
-        int hi = lo;
+    res_store.clear(); cig_store.clear();
+    *res_out = nullptr; *cig_out = nullptr;
+    std::vector<int> cuts{0};
+    {
         int64_t acc = 0;
-        while (hi < nj) {
-            const ExtJob &jb = jobs[hi];
+        for (int j = 0; j < nj; ++j) {
+            const ExtJob &jb = jobs[j];
             const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
-            const int64_t sz = ((int64_t)jb.qlen + jb.tlen - 1) * (std::min(std::min(jb.qlen, jb.tlen), w + 1) + 1);
-            if (hi > lo && acc + sz > budget) break;
+            const int nc = std::min(std::min(jb.qlen, jb.tlen), w + 1) + 1;
+            const int64_t sz = ((int64_t)jb.qlen + jb.tlen - 1) * (nc <= 1024 ? std::max(128, 2 * nc) : nc);  // upper bound of every layout
+            if (j > cuts.back() && acc + sz > budget) { cuts.push_back(j); acc = 0; }
             acc += sz;
-            ++hi;
         }
-        std::vector<ExtJob> sub(jobs.begin() + lo, jobs.begin() + hi);
-        std::vector<ExtRes> rsub;
-        std::vector<uint32_t> csub;
-        if (run_job_group(rv, opt, sub, d_reads, d_read_off, d_read_len, rsub, csub, st)) return -1;
-        const int64_t base = (int64_t)cig.size();
-        for (int k = 0; k < hi - lo; ++k) { rsub[k].cig_pos += base; jobs[lo + k] = sub[k]; res[lo + k] = rsub[k]; }
-        cig.insert(cig.end(), csub.begin(), csub.end());
-        lo = hi;
+        cuts.push_back(nj);
     }
+    const int n_groups = (int)cuts.size() - 1;
+    for (int g = 0; g < n_groups; ++g) {
+        const int lo = cuts[g], hi = cuts[g + 1];
+        const ExtRes *r = nullptr; const uint32_t *c = nullptr; int64_t used = 0;
+        if (run_job_group(rv, opt, jobs + lo, hi - lo, d_reads, d_read_off, d_read_len, n_threads, &r, &c, &used, st)) return -1;
+        if (n_groups == 1) { *res_out = r; *cig_out = c; return 0; }
+        const int64_t cbase = (int64_t)cig_store.size();
+        res_store.resize((size_t)hi);
+        for (int k = 0; k < hi - lo; ++k) { res_store[lo + k] = r[k]; res_store[lo + k].cig_pos += cbase; }
+        cig_store.insert(cig_store.end(), c, c + used);
+    }
+    *res_out = res_store.data(); *cig_out = cig_store.data();
     return 0;
 }
 
 }  // namespace mpn
 
 using namespace mpn;
+
+static const struct Nt4Tables {  // ASCII -> 0..4 code, and the complement of a code
+    uint8_t fwd[256], comp[8];
+    Nt4Tables() {
+        memset(fwd, 4, sizeof(fwd));
+        const char *b = "ACGT";
+        for (int i = 0; i < 4; ++i) { fwd[(unsigned char)b[i]] = (uint8_t)i; fwd[(unsigned char)(b[i] | 0x20)] = (uint8_t)i; }
+        fwd[(unsigned char)'U'] = fwd[(unsigned char)'u'] = 3;
+        for (int i = 0; i < 8; ++i) comp[i] = (uint8_t)(i < 4 ? 3 - i : 4);
+    }
+} g_nt4;
 
 // One contiguous range [lo, hi) of the batch through the whole path, on the calling worker's stream and arena.
 // Fills rs[lo..hi), rep_len[lo..hi) and lines[lo..hi) (PAF text, only if want_paf).
@@ -1084,12 +1155,9 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             S.n_a = squeeze_a(S.regs, S.a.data());
             const char *s = seqs + seq_off[i];
             S.q4[0].resize(qlen); S.q4[1].resize(qlen);
-            for (int j = 0; j < qlen; ++j) {
-                unsigned char c = (unsigned char)s[j] | 0x20;
-                const uint8_t code = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;
-                S.q4[0][j] = code;
-                S.q4[1][qlen - 1 - j] = code < 4 ? 3 - code : 4;
-            }
+            uint8_t *f = S.q4[0].data(), *rc = S.q4[1].data();
+            for (int j = 0; j < qlen; ++j) f[j] = g_nt4.fwd[(unsigned char)s[j]];
+            for (int j = 0; j < qlen; ++j) rc[j] = g_nt4.comp[f[qlen - 1 - j]];
         }
     });
     wt.stop_into(g_stats[19]);
@@ -1132,9 +1200,13 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             wt.stop_into(g_stats[20]);
             if (!any) break;
             ++g_stats[7];
-            std::vector<ExtRes> res;
-            std::vector<uint32_t> cig;
-            if (run_jobs(RefView{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns}, opt, sink.jobs, d_seqs.p, d_off.p, d_len.p, res, cig, st)) return -1;
+            std::vector<ExtRes> res_store;
+            std::vector<uint32_t> cig_store;
+            const ExtRes *res = nullptr;
+            const uint32_t *cig = nullptr;
+            if (run_jobs(RefView{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns}, opt, sink.jobs.data(),
+                         (int)sink.jobs.size(), d_seqs.p, d_off.p, d_len.p, n_threads, res_store, cig_store, &res, &cig, st))
+                return -1;
             wt.stop_into(g_stats[21]);
             parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
@@ -1144,7 +1216,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
                 for (size_t pi = 0; pi < S.pending.size(); ++pi) {
                     const int k = S.pending[pi] + shift;
                     Reg r2;
-                    const bool has = stitch_align(opt, idx, seq_len[i], q2, S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs, cig.data());
+                    const bool has = stitch_align(opt, idx, seq_len[i], q2, S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs.data(), cig);
                     if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
                 }
             });
@@ -1207,10 +1279,17 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     if (n_threads < 1) n_threads = 1;
     // sub-batches of ~48 Mbp run through a small pool of workers, each with its own HIP stream and device arena, so
     // that the host phases of one sub-batch overlap the GPU phases of another
+    int n_workers = 4;
+    if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(8, atoi(e)));
     std::vector<int> cut{0};
     {
         int64_t target = 48000000;
         if (const char *e = getenv("MPN_SUB_BATCH_BP")) target = std::max<int64_t>(1000, atoll(e));
+        // equal-sized sub-batches, their count a multiple of the worker count so that no worker idles in the last round
+        int64_t n_cut = std::max<int64_t>(1, (bases + target - 1) / target);
+        n_workers = (int)std::min<int64_t>(n_workers, n_cut);
+        n_cut = (n_cut + n_workers - 1) / n_workers * n_workers;
+        target = std::max<int64_t>(1, (bases + n_cut - 1) / n_cut);
         int64_t acc = 0;
         for (int i = 0; i < n; ++i) {
             acc += seq_len[i];
@@ -1219,9 +1298,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         cut.push_back(n);
     }
     const int n_sub = (int)cut.size() - 1;
-    int n_workers = 4;
-    if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(4, atoi(e)));
-    n_workers = std::min(n_workers, n_sub);
+    n_workers = std::max(1, std::min(n_workers, n_sub));
     int dev = 0;
     MPN_HIP_CHECK(hipGetDevice(&dev));
     std::vector<ReadState> rs(n);
@@ -1327,13 +1404,16 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
         j.read = i; j.rid = i; j.rev = 0; j.qs = 0; j.qlen = q_len[i]; j.ts = 0; j.tlen = t_len[i]; j.reversed = 0;
         j.w = w[i]; j.zdrop = zdrop[i]; j.end_bonus = end_bonus[i]; j.flag = flag[i];
     }
-    std::vector<ExtRes> res;
-    std::vector<uint32_t> cig;
+    std::vector<ExtRes> res_store;
+    std::vector<uint32_t> cig_store;
+    const ExtRes *res = nullptr;
+    const uint32_t *cig = nullptr;
     g_force_kernel = force_kernel;
     // no second pass here: the caller asks for exactly one DP per pair
     mpn_map_opt o2 = *opt;
     o2.zdrop = 0x3fffffff;
-    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, jobs, d_reads.p, d_qoff.p, d_qlen.p, res, cig, st);
+    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, jobs.data(), n, d_reads.p, d_qoff.p, d_qlen.p, 4, res_store, cig_store,
+                            &res, &cig, st);
     g_force_kernel = 0;
     if (rc) return rc;
     int64_t used = 0;
@@ -1344,7 +1424,7 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
         o[8] = e.n_cigar;
         cig_off[i] = used;
         if (used + e.n_cigar > cigar_cap) return -3;
-        if (e.n_cigar) memcpy(cigar_pool + used, cig.data() + e.cig_pos, (size_t)e.n_cigar * 4);
+        if (e.n_cigar) memcpy(cigar_pool + used, cig + e.cig_pos, (size_t)e.n_cigar * 4);
         used += e.n_cigar;
     }
     return 0;

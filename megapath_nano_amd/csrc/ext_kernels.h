@@ -29,8 +29,9 @@ struct ExtJob {
     int32_t n_col;
     int32_t state_mode;  // 0: state arrays in LDS, 1: in global scratch
     int64_t state_off;
-    int32_t layout;      // direction matrix: 0 = [anti-diagonal][t - band start]; 1 = strip kernel: cell (t, j) at [j + t/S][t]
-    int32_t qstride;     // layout 1: row width W = n_lanes * S bytes
+    int32_t layout;      // direction matrix: 0 = [anti-diagonal][t - band start]; 1 = strip kernel: cell (t, j) at [j + t/S][t];
+                         // 2 = band kernel: [anti-diagonal][t mod SL]
+    int32_t qstride;     // layout 1: row width W = n_lanes * S bytes; layout 2: SL
     int32_t strip_s;     // layout 1: S
 };
 
@@ -530,6 +531,196 @@ __global__ __launch_bounds__(NT) void ext_dp_wg_kernel(const ExtJob *__restrict_
     if (tid == 0) res[jid] = out;
 }
 
+// Band-in-registers variant: the general kernel for windows whose band is at most NW*64*T cells wide (any tlen, both
+// the approximate-max gap fills and the exact-max / z-drop end extensions).  Target position t lives in slot
+// t mod SL (SL = NW*64*T, a power of two); thread `tid` owns the T consecutive slots tid*T..tid*T+T-1 for the whole job,
+// so the six difference states and the H row never leave VGPRs while the band slides along the target.  The left
+// neighbour t-1 is the thread's own previous slot, the previous lane's last slot (one DPP wave_shr per state) or, for
+// lane 0, the last slot of the previous wave, handed over through LDS.  One barrier per anti-diagonal: boundary
+// states, per-wave maxima and the few single-owner values (H[en], H[st], the approximate-max cell) are published
+// into parity-indexed LDS slots at the end of anti-diagonal r and consumed at the start of r+1, which also moves the
+// z-drop decision for r there (nothing of r+1 is computed before it).  Direction codes are stored by slot
+// ([r][t mod SL], one aligned 32-bit store per four cells); the traceback recomputes the band limits from r, so no
+// band-start/end arrays are written.
+template <int NW, int T>
+__global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                              ExtParams prm, const uint8_t *__restrict__ reads,
+                                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                              RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
+    static_assert(T % 4 == 0 || T == 2, "T must be 2 or a multiple of 4");
+    constexpr int NT = NW * 64, SL = NT * T;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int bnd[2][NW][4];   // last slot of each wave after the anti-diagonal: v, x, x2, H
+    __shared__ int red[2][NW][2];   // per-wave best H and its tie-break key
+    __shared__ int pub[2][4];       // H[en], H[st], v[last_H0_t], u[last_H0_t + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    const int qlen = jb.qlen, tlen = jb.tlen;
+    int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    ExtRes out;
+    out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
+    out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
+    if (qlen <= 0 || tlen <= 0 || -prm.sc_mis > 2 * (q + e)) { if (tid == 0) res[jid] = out; return; }
+    int w = jb.w;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    uint8_t *qs_ = smem;
+    uint8_t *ts_ = smem + ((qlen + 3) & ~3);
+    const bool approx = (jb.flag & EZ_APPROX_MAX) != 0;
+    {
+        const int64_t roff = read_off[jb.read];
+        const int32_t rlen = read_len[jb.read];
+        for (int i = tid; i < qlen; i += NT) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
+        const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
+        for (int i = tid; i < tlen; i += NT) ts_[i] = (uint8_t)ref_code(rv, g0 + (jb.reversed ? tlen - 1 - i : i));
+    }
+    int U[T], V[T], X[T], Y[T], X2[T], Y2[T], H[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) { U[k] = V[k] = X[k] = Y[k] = -qe; X2[k] = Y2[k] = -qe2; H[k] = NEG_INF; }
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+    uint8_t *p = P + jb.p_off + tid * T;
+    const int n_r = qlen + tlen - 1;
+    ExtApply ez; ez.max = 0; ez.max_t = ez.max_q = -1; ez.zdropped = 0;
+    int32_t mqe = NEG_INF, mqe_t = -1, score = NEG_INF, H0 = 0, last_H0_t = 0;
+    int last_st = -1, last_en = -1, r, r_done = n_r - 1;
+    const bool right = (jb.flag & EZ_RIGHT) != 0;
+    const int slot0 = tid * T;
+    for (r = 0;; ++r) {
+        const int par = r & 1;
+        __syncthreads();  // publications of anti-diagonal r-1 (and, for r = 0, the staged sequences) are visible
+        if (r > 0) {      // close anti-diagonal r-1
+            const int pr_ = r - 1, pp = par ^ 1;
+            if (!approx) {
+                const int32_t hen = pub[pp][0];
+                int32_t max_H = hen, max_t = last_en;
+                if (pr_ > 0) {
+                    int32_t mm = NEG_INF; int mk = 0x7fffffff;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        const int32_t hh = red[pp][i][0]; const int k2 = red[pp][i][1];
+                        if (hh > mm || (hh == mm && k2 < mk)) { mm = hh; mk = k2; }
+                    }
+                    if (mm > hen) { max_H = mm; max_t = mk & 0xffffff; }
+                }
+                if (pr_ - last_st == qlen - 1) { const int32_t hs = pub[pp][1]; if (hs > mqe) { mqe = hs; mqe_t = last_st; } }
+                if (ext_apply_zdrop(ez, max_H, pr_, max_t, jb.zdrop, e2)) { r_done = pr_; break; }
+                if (pr_ == n_r - 1 && last_en == tlen - 1) score = hen;
+            } else {
+                if (pr_ > 0) {
+                    const bool in0 = last_H0_t >= last_st && last_H0_t <= last_en, in1 = last_H0_t + 1 >= last_st && last_H0_t + 1 <= last_en;
+                    const int32_t d0 = pub[pp][2], d1 = pub[pp][3];
+                    if (in0 && in1) { if (d0 > d1) H0 += d0; else { H0 += d1; ++last_H0_t; } }
+                    else if (in0) H0 += d0;
+                    else { ++last_H0_t; H0 += d1; }
+                } else { H0 = pub[pp][2] - qe; last_H0_t = 0; }
+                if (pr_ == n_r - 1 && last_en == tlen - 1) score = H0;
+            }
+        }
+        if (r == n_r) break;
+        int st = 0, en = tlen - 1;
+        if (st < r - qlen + 1) st = r - qlen + 1;
+        if (en > r) en = r;
+        if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+        if (en > (r + w) >> 1) en = (r + w) >> 1;
+        if (st > en) { ez.zdropped = 1; r_done = r; break; }
+        const bool left_known = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
+        const int bnd_u = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
+        const int bv1 = st == 0 ? bnd_u : -qe;
+        const bool en_new = en > last_en;
+        // old state of the slot to the left of this thread's first slot
+        const int pw = (wv + NW - 1) % NW;
+        int cv = 0, cx = 0, cx2 = 0, ch = 0;
+        if (r > 0 && lane == 0) { cv = bnd[par ^ 1][pw][0]; cx = bnd[par ^ 1][pw][1]; cx2 = bnd[par ^ 1][pw][2]; ch = bnd[par ^ 1][pw][3]; }
+        const int lv = wave_shr1(V[T - 1], cv), lx = wave_shr1(X[T - 1], cx), lx2 = wave_shr1(X2[T - 1], cx2), lh = wave_shr1(H[T - 1], ch);
+        const int en1 = st + (en - st) / 4 * 4;
+        int32_t bestH = NEG_INF, bestKey = 0x7fffffff;
+        uint32_t dw[(T + 3) / 4];
+#pragma unroll
+        for (int k = 0; k < (T + 3) / 4; ++k) dw[k] = 0;
+        bool any = false;
+#pragma unroll
+        for (int k = T - 1; k >= 0; --k) {
+            const int t = st + ((slot0 + k - st) & (SL - 1));
+            const bool act = t <= en;
+            any |= act;
+            const bool fresh = t == en && en_new;
+            int ut = fresh ? -qe : U[k], yt = fresh ? -qe : Y[k], y2t = fresh ? -qe2 : Y2[k];
+            if (en >= r && t == r) { yt = -qe; y2t = -qe2; ut = bnd_u; }
+            int v1 = k > 0 ? V[k > 0 ? k - 1 : 0] : lv, x1 = k > 0 ? X[k > 0 ? k - 1 : 0] : lx, x21 = k > 0 ? X2[k > 0 ? k - 1 : 0] : lx2;
+            const int hl = k > 0 ? H[k > 0 ? k - 1 : 0] : lh;
+            if (t == st && !left_known) { v1 = bv1; x1 = -qe; x21 = -qe2; }
+            const int sq = act ? (int)ts_[t] : 4, sr = act ? (int)qs_[r - t] : 4;
+            const int sc = (sq == 4 || sr == 4) ? prm.sc_n : sq == sr ? prm.sc_mch : prm.sc_mis;
+            int z = sc, a = x1 + v1, b = yt + ut, a2 = x21 + v1, b2 = y2t + ut, d;
+            if (!right) {
+                d = a > z ? 1 : 0; z = max(z, a);
+                d = b > z ? 2 : d; z = max(z, b);
+                d = a2 > z ? 3 : d; z = max(z, a2);
+                d = b2 > z ? 4 : d; z = max(z, b2);
+            } else {
+                d = z > a ? 0 : 1; z = max(z, a);
+                d = z > b ? d : 2; z = max(z, b);
+                d = z > a2 ? d : 3; z = max(z, a2);
+                d = z > b2 ? d : 4; z = max(z, b2);
+            }
+            z = min(z, (int)prm.sc_mch);
+            const int nu = z - v1, nv = z - ut;
+            int tmp = z - q; a -= tmp; b -= tmp;
+            tmp = z - q2; a2 -= tmp; b2 -= tmp;
+            if (!right) { d |= a > 0 ? 0x08 : 0; d |= b > 0 ? 0x10 : 0; d |= a2 > 0 ? 0x20 : 0; d |= b2 > 0 ? 0x40 : 0; }
+            else { d |= a >= 0 ? 0x08 : 0; d |= b >= 0 ? 0x10 : 0; d |= a2 >= 0 ? 0x20 : 0; d |= b2 >= 0 ? 0x40 : 0; }
+            if (act) {
+                U[k] = nu; V[k] = nv;
+                X[k] = max(a, 0) - qe; Y[k] = max(b, 0) - qe;
+                X2[k] = max(a2, 0) - qe2; Y2[k] = max(b2, 0) - qe2;
+                dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
+                if (!approx) {
+                    int32_t h;
+                    if (r == 0) h = nv - qe;
+                    else if (t < en) {
+                        h = H[k] + nv;
+                        const int key = (t < en1 ? 1 + ((t - st) & 3) : 5) << 24 | t;
+                        if (h > bestH || (h == bestH && key < bestKey)) { bestH = h; bestKey = key; }
+                    } else h = en > 0 ? hl + nu : H[k] + nv;
+                    H[k] = h;
+                    if (t == en) pub[par][0] = h;
+                    if (t == st && r - st == qlen - 1) pub[par][1] = h;
+                } else {
+                    if (t == last_H0_t) pub[par][2] = nv;
+                    if (t == last_H0_t + 1) pub[par][3] = nu;
+                }
+            }
+        }
+        if (any) {
+            uint8_t *dst = p + (int64_t)r * SL;
+            if constexpr (T == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)dw[0];
+            else {
+#pragma unroll
+                for (int k = 0; k < T / 4; ++k) reinterpret_cast<uint32_t *>(dst)[k] = dw[k];
+            }
+        }
+        if (lane == 63) { bnd[par][wv][0] = V[T - 1]; bnd[par][wv][1] = X[T - 1]; bnd[par][wv][2] = X2[T - 1]; bnd[par][wv][3] = H[T - 1]; }
+        if (!approx && r > 0) {
+            const int32_t m = wave_reduce_max(bestH);
+            int kk = (bestH == m && m > NEG_INF) ? bestKey : 0x7fffffff;
+            kk = wave_reduce_min(kk);
+            if (lane == 0) { red[par][wv][0] = m; red[par][wv][1] = kk; }
+        }
+        last_st = st; last_en = en;
+    }
+    out.max = ez.max; out.max_t = ez.max_t; out.max_q = ez.max_q; out.zdropped = ez.zdropped;
+    out.mqe = mqe; out.mqe_t = mqe_t; out.score = score;
+    out.r_done = r_done;
+    if (!ez.zdropped && !(jb.flag & EZ_EXTZ_ONLY)) { out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1; }
+    else if (!ez.zdropped && (jb.flag & EZ_EXTZ_ONLY) && mqe + jb.end_bonus > ez.max) { out.reach_end = 1; out.do_bt = 1; out.bt_i = mqe_t; out.bt_j = qlen - 1; }
+    else if (ez.max_t >= 0 && ez.max_q >= 0) { out.do_bt = 1; out.bt_i = ez.max_t; out.bt_j = ez.max_q; }
+    if (tid == 0) res[jid] = out;
+}
+
 // Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 64*S): lane l owns
 // the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l, so after a 63-step
 // ramp every lane computes S cells per step -- no partially filled anti-diagonal tiles.  The left neighbour (t, j-1)
@@ -661,6 +852,8 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     const uint8_t *p = P + jb.p_off;
     const int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
     const bool rowmajor = jb.layout == 1;  // strip kernel: cell (t, j) at [j + t/S][t], band never clips
+    const bool byslot = jb.layout == 2;    // band kernel: cell (t, r) at [r][t mod SL], band limits recomputed here
+    const int bw = jb.w < 0 ? (jb.tlen > jb.qlen ? jb.tlen : jb.qlen) : jb.w;
     const bool rev_cigar = (jb.flag & EZ_REV_CIGAR) != 0;
     // ops are generated last-to-first.  REV_CIGAR keeps that order (write forward from the region start),
     // otherwise they are written back to front so that they read forward.
@@ -675,7 +868,16 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
         const int rr = i + j;
         int force_state = -1, tmp;
         if (rowmajor) tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i];
-        else {
+        else if (byslot) {
+            int st = 0, en = jb.tlen - 1;
+            if (st < rr - jb.qlen + 1) st = rr - jb.qlen + 1;
+            if (en > rr) en = rr;
+            if (st < (rr - bw + 1) >> 1) st = (rr - bw + 1) >> 1;
+            if (en > (rr + bw) >> 1) en = (rr + bw) >> 1;
+            if (i < st) force_state = 2;
+            if (i > en) force_state = 1;
+            tmp = force_state < 0 ? p[(int64_t)rr * jb.qstride + (i & (jb.qstride - 1))] : 0;
+        } else {
             if (i < off[rr]) force_state = 2;
             if (i > off_end[rr]) force_state = 1;
             tmp = force_state < 0 ? p[(int64_t)rr * n_col + i - off[rr]] : 0;
@@ -711,6 +913,7 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     if (k >= n_jobs) return;
     const int jid = order[k];
     const ExtJob jb = jobs[jid];
+    if (!(jb.flag & EZ_APPROX_MAX)) return;  // only gap fills are tested
     const ExtRes r = res[jid];
     const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
     const int64_t roff = read_off[jb.read];

@@ -10,6 +10,19 @@
 
 namespace mpn {
 
+hipError_t stream_sync(hipStream_t st) {
+    struct Ev {  // one blocking-sync event per host thread
+        hipEvent_t e = nullptr;
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+    };
+    static thread_local Ev ev;
+    hipError_t rc;
+    if (!ev.e && (rc = hipEventCreateWithFlags(&ev.e, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return rc;
+    if ((rc = hipEventRecord(ev.e, st)) != hipSuccess) return rc;
+    return hipEventSynchronize(ev.e);
+}
+
+
 thread_local int64_t g_stats[32] = {0};
 
 void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne) {
@@ -57,7 +70,7 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     MPN_HIP_CHECK(hipGetLastError());
     int64_t total = 0;
     MPN_HIP_CHECK(hipMemcpyAsync(&total, mz_off.p + n, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     if (mz.alloc((size_t)total)) return -1;
     if (n_chunks > 0 && total > 0) {
         hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(grid), dim3(64), lds, st, d_seqs, d_off, d_len, n,
@@ -92,7 +105,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<u128> mz;
     EvTimer ev(st);
     if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st)) return -1;
-    ev.stop_into(g_stats[10]);
+    ev.mark(10);
     g_stats[1] += n_mz;
     const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
     DevBuf<int32_t> occ;
@@ -112,7 +125,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_a = 0;
     MPN_HIP_CHECK(hipMemcpyAsync(&n_a, o.anchor_off.p + n, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     o.n_anchors = n_a;
     g_stats[2] += n_a;
     DevBuf<u128> tmp;
@@ -122,16 +135,16 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
         o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(2) || o.used.zero(st))
         return -1;
-    ev.stop_into(g_stats[11]);
+    ev.mark(11);
     if (n_a > 0) {
         hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
                            pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, o.anchors.p);
         MPN_HIP_CHECK(hipGetLastError());
-        ev.stop_into(g_stats[11]);
+        ev.mark(11);
         hipLaunchKernelGGL(seg_sort_kernel<4>, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n);
         MPN_HIP_CHECK(hipGetLastError());
     }
-    ev.stop_into(g_stats[12]);
+    ev.mark(12);
     ChainParams cp;
     cp.max_dist_x = opt->max_gap; cp.max_dist_y = opt->max_gap; cp.bw = opt->bw; cp.max_skip = opt->max_chain_skip;
     cp.max_iter = opt->max_chain_iter; cp.min_cnt = opt->min_cnt; cp.min_sc = opt->min_chain_score;
@@ -145,7 +158,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(chain_dp_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, (const int32_t *)d_ord.p, n, cp, F.p, P.p,
                        T.p, V.p);
     MPN_HIP_CHECK(hipGetLastError());
-    ev.stop_into(g_stats[13]);
+    ev.mark(13);
     hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);
     MPN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(chain_sort_ends_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(256), 0, st, o.u.p, Utmp.p,
@@ -157,8 +170,9 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p,
                        o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p);
     MPN_HIP_CHECK(hipGetLastError());
-    ev.stop_into(g_stats[14]);
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    ev.mark(14);
+    MPN_HIP_CHECK(stream_sync(st));
+    ev.resolve();
     return 0;
 }
 
@@ -172,7 +186,7 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st) {
     if (o.anchor_off.download(h.anchor_off.data(), (size_t)n + 1, st) || o.n_chain.download(h.n_chain.data(), n, st) ||
         o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st))
         return -1;
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     // gather only the used prefixes: u[0..n_chain) and chained[0..n_chained) of every read
     h.chain_off.assign((size_t)n + 1, 0);
     h.b_off.assign((size_t)n + 1, 0);
@@ -182,11 +196,11 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st) {
     std::vector<int64_t> u_pos(n), b_pos(n);
     unsigned long long used[2] = {0, 0};
     if (o.u_pos.download(u_pos.data(), n, st) || o.b_pos.download(b_pos.data(), n, st) || o.used.download(used, 2, st)) return -1;
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     std::vector<uint64_t> u_all((size_t)used[0]);
     std::vector<u128> b_all((size_t)used[1]);
     if (o.u_compact.download(u_all.data(), (size_t)used[0], st) || o.chained.download(b_all.data(), (size_t)used[1], st)) return -1;
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     for (int i = 0; i < n; ++i) {
         const int nc = h.n_chain[i];
         if (nc == 0) continue;
@@ -296,7 +310,7 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
         hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, block_cnt.p, block_off.p, (int)n_blocks);
         int64_t n_keys = 0;
         if (hipMemcpyAsync(&n_keys, block_off.p + n_blocks, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: key count failed: %s", hipGetErrorString(hipGetLastError())); return fail(); }
+            stream_sync(st) != hipSuccess) { set_error("mpn_index_build: key count failed: %s", hipGetErrorString(hipGetLastError())); return fail(); }
         idx->n_keys = n_keys;
         if (idx->keys.alloc((size_t)n_keys) || idx->key_off.alloc((size_t)n_keys + 1) || idx->pos.alloc((size_t)n_mz)) return fail();
         if (n_blocks > 0) hipLaunchKernelGGL(idx_emit_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_off.p, idx->keys.p,
@@ -304,7 +318,7 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
         if (hipMemcpyAsync(idx->key_off.p + n_keys, &n_mz, 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail();
         idx->h_key_off.resize((size_t)n_keys + 1);
         if (idx->key_off.download(idx->h_key_off.data(), (size_t)n_keys + 1, st)) return fail();
-        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("mpn_index_build: GPU sort failed"); return fail(); }
+        if (stream_sync(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("mpn_index_build: GPU sort failed"); return fail(); }
         if (idx->d_seq_off.upload(off.data(), off.size(), st)) return fail();
     }
     {
@@ -316,7 +330,7 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
             idx->d_nrun_e.upload(ne.data(), ne.size(), st))
             return fail();
     }
-    if (hipStreamSynchronize(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
+    if (stream_sync(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
     return idx;
 }
 
@@ -344,7 +358,7 @@ int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uin
     if (idx->keys.download(keys, (size_t)idx->n_keys, st) || idx->key_off.download(key_off, (size_t)idx->n_keys + 1, st) ||
         idx->pos.download(pos, (size_t)idx->n_mz, st))
         return -1;
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     return 0;
 }
 
@@ -360,7 +374,7 @@ int64_t mpn_sketch_batch(int32_t n, const char *seqs, const int64_t *seq_off, co
     if (sketch_device(d_seqs.p, d_off.p, d_len.p, seq_len, n, k, w, 0, d_mz_off, d_mz, &n_mz, st)) return -1;
     if (d_mz_off.download(mz_off, (size_t)n + 1, st)) return -1;
     if (n_mz <= cap && d_mz.download((u128 *)mz, (size_t)n_mz, st)) return -1;
-    MPN_HIP_CHECK(hipStreamSynchronize(st));
+    MPN_HIP_CHECK(stream_sync(st));
     return n_mz <= cap ? n_mz : -3;
 }
 

@@ -57,20 +57,38 @@ extern thread_local int64_t g_stats[32];
 // 2-bit packing of 0..4 codes (N -> 0 + run list)
 void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne);
 
-// HIP-event timer for a group of launches on one stream; accumulate() syncs on the stop event
+// Waits for a stream without spinning: the worker threads of the pipelined mapper share the host cores with the
+// host phases of the other workers, so a waiting thread must sleep (blocking-sync event), not poll.
+hipError_t stream_sync(hipStream_t st);
+
+// HIP-event timer for groups of launches on one stream.  mark() only RECORDS an event and remembers which counter the
+// span since the previous mark belongs to; the elapsed times are read back in resolve(), which the caller invokes
+// after a synchronisation it needs anyway -- timing never adds a host/device round trip of its own.
 struct EvTimer {
-    hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
-    explicit EvTimer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-    void stop_into(int64_t &acc) {
-        (void)hipEventRecord(b, st);
-        (void)hipEventSynchronize(b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, a, b);
-        acc += (int64_t)(ms * 1e6);
-        (void)hipEventRecord(a, st);
+    std::vector<hipEvent_t> ev;
+    std::vector<int> slot;  // slot[i]: g_stats index charged with ev[i] -> ev[i+1]; -1 = gap (not charged)
+    explicit EvTimer(hipStream_t s) : st(s) { push(-1); }
+    void push(int sl) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, st);
+        ev.push_back(e);
+        slot.push_back(sl);
     }
-    ~EvTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void mark(int stat_index) { slot.back() = stat_index; push(-1); }  // the span that ends here goes to stat_index
+    void skip() { push(-1); }                                          // the span that ends here is not charged
+    void resolve() {  // call after the stream has been synchronised
+        for (size_t i = 0; i + 1 < ev.size(); ++i) {
+            if (slot[i] < 0) continue;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) g_stats[slot[i]] += (int64_t)(ms * 1e6);
+        }
+        for (size_t i = 0; i + 1 < ev.size(); ++i) (void)hipEventDestroy(ev[i]);
+        hipEvent_t last = ev.back();
+        ev.assign(1, last); slot.assign(1, -1);
+    }
+    ~EvTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 
 // Grow-only device / pinned-host scratch that survives across calls (hipMalloc of multi-GB scratch per batch costs

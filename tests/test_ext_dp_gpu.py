@@ -1,4 +1,4 @@
-"""GPU parity tests (-m gpu) of the three extension-DP kernels (single-wave LDS, register-resident, workgroup) against
+"""GPU parity tests (-m gpu) of the extension-DP kernels (single-wave LDS, register-resident, workgroup, strip, band) against
 the oracle's mmo_extd2 on seeded pairs: global / approximate-max / extension-only / right-aligned modes, band clipping,
 z-drop, ambiguous bases, small to large windows.  Bit-exact on scores, end points and CIGAR."""
 import numpy as np
@@ -71,37 +71,53 @@ def opt(libmpn, oracle_built):
 
 def test_gap_fill_windows_all_kernels(opt):
     qs, ts = make_pairs(1, [30, 64, 65, 128, 200, 230, 256, 257, 300, 400, 511])
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 0])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 5, 0])
     qs, ts = make_pairs(2, [220, 260, 310], ambig=True)
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 5])
     qs, ts = make_pairs(3, [450, 500], big_indel=True)
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 5])
     qs, ts = make_pairs(11, [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 512, 513, 600, 700])
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 4])
-    check(opt, qs, ts, 751, 400, -1, APPROX | RIGHT, [1, 4])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 4, 5])
+    check(opt, qs, ts, 751, 400, -1, APPROX | RIGHT, [1, 4, 5])
 
 
 def test_exact_global_mode(opt):
     qs, ts = make_pairs(4, [50, 180, 260, 420, 700])
-    check(opt, qs, ts, 751, 400, -1, 0, [1, 3])
+    check(opt, qs, ts, 751, 400, -1, 0, [1, 3, 5])
     qs, ts = make_pairs(5, [300, 600], big_indel=True)  # z-drop inside a global fill
-    check(opt, qs, ts, 751, 50, -1, 0, [1, 3])
+    check(opt, qs, ts, 751, 50, -1, 0, [1, 3, 5])
 
 
 def test_extension_modes_with_zdrop(opt):
     qs, ts = make_pairs(6, [40, 150, 400, 900], tail=True)
-    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 0])
-    check(opt, qs, ts, 751, 400, -1, EXTZ | RIGHT | REV, [1, 3, 0])
-    check(opt, qs, ts, 751, 400, 50, EXTZ, [1, 3])  # end bonus: reach_end path
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 5, 0])
+    check(opt, qs, ts, 751, 400, -1, EXTZ | RIGHT | REV, [1, 3, 5, 0])
+    check(opt, qs, ts, 751, 400, 50, EXTZ, [1, 3, 5])  # end bonus: reach_end path
     qs, ts = make_pairs(7, [300, 500])
-    check(opt, qs, ts, 751, 400, 10, EXTZ, [1, 3])
+    check(opt, qs, ts, 751, 400, 10, EXTZ, [1, 3, 5])
 
 
 def test_band_clipping_and_large_windows(opt):
     qs, ts = make_pairs(8, [600, 1500])
-    check(opt, qs, ts, 100, 400, -1, 0, [1, 3])       # narrow band: cells outside the previous band
-    check(opt, qs, ts, 20, 400, -1, APPROX, [1, 2, 3])
+    check(opt, qs, ts, 100, 400, -1, 0, [1, 3, 5])       # narrow band: cells outside the previous band
+    check(opt, qs, ts, 20, 400, -1, APPROX, [1, 2, 3, 5])
     qs, ts = make_pairs(9, [3000, 5200], tail=True)
-    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 0])
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 5, 0])
     qs, ts = make_pairs(10, [14000])                  # state arrays in the global scratch
-    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3])
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 5])
+
+
+def test_band_kernel_slot_variants(opt):
+    """Every slot count of the band kernel (128/256/512/1024), with the band sliding far enough to wrap the slots several
+    times, in approximate, exact and extension modes; the single-wave LDS kernel (1) must agree with the oracle too."""
+    qs, ts = make_pairs(12, [900, 2500, 4100])
+    for w in (10, 63, 126, 127, 128, 254, 255, 256, 400, 510, 511, 600, 1022, 1023):
+        check(opt, qs, ts, w, 400, -1, APPROX, [5])
+        check(opt, qs, ts, w, 400, -1, 0, [5])
+    qs, ts = make_pairs(13, [700, 2000, 3500], tail=True)
+    for w in (100, 200, 500, 751, 1000):
+        check(opt, qs, ts, w, 400, -1, EXTZ, [5])
+        check(opt, qs, ts, w, 200, 30, EXTZ | RIGHT | REV, [5])
+    qs, ts = make_pairs(14, [1800, 2600], ambig=True, big_indel=True)
+    check(opt, qs, ts, 300, 100, -1, 0, [1, 5])
+    check(opt, qs, ts, 300, 100, -1, APPROX | RIGHT, [1, 5])
