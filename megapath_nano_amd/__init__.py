@@ -6,3 +6,8 @@ loader, no CPU fallback), and host-side mirrors of the reference's stage interfa
   aligner.py      <- /root/reference/bin/lib/aligner.py             (Align)
   reassignment.py <- /root/reference/bin/lib/reassignment.py        (Reassign)
 """
+import os as _os
+
+# 8 pipeline workers x 2 HIP streams need more than ROCm's default 4 hardware queues (streams sharing a queue serialise);
+# the HIP runtime reads this when it initialises, so import this package before the first GPU call (see csrc/mpn_runtime.hip)
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')

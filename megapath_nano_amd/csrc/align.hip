@@ -29,7 +29,7 @@ int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32
                 DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st);
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
                       const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st);
-int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st);
+int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st);
 
 const char *get_error();
 
@@ -770,8 +770,9 @@ struct Slot {
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
+    PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
 };
-static Slot g_slots[8];
+static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
 
 static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel, 4 strip, 5 band
@@ -812,6 +813,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         int too_large = 0, tl_q = 0, tl_t = 0;
     };
     const int nt = std::max(1, n_threads);
+    const bool strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi);
     std::vector<Acc> accs(nt);
     std::vector<int8_t> list_id(nj), band_v(nj), band_c(nj), redo_list(nj);
     std::vector<int64_t> p_bytes(nj);
@@ -826,8 +828,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             n_col = std::min(n_col, w + 1) + 1;
             jb.n_col = n_col;
             const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
-            const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
-                               w >= std::max(jb.qlen, jb.tlen) && (g_force_kernel == 0 || g_force_kernel == 4);
+            const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
+                               w >= std::max(jb.qlen, jb.tlen) && strip_scores && (g_force_kernel == 0 || g_force_kernel == 4);
             const size_t seqb = (size_t)((jb.qlen + 3) & ~3) + (size_t)((jb.tlen + 3) & ~3);
             // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
             int bv = n_col <= 128 ? 0 : n_col <= 256 ? 1 : n_col <= 512 ? 2 : n_col <= 1024 ? 3 : -1;
@@ -1132,10 +1134,10 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         SeedChainOut o;
         if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
         wt.stop_into(g_stats[17]);
-        if (download_chains(n, o, h, st)) return -1;
+        if (download_chains(n, o, h, tl_slot->pin_chain_u, tl_slot->pin_chain_b, st)) return -1;
         wt.stop_into(g_stats[18]);
     }
-    g_stats[3] += (int64_t)h.u.size();
+    g_stats[3] += h.chain_off[n];
     for (int i = 0; i < n; ++i) rep_len_all[lo + i] = h.rep_len[i];
     // hits from chains
     parallel_for(n, n_threads, [&](int i, int) {
@@ -1143,11 +1145,13 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         const int nc = h.n_chain[i];
         if (nc == 0) return;
         const int qlen = seq_len[i];
-        S.a.assign(h.b.begin() + h.b_off[i], h.b.begin() + h.b_off[i + 1]);
+        std::vector<uint64_t> u_loc(nc);
+        S.a.resize((size_t)h.n_chained[i]);
+        h.read_chains(i, u_loc.data(), S.a.data());
         uint32_t hash = names && names[lo + i] ? x31_hash(names[lo + i]) : 0;
         hash ^= wang32((uint32_t)qlen) + wang32(opt->seed);
         hash = wang32(hash);
-        gen_regs(hash, qlen, nc, &h.u[h.chain_off[i]], S.a.data(), S.regs);
+        gen_regs(hash, qlen, nc, u_loc.data(), S.a.data(), S.regs);
         set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
         select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
         join_long(opt, qlen, S.regs, S.a.data());
@@ -1275,25 +1279,29 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     }
     MPN_HIP_CHECK(hipStreamSynchronize(st0));
     wt.stop_into(g_stats[16]);
-    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, (int)std::thread::hardware_concurrency());
+    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
+    if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
     if (n_threads < 1) n_threads = 1;
-    // sub-batches of ~48 Mbp run through a small pool of workers, each with its own HIP stream and device arena, so
-    // that the host phases of one sub-batch overlap the GPU phases of another
-    int n_workers = 4;
-    if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(8, atoi(e)));
+    // sub-batches of ~48 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
+    // device arena, so that the host phases of one sub-batch overlap the GPU phases of the others and the
+    // latency-bound kernels (chain DP, long extensions) of one overlap the throughput-bound ones of another
+    int n_workers = 8;
+    if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(16, atoi(e)));
     std::vector<int> cut{0};
     {
         int64_t target = 48000000;
         if (const char *e = getenv("MPN_SUB_BATCH_BP")) target = std::max<int64_t>(1000, atoll(e));
         // equal-sized sub-batches, their count a multiple of the worker count so that no worker idles in the last round
+        const int W = n_workers;
+        std::vector<int64_t> sizes;
         int64_t n_cut = std::max<int64_t>(1, (bases + target - 1) / target);
-        n_workers = (int)std::min<int64_t>(n_workers, n_cut);
-        n_cut = (n_cut + n_workers - 1) / n_workers * n_workers;
-        target = std::max<int64_t>(1, (bases + n_cut - 1) / n_cut);
+        if (n_cut > W) n_cut = (n_cut + W - 1) / W * W;
+        for (int64_t i = 0; i < n_cut; ++i) sizes.push_back(std::max<int64_t>(1, (bases + n_cut - 1) / n_cut));
+        size_t si = 0;
         int64_t acc = 0;
         for (int i = 0; i < n; ++i) {
             acc += seq_len[i];
-            if (acc >= target && i + 1 < n) { cut.push_back(i + 1); acc = 0; }
+            if (si + 1 < sizes.size() && acc >= sizes[si] && i + 1 < n) { cut.push_back(i + 1); acc = 0; ++si; }
         }
         cut.push_back(n);
     }

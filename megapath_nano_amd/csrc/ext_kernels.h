@@ -641,19 +641,28 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
         uint32_t dw[(T + 3) / 4];
 #pragma unroll
         for (int k = 0; k < (T + 3) / 4; ++k) dw[k] = 0;
-        bool any = false;
+        // single-owner values of this anti-diagonal, published once after the cell loop (selects, no branches, inside it)
+        int32_t pv_en = 0, pv_st = 0, pv_h0v = 0, pv_h0u = 0;
+        bool has_en = false, has_st = false, has_h0v = false, has_h0u = false, any = false;
+        const bool first = r == 0, en_pos = en > 0;
 #pragma unroll
         for (int k = T - 1; k >= 0; --k) {
+            // Cells outside the band compute on clamped operands and their results are never read: a slot that has not
+            // entered the band yet is overridden when it does (`fresh`), one that left it is read at most once more, as
+            // the left neighbour of the band start, and that read sees the values from before this anti-diagonal.
             const int t = st + ((slot0 + k - st) & (SL - 1));
             const bool act = t <= en;
             any |= act;
-            const bool fresh = t == en && en_new;
-            int ut = fresh ? -qe : U[k], yt = fresh ? -qe : Y[k], y2t = fresh ? -qe2 : Y2[k];
-            if (en >= r && t == r) { yt = -qe; y2t = -qe2; ut = bnd_u; }
-            int v1 = k > 0 ? V[k > 0 ? k - 1 : 0] : lv, x1 = k > 0 ? X[k > 0 ? k - 1 : 0] : lx, x21 = k > 0 ? X2[k > 0 ? k - 1 : 0] : lx2;
+            const bool is_en = t == en, is_st = t == st;
+            const bool fresh = is_en && en_new;
+            const bool col0 = is_en && en >= r;  // t == r: first query column
+            const int ut = col0 ? bnd_u : fresh ? -qe : U[k], yt = fresh ? -qe : Y[k], y2t = fresh ? -qe2 : Y2[k];
+            const bool edge = is_st && !left_known;
+            const int v1 = edge ? bv1 : k > 0 ? V[k > 0 ? k - 1 : 0] : lv;
+            const int x1 = edge ? -qe : k > 0 ? X[k > 0 ? k - 1 : 0] : lx;
+            const int x21 = edge ? -qe2 : k > 0 ? X2[k > 0 ? k - 1 : 0] : lx2;
             const int hl = k > 0 ? H[k > 0 ? k - 1 : 0] : lh;
-            if (t == st && !left_known) { v1 = bv1; x1 = -qe; x21 = -qe2; }
-            const int sq = act ? (int)ts_[t] : 4, sr = act ? (int)qs_[r - t] : 4;
+            const int sq = ts_[min(t, tlen - 1)], sr = qs_[min(max(r - t, 0), qlen - 1)];
             const int sc = (sq == 4 || sr == 4) ? prm.sc_n : sq == sr ? prm.sc_mch : prm.sc_mis;
             int z = sc, a = x1 + v1, b = yt + ut, a2 = x21 + v1, b2 = y2t + ut, d;
             if (!right) {
@@ -673,27 +682,22 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
             tmp = z - q2; a2 -= tmp; b2 -= tmp;
             if (!right) { d |= a > 0 ? 0x08 : 0; d |= b > 0 ? 0x10 : 0; d |= a2 > 0 ? 0x20 : 0; d |= b2 > 0 ? 0x40 : 0; }
             else { d |= a >= 0 ? 0x08 : 0; d |= b >= 0 ? 0x10 : 0; d |= a2 >= 0 ? 0x20 : 0; d |= b2 >= 0 ? 0x40 : 0; }
-            if (act) {
-                U[k] = nu; V[k] = nv;
-                X[k] = max(a, 0) - qe; Y[k] = max(b, 0) - qe;
-                X2[k] = max(a2, 0) - qe2; Y2[k] = max(b2, 0) - qe2;
-                dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
-                if (!approx) {
-                    int32_t h;
-                    if (r == 0) h = nv - qe;
-                    else if (t < en) {
-                        h = H[k] + nv;
-                        const int key = (t < en1 ? 1 + ((t - st) & 3) : 5) << 24 | t;
-                        if (h > bestH || (h == bestH && key < bestKey)) { bestH = h; bestKey = key; }
-                    } else h = en > 0 ? hl + nu : H[k] + nv;
-                    H[k] = h;
-                    if (t == en) pub[par][0] = h;
-                    if (t == st && r - st == qlen - 1) pub[par][1] = h;
-                } else {
-                    if (t == last_H0_t) pub[par][2] = nv;
-                    if (t == last_H0_t + 1) pub[par][3] = nu;
-                }
-            }
+            U[k] = nu; V[k] = nv;
+            X[k] = max(a, 0) - qe; Y[k] = max(b, 0) - qe;
+            X2[k] = max(a2, 0) - qe2; Y2[k] = max(b2, 0) - qe2;
+            dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
+            // exact mode: the H row
+            const int32_t h = first ? nv - qe : (is_en && en_pos) ? hl + nu : H[k] + nv;
+            H[k] = act ? h : H[k];  // (H alone can be read stale: H[en-1] of a one-cell band)
+            const int key = (t < en1 ? 1 + ((t - st) & 3) : 5) << 24 | t;
+            const bool better = t < en && (h > bestH || (h == bestH && key < bestKey));
+            bestH = better ? h : bestH; bestKey = better ? key : bestKey;
+            pv_en = is_en ? h : pv_en; has_en |= is_en;
+            pv_st = is_st ? h : pv_st; has_st |= is_st;
+            // approximate mode: the tracked cell
+            const bool is0 = act && t == last_H0_t, is1 = act && t == last_H0_t + 1;
+            pv_h0v = is0 ? nv : pv_h0v; has_h0v |= is0;
+            pv_h0u = is1 ? nu : pv_h0u; has_h0u |= is1;
         }
         if (any) {
             uint8_t *dst = p + (int64_t)r * SL;
@@ -703,6 +707,10 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
                 for (int k = 0; k < T / 4; ++k) reinterpret_cast<uint32_t *>(dst)[k] = dw[k];
             }
         }
+        if (has_en) pub[par][0] = pv_en;
+        if (has_st) pub[par][1] = pv_st;
+        if (has_h0v) pub[par][2] = pv_h0v;
+        if (has_h0u) pub[par][3] = pv_h0u;
         if (lane == 63) { bnd[par][wv][0] = V[T - 1]; bnd[par][wv][1] = X[T - 1]; bnd[par][wv][2] = X2[T - 1]; bnd[par][wv][3] = H[T - 1]; }
         if (!approx && r > 0) {
             const int32_t m = wave_reduce_max(bestH);
@@ -721,15 +729,26 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
     if (tid == 0) res[jid] = out;
 }
 
-// Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 64*S): lane l owns
-// the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l, so after a 63-step
-// ramp every lane computes S cells per step -- no partially filled anti-diagonal tiles.  The left neighbour (t, j-1)
-// of a cell is the lane's own previous step (u, y, y2 kept per row in VGPRs), the upper neighbour (t-1, j) is the
-// previous row of the same step or, for the first row of a strip, the bottom row lane l-1 finished one step earlier
-// (one DPP wave_shr per state).  Query bases ride the same shift.  Same recurrences, boundary rules and direction
-// codes as ext_dp_kernel.  Directions are stored step-major: cell (t, j) lives at [j + t/S][t], so the S bytes a lane
-// produces in one step are contiguous and the whole wave writes one contiguous row of n_lanes*S bytes per step
-// (measured before this layout: row-major dword stores cost 7x their bytes in HBM writes, partially filled lines).
+// Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 64*S, gaps
+// left-aligned): lane l owns the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l,
+// so after a ramp of n_lanes-1 steps every lane computes S cells per step -- no partially filled anti-diagonal tiles.
+// The left neighbour (t, j-1) of a cell is the lane's own previous step (u, y, y2 kept per row in VGPRs), the upper
+// neighbour (t-1, j) is the previous row of the same step or, for the first row of a strip, the bottom row lane l-1
+// finished one step earlier (one DPP wave_shr per state); query bases ride the same shift.
+// This kernel runs at the VALU issue limit, so the cell is written for instruction count:
+//  * one exec mask per step (j in range) instead of a predicate per cell;
+//  * the substitution score is a bit-field extract: each row keeps its five scores (vs A,C,G,T,N) as 6-bit fields of one
+//    register and the query base travels as the field offset;
+//  * the gap states are stored without their -(q+e) offset, which folds into the three-operand adds of the next cell;
+//  * the direction is "first operand that equals the maximum", the continuation flags come from the new gap states;
+//  * the corner score is summed along row 0 and then down the last column, which costs one add per step.
+// Same recurrences, boundary rules and direction codes as ext_dp_kernel.  Directions are stored step-major: cell
+// (t, j) lives at [j + t/S][t], so the S bytes a lane produces in one step are contiguous and the whole wave writes one
+// contiguous row of n_lanes*S bytes per step (row-major dword stores cost 7x their bytes in HBM writes, measured).
+__host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {  // 6-bit signed fields
+    return mch >= -32 && mch <= 31 && mis >= -32 && mis <= 31 && amb >= -32 && amb <= 31;
+}
+
 template <int S>
 __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                           ExtParams prm, const uint8_t *__restrict__ reads,
@@ -747,81 +766,78 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
     out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
     out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
     if (qlen <= 0 || tlen <= 0 || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
-    uint8_t *qs_ = smem;
+    uint8_t *qs_ = smem;  // 6 * base code: the bit offset of the score field
     {
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];
-        for (int i = lane; i < qlen; i += 64) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
+        for (int i = lane; i < qlen; i += 64) qs_[i] = (uint8_t)(6 * ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i)));
     }
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 #define MPN_BND(R) ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2)
-    int UL[S], YL[S], Y2L[S], TS[S];
+    // UL: u of the previous column; YL, Y2L: y + (q+e), y2 + (q2+e2) of the previous column (both start at 0)
+    int UL[S], YL[S], Y2L[S];
+    uint32_t TB[S];
     const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
     const int t0 = lane * S;
+    const uint32_t f_mch = (uint32_t)prm.sc_mch & 63, f_mis = (uint32_t)prm.sc_mis & 63, f_n = (uint32_t)prm.sc_n & 63;
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const int t = t0 + k;
-        TS[k] = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
+        const int sq = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
+        uint32_t tab = f_n << 24;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tab |= (sq == 4 ? f_n : sq == c ? f_mch : f_mis) << (6 * c);
+        TB[k] = tab;
         UL[k] = MPN_BND(t);   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
-        YL[k] = -qe; Y2L[k] = -qe2;
+        YL[k] = 0; Y2L[k] = 0;
     }
     __syncthreads();
-    const bool right = (jb.flag & EZ_RIGHT) != 0;
     const int n_lanes = (tlen + S - 1) / S;
     const int n_steps = qlen + n_lanes - 1;
     const int W = jb.qstride;
     uint8_t *prow = P + jb.p_off + t0;
-    int out_v = 0, out_x = 0, out_x2 = 0, qb = 4;
-    int32_t col0 = 0, lastrow = 0;  // sum of first-column / last-row differences for the corner score
-    const int last_lane = (tlen - 1) / S, last_k = (tlen - 1) - last_lane * S;
+    int out_v = 0, out_x = 0, out_x2 = 0, qsh = 24;
+    int32_t row0 = 0;  // lane 0: sum of the horizontal differences of row 0
+    const int mqe_ = -qe, mqe2_ = -qe2, mch = prm.sc_mch;
     for (int step = 0; step < n_steps; ++step) {
-        // bases and bottom-row states move one lane to the right
-        const int q_in = step < qlen ? (int)qs_[step] : 4;
-        qb = wave_shr1(qb, q_in);
+        // query bases and bottom-row states move one lane to the right
+        const int q_in = step < qlen ? (int)qs_[step] : 24;
+        qsh = wave_shr1(qsh, q_in);
         int v_up = wave_shr1(out_v, 0), x_up = wave_shr1(out_x, 0), x2_up = wave_shr1(out_x2, 0);
         const int j = step - lane;
-        const bool col_ok = j >= 0 && j < qlen && lane < n_lanes;
-        if (lane == 0) { v_up = MPN_BND(j); x_up = -qe; x2_up = -qe2; }
-        uint32_t dw[S / 4];
+        const int bj = MPN_BND(step);  // lane 0: j = step
+        v_up = lane == 0 ? bj : v_up; x_up = lane == 0 ? 0 : x_up; x2_up = lane == 0 ? 0 : x2_up;
+        if (j >= 0 && j < qlen && lane < n_lanes) {
+            uint32_t dw[S / 4];
 #pragma unroll
-        for (int k = 0; k < S / 4; ++k) dw[k] = 0;
+            for (int k = 0; k < S / 4; ++k) dw[k] = 0;
+            int nv0 = 0;
 #pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const int t = t0 + k;
-            const bool act = col_ok && t < tlen;
-            const int sq = TS[k];
-            const int sc = (sq == 4 || qb == 4) ? prm.sc_n : sq == qb ? prm.sc_mch : prm.sc_mis;
-            const int ut = UL[k];
-            int z = sc, a = x_up + v_up, b = YL[k] + ut, a2 = x2_up + v_up, b2 = Y2L[k] + ut, d;
-            if (!right) {
-                d = a > z ? 1 : 0; z = max(z, a);
-                d = b > z ? 2 : d; z = max(z, b);
-                d = a2 > z ? 3 : d; z = max(z, a2);
-                d = b2 > z ? 4 : d; z = max(z, b2);
-            } else {
-                d = z > a ? 0 : 1; z = max(z, a);
-                d = z > b ? d : 2; z = max(z, b);
-                d = z > a2 ? d : 3; z = max(z, a2);
-                d = z > b2 ? d : 4; z = max(z, b2);
+            for (int k = 0; k < S; ++k) {
+                const int sc = __builtin_amdgcn_sbfe((int)TB[k], qsh, 6);
+                const int ut = UL[k];
+                int a = x_up + v_up + mqe_, b = YL[k] + ut + mqe_, a2 = x2_up + v_up + mqe2_, b2 = Y2L[k] + ut + mqe2_;
+                int z = max(max(sc, a), b);
+                z = max(max(z, a2), b2);
+                int d = 4;                 // first operand (sc, a, b, a2, b2) that equals the maximum
+                d = a2 == z ? 3 : d;
+                d = b == z ? 2 : d;
+                d = a == z ? 1 : d;
+                d = sc == z ? 0 : d;
+                z = min(z, mch);
+                const int nu = z - v_up, nv = z - ut;
+                const int zq = z - q, zq2 = z - q2;
+                a = max(a - zq, 0); b = max(b - zq, 0); a2 = max(a2 - zq2, 0); b2 = max(b2 - zq2, 0);
+                d |= min(a, 1) << 3; d |= min(b, 1) << 4; d |= min(a2, 1) << 5; d |= min(b2, 1) << 6;
+                UL[k] = nu; YL[k] = b; Y2L[k] = b2;
+                v_up = nv; x_up = a; x2_up = a2;
+                dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
+                if (k == 0) nv0 = nv;
             }
-            z = min(z, (int)prm.sc_mch);
-            const int nu = z - v_up, nv = z - ut;
-            int tmp = z - q; a -= tmp; b -= tmp;
-            tmp = z - q2; a2 -= tmp; b2 -= tmp;
-            if (!right) { d |= a > 0 ? 0x08 : 0; d |= b > 0 ? 0x10 : 0; d |= a2 > 0 ? 0x20 : 0; d |= b2 > 0 ? 0x40 : 0; }
-            else { d |= a >= 0 ? 0x08 : 0; d |= b >= 0 ? 0x10 : 0; d |= a2 >= 0 ? 0x20 : 0; d |= b2 >= 0 ? 0x40 : 0; }
-            dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
-            if (act) {
-                UL[k] = nu; YL[k] = max(b, 0) - qe; Y2L[k] = max(b2, 0) - qe2;
-                v_up = nv; x_up = max(a, 0) - qe; x2_up = max(a2, 0) - qe2;
-                if (j == 0) col0 += t == 0 ? z : nu;
-                if (lane == last_lane && k == last_k && j > 0) lastrow += nv;
-            }
-        }
-        out_v = v_up; out_x = x_up; out_x2 = x2_up;
-        if (lane < n_lanes) {  // one contiguous row of n_lanes*S direction bytes per step
+            out_v = v_up; out_x = x_up; out_x2 = x2_up;
+            row0 += nv0;
             uint8_t *dst = prow + (int64_t)step * W;  // S-byte aligned: p_off is 16-aligned, W and t0 are multiples of S
             if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
             else if constexpr (S == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(dw[0], dw[1]);
@@ -829,7 +845,10 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
         }
     }
 #undef MPN_BND
-    int32_t tot = col0 + lastrow;
+    // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1); a lane's UL froze at its last column
+    int32_t tot = lane == 0 ? row0 - qe : 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? UL[k] : 0;
     for (int dlt = 32; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
     out.score = tot;
     out.r_done = qlen + tlen - 2;

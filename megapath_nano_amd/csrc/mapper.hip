@@ -176,53 +176,44 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     return 0;
 }
 
-// download the chains of a batch and put each read's chains in ascending order of their first anchor
-// (minimap2 re-sorts them like this so that neighbouring chains can be joined)
-int download_chains(int n, SeedChainOut &o, HostChains &h, hipStream_t st) {
+// download the compact chain pools of a batch (pinned staging owned by the caller) and the per-read tables
+int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st) {
     h.anchor_off.resize((size_t)n + 1);
-    h.n_chain.resize(n);
-    h.n_chained.resize(n);
-    h.rep_len.resize(n);
+    h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
+    unsigned long long used[2] = {0, 0};
     if (o.anchor_off.download(h.anchor_off.data(), (size_t)n + 1, st) || o.n_chain.download(h.n_chain.data(), n, st) ||
-        o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st))
+        o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st) ||
+        o.u_pos.download(h.u_pos.data(), n, st) || o.b_pos.download(h.b_pos.data(), n, st) || o.used.download(used, 2, st))
         return -1;
     MPN_HIP_CHECK(stream_sync(st));
-    // gather only the used prefixes: u[0..n_chain) and chained[0..n_chained) of every read
+    if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;
+    if (o.u_compact.download(pin_u.as<uint64_t>(), (size_t)used[0], st) || o.chained.download(pin_b.as<u128>(), (size_t)used[1], st)) return -1;
+    h.u_all = pin_u.as<uint64_t>(); h.b_all = pin_b.as<u128>();
     h.chain_off.assign((size_t)n + 1, 0);
     h.b_off.assign((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) { h.chain_off[i + 1] = h.chain_off[i] + h.n_chain[i]; h.b_off[i + 1] = h.b_off[i] + h.n_chained[i]; }
-    h.u.resize((size_t)h.chain_off[n]);
-    h.b.resize((size_t)h.b_off[n]);
-    std::vector<int64_t> u_pos(n), b_pos(n);
-    unsigned long long used[2] = {0, 0};
-    if (o.u_pos.download(u_pos.data(), n, st) || o.b_pos.download(b_pos.data(), n, st) || o.used.download(used, 2, st)) return -1;
     MPN_HIP_CHECK(stream_sync(st));
-    std::vector<uint64_t> u_all((size_t)used[0]);
-    std::vector<u128> b_all((size_t)used[1]);
-    if (o.u_compact.download(u_all.data(), (size_t)used[0], st) || o.chained.download(b_all.data(), (size_t)used[1], st)) return -1;
-    MPN_HIP_CHECK(stream_sync(st));
-    for (int i = 0; i < n; ++i) {
-        const int nc = h.n_chain[i];
-        if (nc == 0) continue;
-        const uint64_t *u = &u_all[(size_t)u_pos[i]];
-        const u128 *b = &b_all[(size_t)b_pos[i]];
-        std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w(nc);
-        int64_t k = 0;
-        for (int c = 0; c < nc; ++c) { w[c] = {{b[k].x, (uint64_t)k << 32 | (uint32_t)c}, c}; k += (int32_t)u[c]; }
-        std::sort(w.begin(), w.end());
-        uint64_t *uo = &h.u[(size_t)h.chain_off[i]];
-        u128 *bo = &h.b[(size_t)h.b_off[i]];
-        int64_t kk = 0;
-        for (int c = 0; c < nc; ++c) {
-            const int j = w[c].second;
-            const int64_t start = (int64_t)(w[c].first.second >> 32);
-            const int32_t cnt = (int32_t)u[j];
-            uo[c] = u[j];
-            memcpy(bo + kk, b + start, (size_t)cnt * sizeof(u128));
-            kk += cnt;
-        }
-    }
     return 0;
+}
+
+void HostChains::read_chains(int i, uint64_t *uo, u128 *bo) const {
+    const int nc = n_chain[i];
+    if (nc == 0) return;
+    const uint64_t *u = u_all + u_pos[i];
+    const u128 *b = b_all + b_pos[i];
+    std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w(nc);
+    int64_t k = 0;
+    for (int c = 0; c < nc; ++c) { w[c] = {{b[k].x, (uint64_t)k << 32 | (uint32_t)c}, c}; k += (int32_t)u[c]; }
+    std::sort(w.begin(), w.end());
+    int64_t kk = 0;
+    for (int c = 0; c < nc; ++c) {
+        const int j = w[c].second;
+        const int64_t start = (int64_t)(w[c].first.second >> 32);
+        const int32_t cnt = (int32_t)u[j];
+        uo[c] = u[j];
+        memcpy(bo + kk, b + start, (size_t)cnt * sizeof(u128));
+        kk += cnt;
+    }
 }
 
 }  // namespace mpn
@@ -392,13 +383,14 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     SeedChainOut o;
     if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
     HostChains h;
-    if (download_chains(n, o, h, st)) return -1;
+    PoolBuf pin_u{nullptr, 0, true}, pin_b{nullptr, 0, true};
+    struct Free { PoolBuf &a, &b; ~Free() { a.release(); b.release(); } } free_pins{pin_u, pin_b};
+    if (download_chains(n, o, h, pin_u, pin_b, st)) return -1;
     for (int i = 0; i < n; ++i) { n_anchor[i] = h.anchor_off[i + 1] - h.anchor_off[i]; rep_len[i] = h.rep_len[i]; }
     memcpy(chain_off, h.chain_off.data(), ((size_t)n + 1) * 8);
     memcpy(anchor_off, h.b_off.data(), ((size_t)n + 1) * 8);
-    if ((int64_t)h.u.size() > u_cap || (int64_t)h.b.size() > b_cap) return -3;
-    if (!h.u.empty()) memcpy(u, h.u.data(), h.u.size() * 8);
-    if (!h.b.empty()) memcpy(b, h.b.data(), h.b.size() * 16);
+    if (h.chain_off[n] > u_cap || h.b_off[n] > b_cap) return -3;
+    for (int i = 0; i < n; ++i) h.read_chains(i, u + h.chain_off[i], (u128 *)b + h.b_off[i]);
     return 0;
 }
 

@@ -46,10 +46,14 @@ struct SeedChainOut {
 };
 
 struct HostChains {
-    std::vector<int64_t> anchor_off, chain_off, b_off, n_chained;
+    std::vector<int64_t> anchor_off, chain_off, b_off;  // per read: anchors found; prefix sums of chains and of chained anchors
+    std::vector<int64_t> n_chained, u_pos, b_pos;       // per read: chained anchors; start in the compact pools
     std::vector<int32_t> n_chain, rep_len;
-    std::vector<uint64_t> u;
-    std::vector<u128> b;
+    const uint64_t *u_all = nullptr;                    // compact pools as downloaded (caller-owned pinned memory)
+    const u128 *b_all = nullptr;
+    // chains of read i in ascending order of their first anchor (minimap2 re-sorts them like this so that neighbouring
+    // chains can be joined): u_out[n_chain[i]], b_out[n_chained[i]]
+    void read_chains(int i, uint64_t *u_out, u128 *b_out) const;
 };
 
 extern thread_local int64_t g_stats[32];
@@ -106,6 +110,7 @@ struct PoolBuf {
         cap = want;
         return 0;
     }
+    void release() { if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
     template <typename T> T *as() const { return (T *)p; }
 };
 
