@@ -121,9 +121,10 @@ int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
  *  [23] host: rank/MAPQ/PAF  [24] whole call
  * device ns measured with HIP events on the stream the kernels run on:
  *  [10] sketch  [11] seed lookup+fill  [12] anchor sort  [13] chain DP  [14] chain ends+backtrack
- *  [15] extension DP kernel  [25] traceback kernel  [26] z-drop test kernel
+ *  [15] extension DP kernels other than the strip kernel  [25] traceback kernel  [26] z-drop test kernel
  *  inside [21], wall ns: [27] host: kernel choice + scratch layout + staging  [28] enqueue  [29] wait for the GPU
- *  [30] second pass + CIGAR download */
+ *  [30] second pass + CIGAR download
+ *  [9] device ns of the strip-kernel launches ([15] covers the other DP kernels)  [31] cells (qlen x tlen) those launches computed */
 void mpn_map_last_stats(int64_t stats[32]);
 
 #ifdef __cplusplus

@@ -768,7 +768,7 @@ struct Slot {
     hipStream_t st2 = nullptr;       // side stream: the few long windows run beside the many short ones
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     Arena arena;
-    PoolBuf pool_jobs, pool_P, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
+    PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
 };
@@ -785,13 +785,15 @@ static void parallel_chunks(int64_t n, int n_threads, const std::function<void(i
 }
 
 // the second pass of a gap fill whose CIGAR failed the z-drop test: exact maximum, band (or anti-diagonal) layout
-__global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const int32_t *layout, const int32_t *qstride, int n) {
+__global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const int32_t *layout, const int32_t *qstride,
+                                      const int64_t *p_off, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     ExtJob &jb = jobs[ids[k]];
     jb.flag &= ~EZ_APPROX_MAX;
     jb.layout = layout[k];
     jb.qstride = qstride[k];
+    jb.p_off = p_off[k];
 }
 
 // launch lists: every DP job of a group belongs to exactly one
@@ -809,7 +811,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     struct Acc {
         size_t lds_need[5] = {0, 0, 0, 0, 0}, reg_lds[2] = {64, 64}, strip_lds[3] = {64, 64, 64}, band_lds[4] = {64, 64, 64, 64};
-        int64_t cells = 0;
+        int64_t cells = 0, strip_cells = 0;
         int too_large = 0, tl_q = 0, tl_t = 0;
     };
     const int nt = std::max(1, n_threads);
@@ -843,9 +845,10 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
             jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << std::max(bv, 0);  // row width of the direction matrix (layouts 1, 2)
             const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
-            // (a strip window keeps room for the layout of a possible exact second pass)
-            p_bytes[j] = (std::max<int64_t>(strip ? strip_bytes : 0, bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~(int64_t)15;
+            // (the rare exact second pass of a strip window gets its direction matrix from a pool of its own)
+            p_bytes[j] = ((strip ? strip_bytes : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~(int64_t)15;
             A.cells += n_r * n_col;
+            if (strip) A.strip_cells += (int64_t)jb.qlen * jb.tlen;
             const size_t stateb = (size_t)(((size_t)6 * jb.tlen + 3) & ~(size_t)3) + (size_t)4 * jb.tlen;
             int cls = 4;
             for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
@@ -876,7 +879,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         for (int c = 0; c < 2; ++c) M.reg_lds[c] = std::max(M.reg_lds[c], A.reg_lds[c]);
         for (int c = 0; c < 3; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
         for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
-        M.cells += A.cells;
+        M.cells += A.cells; M.strip_cells += A.strip_cells;
         if (A.too_large) { set_error("DP window too large for LDS staging (%d x %d)", A.tl_q, A.tl_t); return -4; }
     }
     // pass B (serial, a few adds per window): scratch offsets and the launch lists (stable in job order)
@@ -893,7 +896,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     }
     base[0] = 0;
     for (int l = 0; l < N_LISTS; ++l) base[l + 1] = base[l] + cnt[l];
-    g_stats[4] += nj; g_stats[5] += M.cells;
+    g_stats[4] += nj; g_stats[5] += M.cells; g_stats[31] += M.strip_cells;
     Slot &SL = *tl_slot;
     if (SL.pin_order.ensure((size_t)nj * 4 + 16) || SL.pin_jobs.ensure((size_t)nj * sizeof(ExtJob))) return -1;
     int32_t *flat = SL.pin_order.as<int32_t>();
@@ -995,8 +998,12 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     for (int l = N_LISTS - 1; l >= 0; --l)
         if (on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], SL.st2)) return -1;
     MPN_HIP_CHECK(hipEventRecord(SL.ev_b, SL.st2));
-    for (int l = N_LISTS - 1; l >= 0; --l)  // wide before narrow, strips (the bulk) in the middle
-        if (!on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
+    for (int l = N_LISTS - 1; l >= 0; --l) {  // wide before narrow, strips (the bulk) in the middle
+        if (on_side(l)) continue;
+        if (l == L_BAND - 1) ev.mark(15);  // the strip launches are timed on their own ([9]): the roofline kernel of bench.py
+        if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
+        if (l == L_STRIP) ev.mark(9);
+    }
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
     ev.mark(15);
     hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
@@ -1025,18 +1032,32 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     if (!redo.empty()) {
         const int nr = (int)redo.size();
         std::stable_sort(redo.begin(), redo.end(), [&](int x, int y) { return redo_list[x] < redo_list[y]; });
-        std::vector<int32_t> pack((size_t)nr * 3);
+        // [ids | layout | qstride | p_off (int64)]: a strip window's second pass needs a band / anti-diagonal matrix, which
+        // comes from a pool of its own (offsets are relative to the main pool's base: one flat address space)
+        std::vector<int32_t> pack((size_t)nr * 5 + 2);
+        int64_t *pack_off = reinterpret_cast<int64_t *>(pack.data() + (((size_t)nr * 3 + 1) & ~(size_t)1));
+        int64_t p2_tot = 0;
         for (int k = 0; k < nr; ++k) {
-            ExtJob &jb = jobs[redo[k]];
+            const int j = redo[k];
+            ExtJob &jb = jobs[j];
             jb.flag &= ~EZ_APPROX_MAX;
-            jb.layout = band_v[redo[k]] >= 0 ? 2 : 0;
-            jb.qstride = 128 << std::max<int>(band_v[redo[k]], 0);
-            pack[k] = redo[k]; pack[nr + k] = jb.layout; pack[2 * nr + k] = jb.qstride;
+            jb.layout = band_v[j] >= 0 ? 2 : 0;
+            jb.qstride = 128 << std::max<int>(band_v[j], 0);
+            pack[k] = j; pack[nr + k] = jb.layout; pack[2 * nr + k] = jb.qstride;
+            if (list_id[j] >= L_STRIP && list_id[j] < L_BAND) {
+                const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
+                pack_off[k] = -1 - p2_tot;  // resolved below, once the pool address is known
+                p2_tot += ((band_v[j] >= 0 ? n_r * (128 << band_v[j]) : n_r * jb.n_col) + 15) & ~(int64_t)15;
+            } else pack_off[k] = jb.p_off;
         }
-        if (SL.pool_redo.ensure((size_t)nr * 12)) return -1;
+        if (SL.pool_P2.ensure((size_t)p2_tot + 16)) return -1;
+        const int64_t p2_base = (int64_t)(SL.pool_P2.as<uint8_t>() - P.p);
+        for (int k = 0; k < nr; ++k) if (pack_off[k] < 0) { pack_off[k] = p2_base + (-1 - pack_off[k]); jobs[redo[k]].p_off = pack_off[k]; }
+        if (SL.pool_redo.ensure(pack.size() * 4)) return -1;
         struct { int32_t *p; } d_redo{SL.pool_redo.as<int32_t>()};
-        MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, pack.data(), (size_t)nr * 12, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(ext_redo_patch_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, d_jobs.p, d_redo.p, d_redo.p + nr, d_redo.p + 2 * nr, nr);
+        MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ext_redo_patch_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, d_jobs.p, d_redo.p, d_redo.p + nr, d_redo.p + 2 * nr,
+                           reinterpret_cast<const int64_t *>(d_redo.p + (((size_t)nr * 3 + 1) & ~(size_t)1)), nr);
         MPN_HIP_CHECK(hipGetLastError());
         ev.skip();
         for (int lo = 0; lo < nr;) {
@@ -1282,14 +1303,14 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
     if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
     if (n_threads < 1) n_threads = 1;
-    // sub-batches of ~48 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
+    // sub-batches of ~24 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
     // device arena, so that the host phases of one sub-batch overlap the GPU phases of the others and the
     // latency-bound kernels (chain DP, long extensions) of one overlap the throughput-bound ones of another
     int n_workers = 8;
     if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(16, atoi(e)));
     std::vector<int> cut{0};
     {
-        int64_t target = 48000000;
+        int64_t target = 24000000;
         if (const char *e = getenv("MPN_SUB_BATCH_BP")) target = std::max<int64_t>(1000, atoll(e));
         // equal-sized sub-batches, their count a multiple of the worker count so that no worker idles in the last round
         const int W = n_workers;
@@ -1307,6 +1328,21 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     }
     const int n_sub = (int)cut.size() - 1;
     n_workers = std::max(1, std::min(n_workers, n_sub));
+    {
+        // every worker holds its own scratch (direction matrices above all): about 400 bytes per base of a sub-batch
+        // with map-ont settings.  Do not start more workers than the free HBM (plus what the slots already hold) covers.
+        size_t free_b = 0, total_b = 0, held = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            for (const Slot &S : g_slots) {
+                held += S.pool_P.cap + S.pool_P2.cap + S.pool_CIG.cap + S.pool_compact.cap + S.pool_jobs.cap + S.pool_res.cap;
+                for (const auto &c : S.arena.chunks) held += c.cap;
+            }
+            const int64_t largest = n_sub > 0 ? (bases + n_sub - 1) / n_sub : bases;
+            const double per_worker = 400.0 * (double)std::max<int64_t>(largest, 1) + 2e9;
+            const int fit = (int)std::max(1.0, 0.9 * (double)(free_b + held) / per_worker);
+            n_workers = std::min(n_workers, fit);
+        }
+    }
     int dev = 0;
     MPN_HIP_CHECK(hipGetDevice(&dev));
     std::vector<ReadState> rs(n);
@@ -1316,6 +1352,9 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     std::mutex mu;
     int64_t tot_stats[32] = {0};
     std::string err;
+    const bool dbg_workers = getenv("MPN_DEBUG_WORKERS") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     auto worker = [&](int wid) {
         if (hipSetDevice(dev) != hipSuccess) { failed = 1; return; }
         Slot &S = g_slots[wid];
@@ -1327,6 +1366,8 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
             const int sb = next.fetch_add(1);
             if (sb >= n_sub || failed) break;
             S.arena.reset();
+            const double t_in = since();
+            struct Out { bool on; int wid, sb; double t_in; decltype(since) &f; ~Out() { if (on) fprintf(stderr, "[worker %d] sub-batch %d: %.1f -> %.1f ms\n", wid, sb, t_in, f()); } } out_{dbg_workers, wid, sb, t_in, since};
             if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1],
                           std::max(1, n_threads / n_workers), S.st, rs, rep_len, lines, paf != nullptr)) {
                 std::lock_guard<std::mutex> g(mu);
@@ -1343,6 +1384,19 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         std::vector<std::thread> th;
         for (int wdx = 0; wdx < n_workers; ++wdx) th.emplace_back(worker, wdx);
         for (auto &t : th) t.join();
+    }
+    if (dbg_workers) {
+        fprintf(stderr, "[call] workers joined at %.1f ms\n", since());
+        for (int wdx = 0; wdx < n_workers; ++wdx) {
+            const Slot &S = g_slots[wdx];
+            size_t arena = 0;
+            for (const auto &c : S.arena.chunks) arena += c.cap;
+            const size_t pools = S.pool_jobs.cap + S.pool_P.cap + S.pool_P2.cap + S.pool_OFF.cap + S.pool_order.cap + S.pool_state.cap + S.pool_CIG.cap +
+                                 S.pool_res.cap + S.pool_redo.cap + S.pool_compact.cap + S.pool_used.cap;
+            const size_t pinned = S.pin_jobs.cap + S.pin_order.cap + S.pin_res.cap + S.pin_cig.cap + S.pin_chain_u.cap + S.pin_chain_b.cap;
+            fprintf(stderr, "[slot %d] arena %.2f GB, pools %.2f GB (P %.2f, CIG %.2f, compact %.2f), pinned host %.2f GB\n", wdx, arena / 1e9,
+                    pools / 1e9, S.pool_P.cap / 1e9, S.pool_CIG.cap / 1e9, S.pool_compact.cap / 1e9, pinned / 1e9);
+        }
     }
     if (failed) { set_error("%s", err.empty() ? "worker failed" : err.c_str()); return -1; }
     {
@@ -1374,7 +1428,12 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
         paf[w] = 0;
     }
+    // the per-read state (regs with their CIGARs, PAF lines) is a few hundred thousand small allocations: free them in parallel
+    parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) { rs[i] = ReadState(); if (paf) std::string().swap(lines[i]); }
+    });
     whole.stop_into(g_stats[24]);
+    if (dbg_workers) fprintf(stderr, "[call] done at %.1f ms\n", since());
     return w;
 }
 

@@ -350,27 +350,86 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
     return (uint64_t)hi << 32 | lo;
 }
 
+// Chaining work items.  The predecessor scan of anchor i stops at the first j with x_i > x_j + max_dist_x, and the
+// anchors of a read are sorted by x = (strand, target, position), so wherever two consecutive anchors are further
+// apart than max_dist_x no chain can cross: the read's anchor list splits into independent SEGMENTS (one per target
+// locus, typically; a stray seed hit is a segment of its own).  One wave per read (this kernel) cuts the list at segment
+// boundaries into work items of at least CHAIN_ITEM anchors (whole segments only, so an item is chained exactly like a
+// short read) and computes the read-wide average seed length the gap cost uses; the DP kernel takes items, not reads,
+// from a shared queue -- the long pole of a batch becomes its longest locus instead of its longest read.  Items of at
+// least CHAIN_BIG anchors are queued first.
+constexpr int CHAIN_ITEM = 1024, CHAIN_BIG = 4096;
+struct ChainSeg { int32_t read, start, end; };
+
+__global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
+                                                            int n_reads, ChainParams cp, float *__restrict__ avg_qspan,
+                                                            ChainSeg *__restrict__ seg_big, ChainSeg *__restrict__ seg_small,
+                                                            unsigned int *__restrict__ counters) {
+    const int lane = threadIdx.x;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        if (n == 0) continue;
+        const u128 *a = anchors + base;
+        unsigned long long sum = 0;
+        int32_t open = 0;  // start of the segment being scanned (uniform)
+        for (int64_t i0 = 0; i0 < n; i0 += 64) {
+            const int64_t i = i0 + lane;
+            bool start = false;
+            if (i < n) {
+                sum += a[i].y >> 32 & 0xff;
+                start = i > 0 && a[i].x > a[i - 1].x + (uint64_t)cp.max_dist_x;
+            }
+            unsigned long long m = __ballot(start);
+            if (lane == 0) {
+                while (m) {
+                    const int32_t s_new = (int32_t)i0 + __builtin_ctzll(m);
+                    if (s_new - open >= CHAIN_ITEM) {
+                        const bool big = s_new - open >= CHAIN_BIG;
+                        const unsigned int pos = atomicAdd(&counters[big ? 0 : 1], 1u);
+                        (big ? seg_big : seg_small)[pos] = ChainSeg{read, open, s_new};
+                        open = s_new;
+                    }
+                    m &= m - 1;
+                }
+            }
+            open = __builtin_amdgcn_readfirstlane(open);
+        }
+        for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) {
+            avg_qspan[read] = (float)sum / (float)n;
+            const bool big = (int32_t)n - open >= CHAIN_BIG;
+            const unsigned int pos = atomicAdd(&counters[big ? 0 : 1], 1u);
+            (big ? seg_big : seg_small)[pos] = ChainSeg{read, open, (int32_t)n};
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
-                                                      const int32_t *__restrict__ read_order, int n_reads, ChainParams cp,
-                                                      int32_t *__restrict__ F, int32_t *__restrict__ P, int32_t *__restrict__ T,
-                                                      int32_t *__restrict__ V) {
+                                                      const float *__restrict__ avg_qspan_r, const ChainSeg *__restrict__ seg_big,
+                                                      const ChainSeg *__restrict__ seg_small, unsigned int *__restrict__ counters,
+                                                      ChainParams cp, int32_t *__restrict__ F, int32_t *__restrict__ P,
+                                                      int32_t *__restrict__ T, int32_t *__restrict__ V) {
     __shared__ int mark[64];
     __shared__ uint64_t wx[CHAIN_CW], wy[CHAIN_CW];
     __shared__ int32_t wf[CHAIN_CW], wp[CHAIN_CW], wt[CHAIN_CW], wv[CHAIN_CW];
     constexpr int64_t M = CHAIN_CW - 1;
     const int lane = threadIdx.x;
-    for (int ridx = blockIdx.x; ridx < n_reads; ridx += gridDim.x) {
-        const int read = read_order[ridx];
-        const int64_t base = anchor_off[read];
-        const int64_t n = anchor_off[read + 1] - base;
-        if (n == 0) continue;
+    const unsigned int n_big = counters[0], n_seg = n_big + counters[1];
+    for (;;) {
+        unsigned int sidx = 0;
+        if (lane == 0) sidx = atomicAdd(&counters[2], 1u);  // shared queue: big segments first
+        sidx = (unsigned int)__builtin_amdgcn_readfirstlane((int)sidx);
+        if (sidx >= n_seg) break;
+        const ChainSeg sg = sidx < n_big ? seg_big[sidx] : seg_small[sidx - n_big];
+        // the segment is chained like a read of its own; predecessor indices are stored relative to the read
+        const int64_t base = anchor_off[sg.read] + sg.start;
+        const int64_t n = sg.end - sg.start;
+        const int32_t rel = sg.start;
         const u128 *a = anchors + base;
         int32_t *f = F + base, *p = P + base, *t = T + base, *v = V + base;
-        // avg_qspan = (float)sum / n
-        unsigned long long sum = 0;
-        for (int64_t i = lane; i < n; i += 64) { sum += a[i].y >> 32 & 0xff; t[i] = 0; }
-        for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
-        const float avg_qspan = (float)sum / (float)n;
+        for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+        const float avg_qspan = avg_qspan_r[sg.read];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // chunk registers: lane l holds anchor c0 + l of the current chunk and of the next one; results of the chunk
         uint64_t cx = lane < n ? a[lane].x : 0, cy = lane < n ? a[lane].y : 0, nx = 0, ny = 0;
@@ -397,7 +456,7 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                     uint64_t ax, ay;
                     int32_t fj;
                     if (inw) { const int sl = (int)(j & M); ax = wx[sl]; ay = wy[sl]; pj = wp[sl]; tj = wt[sl]; fj = wf[sl]; }
-                    else { ax = a[j].x; ay = a[j].y; pj = p[j]; tj = t[j]; fj = f[j]; }
+                    else { ax = a[j].x; ay = a[j].y; pj = p[j]; pj = pj >= 0 ? pj - rel : pj; tj = t[j]; fj = f[j]; }
                     if (ri > ax + (uint64_t)cp.max_dist_x) in = false;  // out of range: so is everything before it
                     else {
                         const int64_t dr = (int64_t)(ri - ax);
@@ -462,7 +521,7 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
             int32_t vprev = 0;
             if (max_j >= 0) vprev = max_j >= win_lo ? wv[(int)(max_j & M)] : v[max_j];
             const int32_t vi = (max_j >= 0 && vprev > max_f) ? vprev : max_f;
-            if (lane == li) { rf = max_f; rp = (int32_t)max_j; rv = vi; }
+            if (lane == li) { rf = max_f; rp = max_j >= 0 ? (int32_t)max_j + rel : -1; rv = vi; }
             if (lane == 0) {
                 const int sl = (int)(i & M);
                 wx[sl] = ri; wy[sl] = yi; wf[sl] = max_f; wp[sl] = (int32_t)max_j; wv[sl] = vi; wt[sl] = 0;

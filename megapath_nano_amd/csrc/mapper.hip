@@ -149,14 +149,18 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     cp.max_dist_x = opt->max_gap; cp.max_dist_y = opt->max_gap; cp.bw = opt->bw; cp.max_skip = opt->max_chain_skip;
     cp.max_iter = opt->max_chain_iter; cp.min_cnt = opt->min_cnt; cp.min_sc = opt->min_chain_score;
     const int g = std::max(1, std::min(n, 256 * 32));
-    // longest reads first: the kernel is sequential per read, so its tail is the longest read
-    std::vector<int32_t> ord(n);
-    for (int i = 0; i < n; ++i) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return h_len[x] > h_len[y]; });
-    DevBuf<int32_t> d_ord;
-    if (d_ord.upload(ord.data(), n, st)) return -1;
-    hipLaunchKernelGGL(chain_dp_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, (const int32_t *)d_ord.p, n, cp, F.p, P.p,
-                       T.p, V.p);
+    // work items of the chain DP: runs of whole independent segments of each read's anchor list, cut on the device
+    DevBuf<ChainSeg> seg_big, seg_small;
+    DevBuf<float> avg_qspan;
+    DevBuf<unsigned int> seg_counters;
+    if (seg_big.alloc((size_t)n_a / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_a / CHAIN_ITEM + (size_t)n + 1) || avg_qspan.alloc(n) ||
+        seg_counters.alloc(4) || seg_counters.zero(st))
+        return -1;
+    hipLaunchKernelGGL(chain_segments_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, avg_qspan.p, seg_big.p,
+                       seg_small.p, seg_counters.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(chain_dp_kernel, dim3(256 * 32), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, (const float *)avg_qspan.p,
+                       (const ChainSeg *)seg_big.p, (const ChainSeg *)seg_small.p, seg_counters.p, cp, F.p, P.p, T.p, V.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(13);
     hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);

@@ -271,7 +271,7 @@ STAT_NAMES = {0: 'bases', 1: 'minimizers', 2: 'anchors', 3: 'chains', 4: 'dp_job
               16: 'wall_h2d_ns', 17: 'wall_seed_chain_ns', 18: 'wall_d2h_chains_ns', 19: 'wall_host_hits_ns',
               20: 'wall_host_plan_ns', 21: 'wall_ext_stage_ns', 22: 'wall_host_stitch_ns', 23: 'wall_host_final_ns',
               24: 'wall_total_ns', 27: 'wall_ext_host_prep_ns', 28: 'wall_ext_enqueue_ns', 29: 'wall_ext_gpu_wait_ns',
-              30: 'wall_ext_finish_ns'}
+              30: 'wall_ext_finish_ns', 9: 'ev_ext_strip_ns', 31: 'strip_cells'}
 
 
 def last_stats():

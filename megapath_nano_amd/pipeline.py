@@ -12,6 +12,19 @@ from . import mapper
 from .reassignment import ReassignPlan
 
 
+def random_block(rnd, n):
+    """The next n values of `rnd.random()` (a random.Random, or the random module) as a float64 array, leaving `rnd` where
+    n calls would have left it.  Python's generator and numpy's RandomState are the same MT19937 with the same 53-bit
+    double construction, so the state is lent to numpy for the block instead of making n Python-level calls."""
+    ver, st, gauss = rnd.getstate()
+    rs = np.random.RandomState()
+    rs.set_state(('MT19937', np.array(st[:-1], dtype=np.uint32), int(st[-1])))
+    out = rs.random_sample(int(n))
+    _, key, pos = rs.get_state()[:3]
+    rnd.setstate((ver, tuple(int(x) for x in key) + (int(pos),), gauss))
+    return out
+
+
 class Taxonomy:
     """Per target sequence: dense species-name code (reassignment.py:69-71) and dense species_tax_id code."""
 
@@ -31,8 +44,7 @@ def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_thre
     score = c['as_'][keep]
     aligned_bp = (c['re'][keep] - c['rs'][keep]).astype(np.int64)
     n_rows = len(read_idx)
-    rnd = rng if rng is not None else random
-    tiebreak = np.fromiter((rnd.random() for _ in range(n_rows)), dtype=np.float64, count=n_rows)  # aligner.py:334-335
+    tiebreak = random_block(rng if rng is not None else random, n_rows)     # aligner.py:334-335
     read_count = np.zeros(tax.n_names, dtype=np.int64)
     bp = np.zeros(tax.n_species, dtype=np.int64)
     nrel = 0
