@@ -797,7 +797,7 @@ __global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const in
 }
 
 // launch lists: every DP job of a group belongs to exactly one
-enum { L_LDS = 0, L_WG = 5, L_REG = 20, L_STRIP = 22, L_BAND = 25, N_LISTS = 41 };
+enum { L_LDS = 0, L_WG = 5, L_REG = 20, L_STRIP = 22, N_STRIP = 4, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
 
 // Run one group of DP jobs on the GPU (its scratch fits the budget).  jobs[0..nj) are completed in place (scratch
 // offsets, layout); results and CIGAR ops stay in the worker's pinned buffers: *res_out / *cig_out are valid until the
@@ -810,7 +810,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     WallTimer wt;
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     struct Acc {
-        size_t lds_need[5] = {0, 0, 0, 0, 0}, reg_lds[2] = {64, 64}, strip_lds[3] = {64, 64, 64}, band_lds[4] = {64, 64, 64, 64};
+        size_t lds_need[5] = {0, 0, 0, 0, 0}, reg_lds[2] = {64, 64}, strip_lds[N_STRIP] = {0}, band_lds[4] = {64, 64, 64, 64};
         int64_t cells = 0, strip_cells = 0;
         int too_large = 0, tl_q = 0, tl_t = 0;
     };
@@ -841,7 +841,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             band_v[j] = (int8_t)bv; band_c[j] = (int8_t)bc;
             if (bv >= 0) A.band_lds[bc] = std::max(A.band_lds[bc], seqb);
             jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
-            jb.strip_s = jb.tlen <= 256 ? 4 : jb.tlen <= 512 ? 8 : 16;
+            jb.strip_s = std::max(1, std::min(16, (jb.tlen + 63) / 64));  // strip height: the window's rows over all 64 lanes
             const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
             jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << std::max(bv, 0);  // row width of the direction matrix (layouts 1, 2)
             const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
@@ -859,7 +859,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             const bool use_wg = g_force_kernel == 3 || (g_force_kernel != 1 && n_col - 1 > 128);
             const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
             redo_list[j] = (int8_t)(bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls);
-            if (strip) { const int rc = jb.tlen <= 256 ? 0 : jb.tlen <= 512 ? 1 : 2; lid = L_STRIP + rc; A.strip_lds[rc] = std::max(A.strip_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
+            if (strip) { const int rc = (jb.strip_s - 1) / 4; lid = L_STRIP + rc; A.strip_lds[rc] = std::max(A.strip_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
             else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
             else if (reg_ok && g_force_kernel == 2) { const int rc = jb.tlen <= 256 ? 0 : 1; lid = L_REG + rc; A.reg_lds[rc] = std::max(A.reg_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
             else lid = redo_list[j];
@@ -877,7 +877,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     for (const Acc &A : accs) {
         for (int c = 0; c < 5; ++c) M.lds_need[c] = std::max(M.lds_need[c], A.lds_need[c]);
         for (int c = 0; c < 2; ++c) M.reg_lds[c] = std::max(M.reg_lds[c], A.reg_lds[c]);
-        for (int c = 0; c < 3; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
+        for (int c = 0; c < N_STRIP; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
         for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
         M.cells += A.cells; M.strip_cells += A.strip_cells;
         if (A.too_large) { set_error("DP window too large for LDS staging (%d x %d)", A.tl_q, A.tl_t); return -4; }
@@ -966,9 +966,9 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             if (l == L_REG) hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
             else hipLaunchKernelGGL(ext_dp_reg_kernel<8>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
         } else if (l < L_BAND) {
-            const size_t lds = M.strip_lds[l - L_STRIP];
-#define MPN_STRIP_LAUNCH(SS) hipLaunchKernelGGL(ext_dp_strip_kernel<SS>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p)
-            if (l == L_STRIP) MPN_STRIP_LAUNCH(4); else if (l == L_STRIP + 1) MPN_STRIP_LAUNCH(8); else MPN_STRIP_LAUNCH(16);
+            const size_t lds = std::max<size_t>(M.strip_lds[l - L_STRIP], 64);
+#define MPN_STRIP_LAUNCH(GG) case GG: hipLaunchKernelGGL(ext_dp_strip_kernel<GG>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p); break
+            switch (l - L_STRIP) { MPN_STRIP_LAUNCH(0); MPN_STRIP_LAUNCH(1); MPN_STRIP_LAUNCH(2); MPN_STRIP_LAUNCH(3); }
 #undef MPN_STRIP_LAUNCH
         } else {
             const int bvar = (l - L_BAND) / 4;

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
 }
 
 // Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 64*S, gaps
-// left-aligned): lane l owns the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l,
+// left-aligned; S = ceil(tlen / 64) = 1..16, so that the rows of a window spread over (almost) all 64 lanes): lane l owns the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l,
 // so after a ramp of n_lanes-1 steps every lane computes S cells per step -- no partially filled anti-diagonal tiles.
 // The left neighbour (t, j-1) of a cell is the lane's own previous step (u, y, y2 kept per row in VGPRs), the upper
 // neighbour (t-1, j) is the previous row of the same step or, for the first row of a strip, the bottom row lane l-1
@@ -750,14 +750,10 @@ __host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {
 }
 
 template <int S>
-__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                                          ExtParams prm, const uint8_t *__restrict__ reads,
-                                                          const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void ext_strip_job(const ExtJob &jb, const int jid, const ExtParams &prm, const uint8_t *__restrict__ reads,
+                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                              const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem) {
     const int lane = threadIdx.x;
-    const int jid = order[blockIdx.x];
-    const ExtJob jb = jobs[jid];
     const int qlen = jb.qlen, tlen = jb.tlen;
     int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
     if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
@@ -810,9 +806,9 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
         const int bj = MPN_BND(step);  // lane 0: j = step
         v_up = lane == 0 ? bj : v_up; x_up = lane == 0 ? 0 : x_up; x2_up = lane == 0 ? 0 : x2_up;
         if (j >= 0 && j < qlen && lane < n_lanes) {
-            uint32_t dw[S / 4];
+            uint32_t dw[(S + 3) / 4];
 #pragma unroll
-            for (int k = 0; k < S / 4; ++k) dw[k] = 0;
+            for (int k = 0; k < (S + 3) / 4; ++k) dw[k] = 0;
             int nv0 = 0;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
@@ -838,10 +834,16 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
             }
             out_v = v_up; out_x = x_up; out_x2 = x2_up;
             row0 += nv0;
-            uint8_t *dst = prow + (int64_t)step * W;  // S-byte aligned: p_off is 16-aligned, W and t0 are multiples of S
+            uint8_t *dst = prow + (int64_t)step * W;  // p_off is 16-aligned, W and t0 are multiples of S
             if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
             else if constexpr (S == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(dw[0], dw[1]);
-            else *reinterpret_cast<uint4 *>(dst) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+            else if constexpr (S == 16) *reinterpret_cast<uint4 *>(dst) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+            else {  // other strip heights: 32-bit pieces at the natural alignment of lane*S (global memory takes unaligned stores)
+#pragma unroll
+                for (int c = 0; c < S / 4; ++c) __builtin_memcpy(dst + 4 * c, &dw[c], 4);
+                if constexpr ((S & 2) != 0) { const uint16_t h = (uint16_t)dw[S / 4]; __builtin_memcpy(dst + (S & ~3), &h, 2); }
+                if constexpr ((S & 1) != 0) dst[S - 1] = (uint8_t)(dw[S / 4] >> ((S & 2) ? 16 : 0));
+            }
         }
     }
 #undef MPN_BND
@@ -854,6 +856,24 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
     out.r_done = qlen + tlen - 2;
     out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1;
     if (lane == 0) res[jid] = out;
+}
+
+// One launch per group of four strip heights (G = 0..3: S = 4G+1 .. 4G+4): few launches with many windows each keep
+// the tail of a launch short, and the register budget of a launch is that of its tallest strip only.
+template <int G>
+__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                          ExtParams prm, const uint8_t *__restrict__ reads,
+                                                          const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    switch (jb.strip_s - 4 * G) {
+        case 1: ext_strip_job<4 * G + 1>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
+        case 2: ext_strip_job<4 * G + 2>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
+        case 3: ext_strip_job<4 * G + 3>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
+        default: ext_strip_job<4 * G + 4>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
+    }
 }
 
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
