@@ -83,8 +83,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
 
 /* ---- stage: the banded dual-affine extension DP on arbitrary pairs of 0..4 code strings (parity tests) -------
  * flag bits as in ksw2: 0x02 approximate max, 0x08 right-align gaps, 0x40 extension only, 0x80 reversed CIGAR.
- * force_kernel: 0 = dispatch as mpn_map_batch does, 1 = single-wave LDS kernel, 2 = register kernel where
- * eligible, 3 = workgroup kernel, 4 = systolic strip kernel where eligible, 5 = band-in-registers kernel where the band fits 1024 slots.  out9[i*9..] = max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar. */
+ * force_kernel: 0 = dispatch as mpn_map_batch does, 1 = single-wave LDS kernel, 3 = workgroup kernel, 4 = systolic strip kernel where eligible, 5 = band-in-registers kernel where the band fits 1024 slots.  out9[i*9..] = max, zdropped, max_q, max_t, mqe, mqe_t, score, reach_end, n_cigar. */
 int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t *qcodes, const int64_t *q_off, const int32_t *q_len,
                      const uint8_t *tcodes, const int64_t *t_off, const int32_t *t_len, const int32_t *w, const int32_t *zdrop,
                      const int32_t *end_bonus, const int32_t *flag, int32_t force_kernel, int32_t *out9, uint32_t *cigar_pool,

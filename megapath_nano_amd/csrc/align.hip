@@ -775,7 +775,7 @@ struct Slot {
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
 
-static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 2 register kernel, 3 workgroup kernel, 4 strip, 5 band
+static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 3 workgroup kernel, 4 strip (else band), 5 band
 
 static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn) {
     if (n_threads <= 1 || n < 8192) { fn(0, n, 0); return; }
@@ -797,7 +797,7 @@ __global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const in
 }
 
 // launch lists: every DP job of a group belongs to exactly one
-enum { L_LDS = 0, L_WG = 5, L_REG = 20, L_STRIP = 22, N_STRIP = 4, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
+enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 4, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
 
 // Run one group of DP jobs on the GPU (its scratch fits the budget).  jobs[0..nj) are completed in place (scratch
 // offsets, layout); results and CIGAR ops stay in the worker's pinned buffers: *res_out / *cig_out are valid until the
@@ -810,7 +810,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     WallTimer wt;
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     struct Acc {
-        size_t lds_need[5] = {0, 0, 0, 0, 0}, reg_lds[2] = {64, 64}, strip_lds[N_STRIP] = {0}, band_lds[4] = {64, 64, 64, 64};
+        size_t lds_need[5] = {0, 0, 0, 0, 0}, strip_lds[N_STRIP] = {0}, band_lds[4] = {64, 64, 64, 64};
         int64_t cells = 0, strip_cells = 0;
         int too_large = 0, tl_q = 0, tl_t = 0;
     };
@@ -855,13 +855,11 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             st_bytes[j] = 0;
             jb.state_mode = 0;
             int lid;
-            const bool reg_ok = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & EZ_EXTZ_ONLY) && jb.tlen <= 512 && jb.qlen <= 60000;
             const bool use_wg = g_force_kernel == 3 || (g_force_kernel != 1 && n_col - 1 > 128);
             const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
             redo_list[j] = (int8_t)(bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls);
             if (strip) { const int rc = (jb.strip_s - 1) / 4; lid = L_STRIP + rc; A.strip_lds[rc] = std::max(A.strip_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
             else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
-            else if (reg_ok && g_force_kernel == 2) { const int rc = jb.tlen <= 256 ? 0 : 1; lid = L_REG + rc; A.reg_lds[rc] = std::max(A.reg_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
             else lid = redo_list[j];
             if (bv < 0) {  // the LDS-state kernels may run this window (now or in the second pass)
                 if (cls == 4) {
@@ -876,7 +874,6 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     Acc M;
     for (const Acc &A : accs) {
         for (int c = 0; c < 5; ++c) M.lds_need[c] = std::max(M.lds_need[c], A.lds_need[c]);
-        for (int c = 0; c < 2; ++c) M.reg_lds[c] = std::max(M.reg_lds[c], A.reg_lds[c]);
         for (int c = 0; c < N_STRIP; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
         for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
         M.cells += A.cells; M.strip_cells += A.strip_cells;
@@ -906,7 +903,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         for (int j = 0; j < nj; ++j) flat[cur[(int)list_id[j]]++] = j;
     }
     if (getenv("MPN_DEBUG_JOBS")) {
-        static const char *const fam[] = {"lds", "wg", "reg", "strip", "band"};
+        static const char *const fam[] = {"lds", "wg", "strip", "band"};
         for (int l = 0; l < N_LISTS; ++l) {
             if (!cnt[l]) continue;
             int64_t c = 0, mx = 0, ext = 0;
@@ -915,7 +912,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
                 const int64_t z = ((int64_t)jb.qlen + jb.tlen - 1) * jb.n_col;
                 c += z; mx = std::max(mx, z); ext += (jb.flag & EZ_EXTZ_ONLY) != 0;
             }
-            const int f = l < L_WG ? 0 : l < L_REG ? 1 : l < L_STRIP ? 2 : l < L_BAND ? 3 : 4;
+            const int f = l < L_WG ? 0 : l < L_STRIP ? 1 : l < L_BAND ? 2 : 3;
             fprintf(stderr, "[jobs] %s list %-2d n=%d cells=%.2fG max=%.1fM ext=%lld\n", fam[f], l, cnt[l], c / 1e9, mx / 1e6, (long long)ext);
         }
     }
@@ -950,7 +947,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(ext_dp_kernel, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p,
                                gstate.p, d_res.p);
-        } else if (l < L_REG) {
+        } else if (l < L_STRIP) {
             const int ntc = (l - L_WG) / 5;
             const size_t lds = std::max<size_t>(M.lds_need[(l - L_WG) % 5], 64);
 #define MPN_WG_LAUNCH(NT)                                                                                                             \
@@ -961,10 +958,6 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             } while (0)
             if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
 #undef MPN_WG_LAUNCH
-        } else if (l < L_STRIP) {
-            const size_t lds = M.reg_lds[l - L_REG];
-            if (l == L_REG) hipLaunchKernelGGL(ext_dp_reg_kernel<4>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
-            else hipLaunchKernelGGL(ext_dp_reg_kernel<8>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p, d_res.p);
         } else if (l < L_BAND) {
             const size_t lds = std::max<size_t>(M.strip_lds[l - L_STRIP], 64);
 #define MPN_STRIP_LAUNCH(GG) case GG: hipLaunchKernelGGL(ext_dp_strip_kernel<GG>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p); break
@@ -994,7 +987,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     }
     MPN_HIP_CHECK(hipEventRecord(SL.ev_a, st));
     MPN_HIP_CHECK(hipStreamWaitEvent(SL.st2, SL.ev_a, 0));
-    auto on_side = [](int l) { return (l >= L_WG && l < L_REG) || l >= L_BAND + 8; };  // workgroup windows, 512- and 1024-slot bands
+    auto on_side = [](int l) { return (l >= L_WG && l < L_STRIP) || l >= L_BAND + 8; };  // workgroup windows, 512- and 1024-slot bands
     for (int l = N_LISTS - 1; l >= 0; --l)
         if (on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], SL.st2)) return -1;
     MPN_HIP_CHECK(hipEventRecord(SL.ev_b, SL.st2));

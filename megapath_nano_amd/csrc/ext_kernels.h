@@ -234,135 +234,9 @@ __global__ __launch_bounds__(64) void ext_dp_kernel(const ExtJob *__restrict__ j
     if (lane == 0) res[jid] = out;
 }
 
-// Register-resident variant for gap-fill windows (EZ_APPROX_MAX, tlen <= 64*T): lane l owns target positions
-// t = k*64 + l (k < T) for the whole job, so the six difference states and the target base never leave VGPRs; only
-// the query base of the current anti-diagonal comes from LDS.  Same recurrences, band and boundary rules as
-// ext_dp_kernel; no H row (the approximate-max mode tracks one cell).
-template <int T>
-__global__ __launch_bounds__(64) void ext_dp_reg_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                                        ExtParams prm, const uint8_t *__restrict__ reads,
-                                                        const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                        RefView rv,
-                                                        uint8_t *__restrict__ P, int32_t *__restrict__ OFF, ExtRes *__restrict__ res) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x;
-    const int jid = order[blockIdx.x];
-    const ExtJob jb = jobs[jid];
-    const int qlen = jb.qlen, tlen = jb.tlen;
-    int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
-    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
-    const int qe = q + e, qe2 = q2 + e2;
-    ExtRes out;
-    out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
-    out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
-    if (qlen <= 0 || tlen <= 0 || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
-    int w = jb.w;
-    if (w < 0) w = tlen > qlen ? tlen : qlen;
-    const int n_col = jb.n_col;
-    uint8_t *qs_ = smem;
-    int U[T], V[T], X[T], Y[T], X2[T], Y2[T], TS[T];
-    {
-        const int64_t roff = read_off[jb.read];
-        const int32_t rlen = read_len[jb.read];
-        for (int i = lane; i < qlen; i += 64) qs_[i] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i));
-        const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const int t = k * 64 + lane;
-            TS[k] = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
-            U[k] = V[k] = X[k] = Y[k] = -qe;
-            X2[k] = Y2[k] = -qe2;
-        }
-    }
-    __syncthreads();
-    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
-    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
-    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-    uint8_t *p = P + jb.p_off;
-    const int n_r = qlen + tlen - 1;
-    int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
-    int32_t score = NEG_INF, H0 = 0, last_H0_t = 0;
-    int last_st = -1, last_en = -1, r, zdropped = 0;
-    const bool right = (jb.flag & EZ_RIGHT) != 0;
-    for (r = 0; r < n_r; ++r) {
-        int st = 0, en = tlen - 1;
-        if (st < r - qlen + 1) st = r - qlen + 1;
-        if (en > r) en = r;
-        if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
-        if (en > (r + w) >> 1) en = (r + w) >> 1;
-        if (st > en) { zdropped = 1; break; }
-        // left boundary of the first band cell
-        const bool left_known = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
-        int bx1 = -qe, bx21 = -qe2, bv1 = -qe;
-        if (st == 0) bv1 = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-        const int bnd_u = r == 0 ? -qe : r < long_thres ? -e : r == long_thres ? long_diff : -e2;
-        if (lane == 0) { off[r] = st; off_end[r] = en; }
-        uint8_t *pr = p + (int64_t)r * n_col;
-        int carry_v = 0, carry_x = 0, carry_x2 = 0;  // old lane-63 values of the previous tile
-        int h0_v = 0, h0_u = 0;                      // new v[last_H0_t], u[last_H0_t+1] for the approximate max
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const int t0 = k * 64;
-            // old values of this tile, needed by the next tile's lane 0
-            const int old_v63 = __builtin_amdgcn_readlane(V[k], 63), old_x63 = __builtin_amdgcn_readlane(X[k], 63),
-                      old_x263 = __builtin_amdgcn_readlane(X2[k], 63);
-            if (t0 <= en && t0 + 63 >= st) {
-                const int t = t0 + lane;
-                const bool act = t >= st && t <= en;
-                if (en >= r && t == r) { Y[k] = -qe; Y2[k] = -qe2; U[k] = bnd_u; }
-                int v1 = wave_shr1(V[k], carry_v), x1 = wave_shr1(X[k], carry_x), x21 = wave_shr1(X2[k], carry_x2);
-                if (t == st && !left_known) { v1 = bv1; x1 = bx1; x21 = bx21; }
-                const int sr = act ? (int)qs_[r - t] : 4;
-                const int sq = TS[k];
-                const int sc = (sq == 4 || sr == 4) ? prm.sc_n : sq == sr ? prm.sc_mch : prm.sc_mis;
-                const int ut = U[k];
-                int z = sc, a = x1 + v1, b = Y[k] + ut, a2 = x21 + v1, b2 = Y2[k] + ut, d;
-                if (!right) {
-                    d = a > z ? 1 : 0; z = max(z, a);
-                    d = b > z ? 2 : d; z = max(z, b);
-                    d = a2 > z ? 3 : d; z = max(z, a2);
-                    d = b2 > z ? 4 : d; z = max(z, b2);
-                } else {
-                    d = z > a ? 0 : 1; z = max(z, a);
-                    d = z > b ? d : 2; z = max(z, b);
-                    d = z > a2 ? d : 3; z = max(z, a2);
-                    d = z > b2 ? d : 4; z = max(z, b2);
-                }
-                z = min(z, (int)prm.sc_mch);
-                const int nu = z - v1, nv = z - ut;
-                int tmp = z - q; a -= tmp; b -= tmp;
-                tmp = z - q2; a2 -= tmp; b2 -= tmp;
-                if (!right) { d |= a > 0 ? 0x08 : 0; d |= b > 0 ? 0x10 : 0; d |= a2 > 0 ? 0x20 : 0; d |= b2 > 0 ? 0x40 : 0; }
-                else { d |= a >= 0 ? 0x08 : 0; d |= b >= 0 ? 0x10 : 0; d |= a2 >= 0 ? 0x20 : 0; d |= b2 >= 0 ? 0x40 : 0; }
-                if (act) {
-                    U[k] = nu; V[k] = nv;
-                    X[k] = max(a, 0) - qe; Y[k] = max(b, 0) - qe;
-                    X2[k] = max(a2, 0) - qe2; Y2[k] = max(b2, 0) - qe2;
-                    pr[t - st] = (uint8_t)d;
-                }
-                if (t0 <= last_H0_t && last_H0_t <= t0 + 63) h0_v = __builtin_amdgcn_readlane(V[k], last_H0_t & 63);
-                if (t0 <= last_H0_t + 1 && last_H0_t + 1 <= t0 + 63) h0_u = __builtin_amdgcn_readlane(U[k], (last_H0_t + 1) & 63);
-            }
-            carry_v = old_v63; carry_x = old_x63; carry_x2 = old_x263;
-        }
-        if (r > 0) {
-            if (last_H0_t >= st && last_H0_t <= en && last_H0_t + 1 >= st && last_H0_t + 1 <= en) {
-                if (h0_v > h0_u) H0 += h0_v; else { H0 += h0_u; ++last_H0_t; }
-            } else if (last_H0_t >= st && last_H0_t <= en) H0 += h0_v;
-            else { ++last_H0_t; H0 += h0_u; }
-        } else { H0 = __builtin_amdgcn_readlane(V[0], 0) - qe; last_H0_t = 0; }
-        if (r == n_r - 1 && en == tlen - 1) score = H0;
-        last_st = st; last_en = en;
-    }
-    out.zdropped = zdropped; out.score = score;
-    out.r_done = r < n_r ? r : n_r - 1;
-    if (!zdropped) { out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1; }
-    if (lane == 0) res[jid] = out;
-}
-
-// Workgroup-per-window variant for LARGE windows (long end extensions, long-join fills): the band of one
-// anti-diagonal (up to 2*bw+1 cells) is spread over NT threads instead of being walked by one wave tile after tile,
-// which removes the long single-wave tail those few windows otherwise leave behind.  States live in LDS (or the
+// Workgroup-per-window variant for windows the band kernel below cannot take (band wider than 1024 cells, or
+// sequences that do not fit LDS): the band of one anti-diagonal is spread over NT threads instead of being walked by one
+// wave tile after tile.  States live in LDS (or the
 // global scratch for huge windows).  Tiles are processed from the highest target position down: a tile reads its own
 // cells and its left neighbour (t-1, old values), a barrier follows, then it writes; lower tiles are still untouched.
 template <int NT>

@@ -1,4 +1,4 @@
-"""GPU parity tests (-m gpu) of the extension-DP kernels (single-wave LDS, register-resident, workgroup, strip, band) against
+"""GPU parity tests (-m gpu) of the extension-DP kernels (single-wave LDS, workgroup, strip, band) against
 the oracle's mmo_extd2 on seeded pairs: global / approximate-max / extension-only / right-aligned modes, band clipping,
 z-drop, ambiguous bases, small to large windows.  Bit-exact on scores, end points and CIGAR."""
 import numpy as np
@@ -71,14 +71,34 @@ def opt(libmpn, oracle_built):
 
 def test_gap_fill_windows_all_kernels(opt):
     qs, ts = make_pairs(1, [30, 64, 65, 128, 200, 230, 256, 257, 300, 400, 511])
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 5, 0])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 3, 4, 5, 0])
     qs, ts = make_pairs(2, [220, 260, 310], ambig=True)
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 5])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 3, 4, 5])
     qs, ts = make_pairs(3, [450, 500], big_indel=True)
-    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 2, 3, 4, 5])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [1, 3, 4, 5])
     qs, ts = make_pairs(11, [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 512, 513, 600, 700])
     check(opt, qs, ts, 751, 400, -1, APPROX, [1, 4, 5])
     check(opt, qs, ts, 751, 400, -1, APPROX | RIGHT, [1, 4, 5])
+
+
+def test_strip_heights_up_to_16(opt):
+    """Every strip height S = ceil(tlen / 64) = 1..16 of the systolic kernel (kernel 4), incl. the unaligned 32-bit
+    direction stores of the odd heights and query windows longer / shorter than the target."""
+    rng = np.random.default_rng(21)
+    qs, ts = [], []
+    for S in range(1, 17):
+        tlen = int(rng.integers(64 * (S - 1) + 1, 64 * S + 1))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        q = mutate(rng, t, 0.12)
+        if S % 3 == 0:
+            q = q[: max(1, len(q) * 2 // 3)]
+        if S % 4 == 1:
+            q = np.concatenate([q, rng.integers(0, 4, size=40).astype(np.uint8)])
+        qs.append(q)
+        ts.append(t)
+    ts.append(rng.integers(0, 4, size=1024).astype(np.uint8))
+    qs.append(mutate(rng, ts[-1], 0.1))
+    check(opt, qs, ts, 2000, 400, -1, APPROX, [4, 1])
 
 
 def test_exact_global_mode(opt):
@@ -100,7 +120,7 @@ def test_extension_modes_with_zdrop(opt):
 def test_band_clipping_and_large_windows(opt):
     qs, ts = make_pairs(8, [600, 1500])
     check(opt, qs, ts, 100, 400, -1, 0, [1, 3, 5])       # narrow band: cells outside the previous band
-    check(opt, qs, ts, 20, 400, -1, APPROX, [1, 2, 3, 5])
+    check(opt, qs, ts, 20, 400, -1, APPROX, [1, 3, 5])
     qs, ts = make_pairs(9, [3000, 5200], tail=True)
     check(opt, qs, ts, 751, 400, -1, EXTZ, [1, 3, 5, 0])
     qs, ts = make_pairs(10, [14000])                  # state arrays in the global scratch
