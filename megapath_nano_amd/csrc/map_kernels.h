@@ -178,27 +178,45 @@ __global__ __launch_bounds__(256) void seed_lookup_kernel(const uint64_t *__rest
     }
 }
 
-// per read (one lane): anchor offsets of its minimizers, anchor total and rep_len (minimap2 collect_matches)
-__global__ __launch_bounds__(256) void seed_prefix_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int n,
-                                                          const int32_t *__restrict__ occ, int64_t *__restrict__ rel_off,
-                                                          int64_t *__restrict__ n_anchor, int32_t *__restrict__ rep_len) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t run = 0;
-    int rep_st = 0, rep_en = 0, rl = 0;
-    for (int64_t m = mz_off[i]; m < mz_off[i + 1]; ++m) {
-        const int32_t t = occ[m];
-        rel_off[m] = run;
-        if (t < 0) {
-            const uint32_t q_pos = (uint32_t)mz[m].y, q_span = mz[m].x & 0xff;
-            const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
-            if (st > rep_en) { rl += rep_en - rep_st; rep_st = st, rep_en = en; }
-            else rep_en = en;
-        } else run += t;
+// per read (one wave): anchor offsets of its minimizers, anchor total and rep_len (minimap2 collect_matches).
+// rep_len is the length of the union of the query intervals [st, en) of the too-frequent minimizers; their `en` grows
+// with the minimizer index, so an interval adds en - max(st, en of the previous such interval): a max-scan, no loop.
+__global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int n,
+                                                         const int32_t *__restrict__ occ, int64_t *__restrict__ rel_off,
+                                                         int64_t *__restrict__ n_anchor, int32_t *__restrict__ rep_len) {
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t m0 = mz_off[i], m1 = mz_off[i + 1];
+        int64_t run = 0;
+        int32_t rl = 0, prev_en = 0;
+        for (int64_t c = m0; c < m1; c += 64) {
+            const int64_t m = c + lane;
+            int32_t t = 0, st = 0, en = 0;
+            if (m < m1) {
+                t = occ[m];
+                if (t < 0) {
+                    const uint32_t q_pos = (uint32_t)mz[m].y, q_span = mz[m].x & 0xff;
+                    en = (int)(q_pos >> 1) + 1; st = en - (int)q_span;
+                }
+            }
+            const bool rep = t < 0;
+            // exclusive prefix sum of the hit counts of this tile
+            int32_t incl = t > 0 ? t : 0;
+            const int32_t own = incl;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            if (m < m1) rel_off[m] = run + (incl - own);
+            run += __shfl(incl, 63);
+            // union length of the repetitive intervals
+            const int32_t e_incl = wave_scan_max(rep ? en : 0);
+            const int32_t before = max(wave_shr1(e_incl, 0), prev_en);
+            int32_t add = rep ? en - max(st, before) : 0;
+            for (int d = 32; d; d >>= 1) add += __shfl_xor(add, d);
+            rl += add;
+            prev_en = max(prev_en, __builtin_amdgcn_readlane(e_incl, 63));
+        }
+        if (lane == 0) { n_anchor[i] = run; rep_len[i] = rl; }
     }
-    rl += rep_en - rep_st;
-    n_anchor[i] = run;
-    rep_len[i] = rl;
 }
 
 __global__ __launch_bounds__(256) void seed_fill_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz,

@@ -118,7 +118,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
                            idx->n_keys, mz.p, n_mz, mid_occ, occ.p, pos_start.p);
         MPN_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(seed_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
+    hipLaunchKernelGGL(seed_prefix_kernel, dim3(std::max(1, std::min(n, 256 * 32))), dim3(64), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
                        n_anchor_d.p, o.rep_len.p);
     MPN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, n_anchor_d.p, o.anchor_off.p, n);
