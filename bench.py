@@ -185,8 +185,8 @@ def main():
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))
-        tb = sum(v.get('hbm_bytes_per_step', 0) for k, v in pm['kernels'].items() if k.startswith('ext_dp_strip_kernel'))
-        traffic = tb / max(pm.get('strip_launches_per_step', 1), 1)
+        # measured HBM bytes per strip cell (1.06 at the time of writing) x the cells of one launch group of THIS run
+        traffic = pm['strip_hbm_bytes_per_cell'] * bytes_per_launch
     except Exception:
         pass
     line = {
