@@ -125,13 +125,13 @@ def main():
     opt = mapper.default_opt(**opt_kw)
     opt.mid_occ = idx.mid_occ()
     allreduce = mdist.make_allreduce(red_device)
-    rnd = random.Random(12345 + rank)
+    rnd = random.Random(12345)  # the same stream on every rank: tiebreakers are drawn in global row order (pipeline.sharded_tiebreak)
 
     total = args.warmup + args.steps
     batches = [make_batch(genomes, weights, args, 1000 * (rank + 1) + s, device) for s in range(total)]
 
     def run(b):
-        return align_and_assign(idx, opt, b[0], tax, allreduce=allreduce, rng=rnd)
+        return align_and_assign(idx, opt, b[0], tax, allreduce=allreduce, rng=rnd, shard=(rank, world))
 
     for s in range(args.warmup):
         run(batches[s])

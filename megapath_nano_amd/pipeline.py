@@ -25,6 +25,25 @@ def random_block(rnd, n):
     return out
 
 
+def sharded_tiebreak(rnd, n_rows, shard, allreduce):
+    """Tiebreakers for this rank's rows such that the concatenation over ranks equals ONE `random.random()` stream drawn
+    in global row order (the reference draws them row by row over the whole table, aligner.py:334-335).  Every rank
+    seeds `rnd` identically; ranks hold contiguous read ranges in rank order; the row counts are exchanged as one small
+    all-reduce, the draws of the ranks before this one are skipped and those of the ranks after it consumed, so that
+    the generator is in the same state on every rank afterwards.  shard = (rank, world)."""
+    rank, world = shard
+    if world <= 1 or allreduce is None:
+        return random_block(rnd, n_rows)
+    counts = np.zeros(world, dtype=np.int64)
+    counts[rank] = n_rows
+    allreduce(counts)
+    before, after = int(counts[:rank].sum()), int(counts[rank + 1:].sum())
+    random_block(rnd, before)
+    out = random_block(rnd, n_rows)
+    random_block(rnd, after)
+    return out
+
+
 class Taxonomy:
     """Per target sequence: dense species-name code (reassignment.py:69-71) and dense species_tax_id code."""
 
@@ -35,8 +54,9 @@ class Taxonomy:
 
 
 def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_threshold=0.0, min_alignment_score=0,
-                     allreduce=None, rng=None, reassign=True):
-    """One step of the hot path for one batch of reads.  Returns dict(read_count, aligned_bp, n_rows, n_relations)."""
+                     allreduce=None, rng=None, reassign=True, shard=(0, 1)):
+    """One step of the hot path for one batch of reads.  Returns dict(read_count, aligned_bp, n_rows, n_relations).
+    With shard=(rank, world) and an all-reduce, `rng` must be seeded identically on every rank (see sharded_tiebreak)."""
     _, c = mapper.map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True)
     keep = c['as_'] >= min_alignment_score                                   # aligner.py:311-312
     read_idx = c['read_idx'][keep]
@@ -44,7 +64,7 @@ def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_thre
     score = c['as_'][keep]
     aligned_bp = (c['re'][keep] - c['rs'][keep]).astype(np.int64)
     n_rows = len(read_idx)
-    tiebreak = random_block(rng if rng is not None else random, n_rows)     # aligner.py:334-335
+    tiebreak = sharded_tiebreak(rng if rng is not None else random, n_rows, shard, allreduce)  # aligner.py:334-335
     read_count = np.zeros(tax.n_names, dtype=np.int64)
     bp = np.zeros(tax.n_species, dtype=np.int64)
     nrel = 0

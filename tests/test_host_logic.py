@@ -84,9 +84,15 @@ GLOO_WORKER = textwrap.dedent('''
         local_counts[code[n]] += c
     total = local_counts.copy()
     ar(total)
+    # tiebreakers in global row order: every rank seeds the same stream, rank r owns 100 + 37 * r rows, two steps
+    import random
+    from megapath_nano_amd.pipeline import sharded_tiebreak
+    rnd = random.Random('reads.fq')
+    tb = [sharded_tiebreak(rnd, 100 + 37 * rank, (rank, world), ar).tolist() for _ in range(2)]
     mdist.barrier()
     with open(os.path.join(os.environ['MPN_TEST_OUT'], f'rank{rank}.json'), 'w') as f:
-        json.dump(dict(rank=rank, local=int(local_counts.sum()), total=[int(x) for x in total], n_reads=len(reads)), f)
+        json.dump(dict(rank=rank, local=int(local_counts.sum()), total=[int(x) for x in total], n_reads=len(reads), tb=tb,
+                       next=rnd.random()), f)
 ''')
 
 
@@ -103,6 +109,29 @@ def test_gloo_world2_count_allreduce(tmp_path, oracle_built):
     assert sorted(l['rank'] for l in lines) == [0, 1]
     assert lines[0]['total'] == lines[1]['total']
     assert sum(lines[0]['total']) == lines[0]['n_reads'] == lines[0]['local'] + lines[1]['local']
+    # the two ranks' tiebreakers, concatenated in rank order, are one random.random() stream (aligner.py:334-335)
+    import random
+    lines.sort(key=lambda l: l['rank'])
+    want = random.Random('reads.fq')
+    for step in range(2):
+        for l in lines:
+            assert l['tb'][step] == [want.random() for _ in range(len(l['tb'][step]))]
+    nxt = want.random()
+    assert lines[0]['next'] == lines[1]['next'] == nxt
+
+
+def test_random_block_is_the_python_stream():
+    import random
+    from megapath_nano_amd.pipeline import random_block, sharded_tiebreak
+    import hashlib
+    seed = hashlib.md5('reads.fq'.encode()).hexdigest()                     # aligner.py:167-168
+    a, b = random.Random(seed), random.Random(seed)
+    assert random_block(a, 3).tolist() == [0.2507641374631844, 0.3100258391581491, 0.8083515623068414]
+    b.random(), b.random(), b.random()
+    for n in (0, 1, 623, 624, 625, 5000):
+        assert random_block(a, n).tolist() == [b.random() for _ in range(n)]
+    assert a.random() == b.random()
+    assert sharded_tiebreak(a, 7, (0, 1), None).tolist() == [b.random() for _ in range(7)]
 
 
 def test_human_decoy_classification_rules():
