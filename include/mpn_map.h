@@ -57,6 +57,17 @@ void mpn_map_opt_init(mpn_map_opt *opt);
 mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
                            int32_t k, int32_t w);
 void mpn_index_destroy(mpn_index *idx);
+/* Persistent form of a built index (the reference rebuilds its index on every run: bin/lib/aligner.py:209-221; minimap2's
+ * own `-d FILE` / prebuilt-index-as-target is used at bin/megapath_nano.py:1641-1645).  save: 0 or negative error;
+ * load: a resident index equal to the one saved (same keys/positions/targets), or NULL + mpn_last_error(). */
+int mpn_index_save(const mpn_index *idx, const char *path);
+mpn_index *mpn_index_load(const char *path);
+/* names and lengths of the targets of an index (for a loaded one): name i is copied into buf (cap bytes incl. NUL) */
+int32_t mpn_index_n_seq(const mpn_index *idx);
+int32_t mpn_index_seq_len(const mpn_index *idx, int32_t i);
+int32_t mpn_index_seq_name(const mpn_index *idx, int32_t i, char *buf, int32_t cap);
+int32_t mpn_index_k(const mpn_index *idx);
+int32_t mpn_index_w(const mpn_index *idx);
 int64_t mpn_index_n_minimizers(const mpn_index *idx);
 int64_t mpn_index_n_keys(const mpn_index *idx);
 /* occurrence cut-off for a given -f (minimap2: mm_idx_cal_max_occ) */

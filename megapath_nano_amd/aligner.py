@@ -201,11 +201,13 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
     random.seed(hashlib.md5(random_hash_string.encode()).hexdigest())                            # :167-168
 
     opt, k, w = parse_aligner_options(aligner_options, mapping_only)
-    genomes = _load_targets(target_paths)
     idx_key = (tuple(target_paths), k, w)
     idx = _INDEX_CACHE.get(idx_key)
     if idx is None:
-        idx = mapper.Index(genomes, k=k, w=w)
+        if len(target_paths) == 1 and mapper.Index.is_index_file(target_paths[0]):
+            idx = mapper.Index.load(target_paths[0])    # a prebuilt index as the target (megapath_nano.py:1641-1645)
+        else:
+            idx = mapper.Index(_load_targets(target_paths), k=k, w=w)
         _INDEX_CACHE[idx_key] = idx
     seq_names = np.array(idx.names, dtype=object)
     seq_lens = idx.lens

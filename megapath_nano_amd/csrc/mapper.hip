@@ -329,9 +329,116 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
     return idx;
 }
 
+// ---- persistent form of the index (minimap2 -d) ----------------------------------------------------
+// Little-endian file: magic "MPNIDX01", then k, w, n_seq, n_nruns (int32), n_keys, n_mz, total bases, n 2-bit words (int64),
+// then lens[n_seq] int32, names (u32 length + bytes each), N runs (start[], end[] int64), 2-bit words, keys, key_off, pos.
+static const char MPN_IDX_MAGIC[8] = {'M', 'P', 'N', 'I', 'D', 'X', '0', '1'};
+
+int mpn_index_save(const mpn_index *idx, const char *path) {
+    if (!idx || !path) { set_error("mpn_index_save: null argument"); return -1; }
+    hipStream_t st = 0;
+    const int64_t total = idx->seq_off.empty() ? 0 : idx->seq_off.back();
+    std::vector<uint32_t> words;
+    std::vector<int64_t> ns, ne;
+    pack_2bit(idx->seq4.data(), total, words, ns, ne);
+    std::vector<uint64_t> keys((size_t)idx->n_keys), pos((size_t)idx->n_mz);
+    if (idx->keys.download(keys.data(), keys.size(), st) || idx->pos.download(pos.data(), pos.size(), st)) return -1;
+    MPN_HIP_CHECK(stream_sync(st));
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("mpn_index_save: cannot open %s", path); return -1; }
+    bool ok = true;
+    auto put = [&](const void *p, size_t bytes) { if (bytes && fwrite(p, 1, bytes, f) != bytes) ok = false; };
+    const int32_t h32[4] = {idx->k, idx->w, idx->n_seq, (int32_t)ns.size()};
+    const int64_t h64[4] = {idx->n_keys, idx->n_mz, total, (int64_t)words.size()};
+    put(MPN_IDX_MAGIC, 8); put(h32, sizeof(h32)); put(h64, sizeof(h64));
+    put(idx->lens.data(), idx->lens.size() * 4);
+    for (const std::string &nm : idx->names) { const uint32_t l = (uint32_t)nm.size(); put(&l, 4); put(nm.data(), l); }
+    put(ns.data(), ns.size() * 8); put(ne.data(), ne.size() * 8);
+    put(words.data(), words.size() * 4);
+    put(keys.data(), keys.size() * 8);
+    put(idx->h_key_off.data(), idx->h_key_off.size() * 8);
+    put(pos.data(), pos.size() * 8);
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("mpn_index_save: short write to %s", path); return -1; }
+    return 0;
+}
+
+mpn_index *mpn_index_load(const char *path) {
+    if (!path) { set_error("mpn_index_load: null path"); return nullptr; }
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("mpn_index_load: cannot open %s", path); return nullptr; }
+    mpn_index *idx = new mpn_index();
+    bool ok = true;
+    auto get = [&](void *p, size_t bytes) { if (bytes && fread(p, 1, bytes, f) != bytes) ok = false; };
+    auto fail = [&](const char *why) { set_error("mpn_index_load: %s (%s)", why, path); fclose(f); delete idx; return (mpn_index *)nullptr; };
+    char magic[8];
+    int32_t h32[4];
+    int64_t h64[4];
+    get(magic, 8); get(h32, sizeof(h32)); get(h64, sizeof(h64));
+    if (!ok || memcmp(magic, MPN_IDX_MAGIC, 8) != 0) return fail("not an mpn index file");
+    idx->k = h32[0]; idx->w = h32[1]; idx->n_seq = h32[2]; idx->n_nruns = h32[3];
+    idx->n_keys = h64[0]; idx->n_mz = h64[1];
+    const int64_t total = h64[2], n_words = h64[3];
+    if (idx->k < 1 || idx->k > 28 || idx->n_seq <= 0 || idx->n_keys < 0 || idx->n_mz < idx->n_keys || total < 0 || n_words < (total + 15) / 16 || n_words > (total + 15) / 16 + 1 ||
+        idx->n_nruns < 0)
+        return fail("corrupt header");
+    idx->lens.resize((size_t)idx->n_seq);
+    get(idx->lens.data(), idx->lens.size() * 4);
+    idx->seq_off.assign((size_t)idx->n_seq + 1, 0);
+    for (int i = 0; i < idx->n_seq && ok; ++i) {
+        uint32_t l = 0;
+        get(&l, 4);
+        if (!ok || l > (1u << 20)) return fail("corrupt name table");
+        std::string nm(l, '\0');
+        get(&nm[0], l);
+        idx->names.push_back(nm);
+        idx->seq_off[(size_t)i + 1] = idx->seq_off[(size_t)i] + idx->lens[(size_t)i];
+    }
+    if (!ok || idx->seq_off.back() != total) return fail("corrupt sequence table");
+    std::vector<int64_t> ns((size_t)idx->n_nruns), ne((size_t)idx->n_nruns);
+    std::vector<uint32_t> words((size_t)n_words);
+    std::vector<uint64_t> keys((size_t)idx->n_keys), pos((size_t)idx->n_mz);
+    idx->h_key_off.resize((size_t)idx->n_keys + 1);
+    get(ns.data(), ns.size() * 8); get(ne.data(), ne.size() * 8);
+    get(words.data(), words.size() * 4);
+    get(keys.data(), keys.size() * 8);
+    get(idx->h_key_off.data(), idx->h_key_off.size() * 8);
+    get(pos.data(), pos.size() * 8);
+    if (!ok || idx->h_key_off.back() != idx->n_mz) return fail("truncated file");
+    // host copy of the targets as one code per base (the hit bookkeeping needs random access to them)
+    idx->seq4.resize((size_t)total);
+    for (int64_t i = 0; i < total; ++i) idx->seq4[(size_t)i] = (uint8_t)(words[(size_t)(i >> 4)] >> (2 * (i & 15)) & 3);
+    for (size_t r = 0; r < ns.size(); ++r) {
+        if (ns[r] < 0 || ne[r] > total || ns[r] > ne[r]) return fail("corrupt N runs");
+        for (int64_t i = ns[r]; i < ne[r]; ++i) idx->seq4[(size_t)i] = 4;
+    }
+    fclose(f);
+    hipStream_t st = 0;
+    if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(idx->h_key_off.data(), idx->h_key_off.size(), st) ||
+        idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq_off.upload(idx->seq_off.data(), idx->seq_off.size(), st) ||
+        idx->d_seq2.upload(words.data(), words.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
+        idx->d_nrun_e.upload(ne.data(), ne.size(), st) || stream_sync(st) != hipSuccess) {
+        delete idx;  // (the failing HIP call has set the error text)
+        return nullptr;
+    }
+    return idx;
+}
+
 void mpn_index_destroy(mpn_index *idx) { delete idx; }
 int64_t mpn_index_n_minimizers(const mpn_index *idx) { return idx->n_mz; }
 int64_t mpn_index_n_keys(const mpn_index *idx) { return idx->n_keys; }
+int32_t mpn_index_n_seq(const mpn_index *idx) { return idx->n_seq; }
+int32_t mpn_index_k(const mpn_index *idx) { return idx->k; }
+int32_t mpn_index_w(const mpn_index *idx) { return idx->w; }
+int32_t mpn_index_seq_len(const mpn_index *idx, int32_t i) { return i >= 0 && i < idx->n_seq ? idx->lens[(size_t)i] : -1; }
+int32_t mpn_index_seq_name(const mpn_index *idx, int32_t i, char *buf, int32_t cap) {
+    if (i < 0 || i >= idx->n_seq || !buf || cap <= 0) return -1;
+    const std::string &nm = idx->names[(size_t)i];
+    const int32_t l = (int32_t)std::min<size_t>(nm.size(), (size_t)cap - 1);
+    memcpy(buf, nm.data(), (size_t)l);
+    buf[l] = 0;
+    return (int32_t)nm.size();
+}
 
 int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
     if (f <= 0.f) return INT32_MAX;

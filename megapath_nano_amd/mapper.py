@@ -1,5 +1,6 @@
 """ctypes wrapper over include/mpn_map.h: index build, stage entry points and the batch mapper."""
 import ctypes as ct
+import os
 
 import numpy as np
 
@@ -48,6 +49,17 @@ def _bind():
         lib.mpn_index_mid_occ.restype = ct.c_int32
         lib.mpn_index_export.argtypes = [P, P, P, P]
         lib.mpn_index_export.restype = ct.c_int
+        lib.mpn_index_save.argtypes = [P, ct.c_char_p]
+        lib.mpn_index_save.restype = ct.c_int
+        lib.mpn_index_load.argtypes = [ct.c_char_p]
+        lib.mpn_index_load.restype = P
+        for fn in ('mpn_index_n_seq', 'mpn_index_k', 'mpn_index_w'):
+            getattr(lib, fn).argtypes = [P]
+            getattr(lib, fn).restype = ct.c_int32
+        lib.mpn_index_seq_len.argtypes = [P, ct.c_int32]
+        lib.mpn_index_seq_len.restype = ct.c_int32
+        lib.mpn_index_seq_name.argtypes = [P, ct.c_int32, ct.c_char_p, ct.c_int32]
+        lib.mpn_index_seq_name.restype = ct.c_int32
         lib.mpn_sketch_batch.argtypes = [ct.c_int32, P, P, P, ct.c_int32, ct.c_int32, P, P, ct.c_int64]
         lib.mpn_sketch_batch.restype = ct.c_int64
         lib.mpn_seed_chain_batch.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, P, P, P, P, P, P, P, ct.c_int64, P, P, ct.c_int64]
@@ -89,7 +101,9 @@ def pack_seqs(seqs):
 
 
 class Index:
-    """Target sequences + minimizer index resident in HBM (mpn_index_build)."""
+    """Target sequences + minimizer index resident in HBM (mpn_index_build), or loaded from a file written by save()."""
+
+    MAGIC = b'MPNIDX01'
 
     def __init__(self, genomes, k=15, w=10):
         lib = _bind()
@@ -103,6 +117,37 @@ class Index:
         self.h = lib.mpn_index_build(n, names, seqs, self.lens.ctypes.data, k, w)
         if not self.h:
             raise _ffi.MpnError('mpn_index_build failed: ' + _ffi.last_error())
+
+    def save(self, path):
+        """Persistent form (minimap2 `-d FILE`): load() gives back an index that maps identically."""
+        _ffi.check(_bind().mpn_index_save(self.h, os.fsencode(path)), 'mpn_index_save')
+
+    @classmethod
+    def load(cls, path):
+        lib = _bind()
+        h = lib.mpn_index_load(os.fsencode(path))
+        if not h:
+            raise _ffi.MpnError('mpn_index_load failed: ' + _ffi.last_error())
+        self = cls.__new__(cls)
+        self.h, self._seqs = h, None
+        n = lib.mpn_index_n_seq(h)
+        buf = ct.create_string_buffer(1 << 16)
+        self.names, lens = [], []
+        for i in range(n):
+            lib.mpn_index_seq_name(h, i, buf, len(buf))
+            self.names.append(buf.value.decode())
+            lens.append(lib.mpn_index_seq_len(h, i))
+        self.lens = np.array(lens, dtype=np.int32)
+        self.k, self.w = lib.mpn_index_k(h), lib.mpn_index_w(h)
+        return self
+
+    @classmethod
+    def is_index_file(cls, path):
+        try:
+            with open(path, 'rb') as f:
+                return f.read(8) == cls.MAGIC
+        except OSError:
+            return False
 
     @property
     def n_minimizers(self):

@@ -1,6 +1,10 @@
 """GPU parity tests (-m gpu): mpn_map_batch (seed-chain-extend + hit bookkeeping + PAF) against the CPU oracle
 oracle/mm2_oracle.c, line by line.  Parity unpinned against a real minimap2 (not vendored by the reference);
 bit-exact against the oracle on coordinates, CIGAR, scores, MAPQ and tags."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -126,3 +130,37 @@ def test_hard_reads_match_oracle(world):
         assert 'zd:i:' in text, 'no split hit in the hard set'
         assert st['dp_rounds'] >= 2 and st['second_pass_jobs'] >= 1, st
     assert text.count('\n') >= len(reads)
+
+
+def test_index_save_load_round_trip(world, tmp_path):
+    """A saved index loaded back (SURVEY 8f1 / minimap2 -d) has the same keys, positions and targets, maps the hard reads
+    (N runs included) to the same PAF, and the `--aligner` drop-in accepts it as the target."""
+    from map_cases import hard_reads
+    from megapath_nano_amd import mapper
+    gen, reads, gidx, _ = world
+    path = tmp_path / 'world.mpi'
+    gidx.save(str(path))
+    assert mapper.Index.is_index_file(str(path))
+    idx2 = mapper.Index.load(str(path))
+    assert idx2.names == gidx.names and list(idx2.lens) == list(gidx.lens) and (idx2.k, idx2.w) == (gidx.k, gidx.w)
+    for a, b in zip(gidx.export(), idx2.export()):
+        assert np.array_equal(a, b)
+    assert idx2.mid_occ() == gidx.mid_occ()
+    hard = hard_reads(gen)
+    opt = mapper.default_opt(best_n=50, pri_ratio=1.0)
+    names, seqs = [r['name'] for r in hard], [r['seq'] for r in hard]
+    assert mapper.map_batch(idx2, opt, names, seqs) == mapper.map_batch(gidx, opt, names, seqs)
+    with pytest.raises(Exception):
+        bad = tmp_path / 'bad.mpi'
+        bad.write_bytes(b'MPNIDX01' + b'\0' * 40)
+        mapper.Index.load(str(bad))
+    # B1: the executable with a saved index as the target
+    fq = tmp_path / 'r.fa'
+    with open(fq, 'w') as f:
+        for r in hard[:4]:
+            f.write(f">{r['name']}\n{bytes(r['seq']).decode()}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bin', 'mpn-aligner'), '-c', '-t', '4', '-I', '1G', '-N', '50', '-p', '1',
+                          '-x', 'map-ont', str(path), str(fq), '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == mapper.map_batch(gidx, opt, names[:4], seqs[:4])
