@@ -164,3 +164,37 @@ def test_index_save_load_round_trip(world, tmp_path):
                           '-x', 'map-ont', str(path), str(fq), '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout == mapper.map_batch(gidx, opt, names[:4], seqs[:4])
+
+
+def test_edge_inputs_match_oracle(world):
+    """Empty and degenerate batches through the C-ABI: no reads, reads shorter than k / shorter than one window, all-N,
+    lower-case and IUPAC bases, duplicated names, a read that is a whole target, reads that map nowhere."""
+    from megapath_nano_amd import mapper
+    from megapath_nano_amd import synth
+    gen, _, gidx, oidx = world
+    from oracle import mm2_bindings as mb
+    opt, oopt = mapper.default_opt(best_n=50, pri_ratio=1.0), mb.default_opt(best_n=50, pri_ratio=1.0)
+    assert mapper.map_batch(gidx, opt, [], []) == ''
+    paf, cols = mapper.map_batch_ex(gidx, opt, mapper.PackedReads([], []), want_paf=True, want_cols=True)
+    assert paf == '' and all(len(v) == 0 for v in cols.values())
+    rng = np.random.default_rng(77)
+    g0 = np.frombuffer(bytes(gen[0][1]), dtype=np.uint8)
+    g1 = np.frombuffer(bytes(gen[1][1]), dtype=np.uint8)
+    seg = g0[20000:26000].copy()
+    iupac = g1[5000:9000].copy()
+    iupac[rng.integers(0, len(iupac), size=60)] = np.frombuffer(b'RYKMSWBDHVN', dtype=np.uint8)[rng.integers(0, 11, size=60)]
+    reads = [
+        ('len1', g0[100:101]), ('len14', g0[100:114]), ('len15', g0[100:115]), ('len24', g0[100:124]), ('len60', g0[100:160]),
+        ('all_n', np.full(500, ord('N'), dtype=np.uint8)), ('lower', np.frombuffer(bytes(seg).lower(), dtype=np.uint8)),
+        ('upper', seg), ('upper', seg),  # the same name twice
+        ('iupac', iupac), ('whole_target', g1), ('nowhere', synth.ALPHA[rng.integers(0, 4, size=7000)]),
+        ('homopolymer', np.full(3000, ord('A'), dtype=np.uint8)),
+    ]
+    rs = [dict(name=n, seq=s) for n, s in reads]
+    got = mapper.map_batch(gidx, opt, [r['name'] for r in rs], [r['seq'] for r in rs])
+    want = ''.join(oracle_paf(oidx, oopt, rs))
+    assert got == want
+    assert 'whole_target\t' in got and 'lower\t' in got and 'nowhere\t' not in got and 'len14\t' not in got
+    # a batch in which nothing maps
+    none = [dict(name=f'x{i}', seq=synth.ALPHA[rng.integers(0, 4, size=900)]) for i in range(5)]
+    assert mapper.map_batch(gidx, opt, [r['name'] for r in none], [r['seq'] for r in none]) == ''.join(oracle_paf(oidx, oopt, none)) == ''
