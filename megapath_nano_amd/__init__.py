@@ -5,6 +5,7 @@ loader, no CPU fallback), and host-side mirrors of the reference's stage interfa
   pyssw.py        <- /root/reference/bin/realignment/pyssw.py       (SSW class)
   aligner.py      <- /root/reference/bin/lib/aligner.py             (Align)
   reassignment.py <- /root/reference/bin/lib/reassignment.py        (Reassign)
+  fastq_filter.py <- /root/reference/bin/tools/nanofastq.c          (read quality / length filter)
 """
 import os as _os
 
