@@ -47,6 +47,9 @@ typedef struct {
     int32_t with_cigar;           /* -c; 0 = mapping_only (aligner.py:188) */
     uint32_t seed;
     int32_t host_threads;         /* threads for the host-side hit bookkeeping; 0 = all cores */
+    int32_t out_sam;              /* -a: the text buffer of mpn_map_batch(_ex) receives SAM records instead of PAF lines
+                                   * (aligner.py:188-192; header lines: mpn_sam_header).  Unmapped reads get a flag-4
+                                   * record; qualities are not carried ('*'). */
 } mpn_map_opt;
 
 /* minimap2 2.17 defaults for `-x map-ont -c` (-N 5 -p 0.8) */
@@ -61,6 +64,8 @@ void mpn_index_destroy(mpn_index *idx);
  * own `-d FILE` / prebuilt-index-as-target is used at bin/megapath_nano.py:1641-1645).  save: 0 or negative error;
  * load: a resident index equal to the one saved (same keys/positions/targets), or NULL + mpn_last_error(). */
 int mpn_index_save(const mpn_index *idx, const char *path);
+/* "@SQ" lines of the targets + one "@PG" line (cmdline may be NULL); returns the text length, or -3 if cap is too small */
+int64_t mpn_sam_header(const mpn_index *idx, const char *cmdline, char *buf, int64_t cap);
 mpn_index *mpn_index_load(const char *path);
 /* names and lengths of the targets of an index (for a loaded one): name i is copied into buf (cap bytes incl. NUL) */
 int32_t mpn_index_n_seq(const mpn_index *idx);

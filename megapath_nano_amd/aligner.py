@@ -8,7 +8,9 @@ file `<paf_path_and_prefix>.paf`.  What differs: no child process.  The `minimap
 target set), reads are mapped in batches through mpn_map_batch_ex (PAF text + integer columns), and no
 awk/SAM2PAF/samtools step exists: the PAF comes out in minimap2's native `-c` tag order directly.
 
-Not produced in this round: `<prefix>.sam` / `.bam` (the reference's `-a` + samtools branch, :225-262).
+With `paf_path_and_prefix` set the reference runs minimap2 with `-a` and keeps `<prefix>.sam` (:183-184,:219-227): so does
+this mirror (second text pass of the same batch with `out_sam`).  Not produced: `<prefix>.bam/.bai` (the reference pipes
+the SAM through samtools, :246-252).
 """
 import gzip
 import hashlib
@@ -214,6 +216,11 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
 
     output_paf = not (paf_path_and_prefix is None or paf_path_and_prefix == '')
     paf_file = open(f'{paf_path_and_prefix}.paf', 'w') if output_paf else None
+    sam_file = open(f'{paf_path_and_prefix}.sam', 'w') if output_paf and not mapping_only else None
+    if sam_file is not None:
+        sam_file.write(idx.sam_header())
+        sam_opt = mapper.MapOpt.from_buffer_copy(bytes(opt))
+        sam_opt.out_sam = 1
     frames = []
     try:
         for query in query_filename_list['path']:
@@ -228,6 +235,8 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
                 paf, c = mapper.map_batch_ex(idx, opt, packed, want_paf=output_paf, want_cols=True)
                 if paf_file is not None:
                     paf_file.write(paf)
+                if sam_file is not None:
+                    sam_file.write(mapper.map_batch_ex(idx, sam_opt, packed, want_paf=True, want_cols=False)[0])
                 names = np.array(packed.names, dtype=object)
                 frames.append(pandas.DataFrame({
                     'read_id': names[c['read_idx']], 'read_length': packed.lens[c['read_idx']].astype(np.int64),
@@ -241,6 +250,8 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
     finally:
         if paf_file is not None:
             paf_file.close()
+        if sam_file is not None:
+            sam_file.close()
     if frames:
         prefilter_align_list = pandas.concat(frames, ignore_index=True)[list(list_col)]
     else:

@@ -762,6 +762,94 @@ static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *nam
     }
 }
 
+// SAM records of one read (minimap2 2.17 -a: mm_write_sam3 / write_sam_cigar / sam_write_sq for single-segment reads
+// without read group; qualities are not carried).  A read without hits gets a flag-4 record.
+static char sam_comp(char c) {
+    static const char from[] = "ACGTUNRYKMSWBDHVacgtunrykmswbdhv", to[] = "TGCAANYRMKSWVHDBtgcaanyrmkswvhdb";
+    const char *p = c ? strchr(from, c) : nullptr;
+    return p ? to[p - from] : c;
+}
+
+static void sam_seq(std::string &out, const char *seq, int st, int en, bool rev) {
+    if (!rev) out.append(seq + st, (size_t)(en - st));
+    else for (int i = en - 1; i >= st; --i) out += sam_comp(seq[i]);
+}
+
+static void write_sam(const mpn_index *mi, const char *name, int32_t qlen, const char *seq, const std::vector<Reg> &regs,
+                      int32_t rep_len, std::string &out) {
+    char buf[1024];
+    if (regs.empty()) {
+        out += name;
+        out += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
+        sam_seq(out, seq, 0, qlen, false);
+        snprintf(buf, sizeof(buf), "\t*\trl:i:%d\n", rep_len);
+        out += buf;
+        return;
+    }
+    for (size_t i = 0; i < regs.size(); ++i) {
+        const Reg &r = regs[i];
+        const int type = r.id == r.parent ? (r.inv ? 'I' : 'P') : (r.inv ? 'i' : 'S');
+        int flag = r.rev ? 0x10 : 0;
+        if (r.parent != r.id) flag |= 0x100;
+        else if (!r.sam_pri) flag |= 0x800;
+        out += name;
+        snprintf(buf, sizeof(buf), "\t%d\t", flag);
+        out += buf;
+        out += mi->names[r.rid];
+        snprintf(buf, sizeof(buf), "\t%d\t%d\t", r.rs + 1, r.mapq);
+        out += buf;
+        if (!r.has_p) out += '*';
+        else {
+            const int clip0 = r.rev ? qlen - r.qe : r.qs, clip1 = r.rev ? r.qs : qlen - r.qe;
+            const char clip_char = (flag & 0x800) ? 'H' : 'S';
+            if (clip0) { snprintf(buf, sizeof(buf), "%d%c", clip0, clip_char); out += buf; }
+            for (uint32_t c : r.cigar) { snprintf(buf, sizeof(buf), "%d%c", c >> 4, "MIDNSH"[c & 0xf]); out += buf; }
+            if (clip1) { snprintf(buf, sizeof(buf), "%d%c", clip1, clip_char); out += buf; }
+        }
+        out += "\t*\t0\t0\t";
+        if ((flag & 0x900) == 0) { sam_seq(out, seq, 0, qlen, r.rev); out += "\t*"; }
+        else if (flag & 0x100) out += "*\t*";
+        else { sam_seq(out, seq, r.qs, r.qe, r.rev); out += "\t*"; }
+        if (r.has_p) {
+            snprintf(buf, sizeof(buf), "\tNM:i:%d\tms:i:%d\tAS:i:%d\tnn:i:%d", r.blen - r.mlen + r.n_ambi, r.dp_max, r.dp_score, r.n_ambi);
+            out += buf;
+        }
+        snprintf(buf, sizeof(buf), "\ttp:A:%c\tcm:i:%d\ts1:i:%d", type, r.cnt, r.score);
+        out += buf;
+        if (r.parent == r.id) { snprintf(buf, sizeof(buf), "\ts2:i:%d", r.subsc); out += buf; }
+        if (r.has_p) {
+            const double div = 1.0 - event_identity(r);
+            if (div == 0.0) out += "\tde:f:0";
+            else { snprintf(buf, sizeof(buf), "\tde:f:%.4f", div); out += buf; }
+        }
+        if (r.split) { snprintf(buf, sizeof(buf), "\tzd:i:%d", r.split); out += buf; }
+        if (r.parent == r.id && r.has_p && regs.size() > 1) {  // SA: the other non-secondary hits that have a CIGAR
+            bool any = false;
+            for (size_t j = 0; j < regs.size(); ++j) {
+                const Reg &q = regs[j];
+                if (j == i || q.parent != q.id || !q.has_p) continue;
+                if (!any) { out += "\tSA:Z:"; any = true; }
+                int l_M, l_I = 0, l_D = 0;
+                if (q.qe - q.qs < q.re - q.rs) { l_M = q.qe - q.qs; l_D = (q.re - q.rs) - l_M; }
+                else { l_M = q.re - q.rs; l_I = (q.qe - q.qs) - l_M; }
+                const int c5 = q.rev ? qlen - q.qe : q.qs, c3 = q.rev ? q.qs : qlen - q.qe;
+                out += mi->names[q.rid];
+                snprintf(buf, sizeof(buf), ",%d,%c,", q.rs + 1, "+-"[q.rev]);
+                out += buf;
+                if (c5) { snprintf(buf, sizeof(buf), "%dS", c5); out += buf; }
+                if (l_M) { snprintf(buf, sizeof(buf), "%dM", l_M); out += buf; }
+                if (l_I) { snprintf(buf, sizeof(buf), "%dI", l_I); out += buf; }
+                if (l_D) { snprintf(buf, sizeof(buf), "%dD", l_D); out += buf; }
+                if (c3) { snprintf(buf, sizeof(buf), "%dS", c3); out += buf; }
+                snprintf(buf, sizeof(buf), ",%d,%d;", q.mapq, q.blen - q.mlen + q.n_ambi);
+                out += buf;
+            }
+        }
+        snprintf(buf, sizeof(buf), "\trl:i:%d\n", rep_len);
+        out += buf;
+    }
+}
+
 // per-worker resources: a stream, a device arena, grow-only scratch pools and pinned staging buffers
 struct Slot {
     hipStream_t st = nullptr;
@@ -1246,17 +1334,22 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     std::atomic<int64_t> n_aln(0);
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
-        if (S.regs.empty()) return;
         const int qlen = seq_len[i];
-        if (opt->with_cigar) {
-            filter_regs(opt, qlen, S.regs);
-            hit_sort(S.regs);
-            set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
-            select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
-            set_sam_pri(S.regs);
+        const char *nm = names && names[lo + i] ? names[lo + i] : "*";
+        if (!S.regs.empty()) {
+            if (opt->with_cigar) {
+                filter_regs(opt, qlen, S.regs);
+                hit_sort(S.regs);
+                set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
+                select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
+                set_sam_pri(S.regs);
+            }
+            set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
         }
-        set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
-        if (want_paf) write_paf(idx, opt, names && names[lo + i] ? names[lo + i] : "*", qlen, S.regs, h.rep_len[i], lines_all[lo + i]);
+        if (want_paf) {
+            if (opt->out_sam) write_sam(idx, nm, qlen, seqs + seq_off[i], S.regs, h.rep_len[i], lines_all[lo + i]);
+            else if (!S.regs.empty()) write_paf(idx, opt, nm, qlen, S.regs, h.rep_len[i], lines_all[lo + i]);
+        }
         n_aln += (int64_t)S.regs.size();
         // the per-read scratch is no longer needed
         std::vector<u128>().swap(S.a);
@@ -1428,6 +1521,23 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     whole.stop_into(g_stats[24]);
     if (dbg_workers) fprintf(stderr, "[call] done at %.1f ms\n", since());
     return w;
+}
+
+extern "C" int64_t mpn_sam_header(const mpn_index *idx, const char *cmdline, char *buf, int64_t cap) {
+    std::string h;
+    char line[64];
+    for (int i = 0; i < idx->n_seq; ++i) {
+        h += "@SQ\tSN:"; h += idx->names[(size_t)i];
+        snprintf(line, sizeof(line), "\tLN:%d\n", idx->lens[(size_t)i]);
+        h += line;
+    }
+    h += "@PG\tID:mpn-aligner\tPN:mpn-aligner\tVN:r01";
+    if (cmdline && cmdline[0]) { h += "\tCL:"; h += cmdline; }
+    h += '\n';
+    if ((int64_t)h.size() + 1 > cap) return -3;
+    memcpy(buf, h.data(), h.size());
+    buf[h.size()] = 0;
+    return (int64_t)h.size();
 }
 
 extern "C" int64_t mpn_map_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,

@@ -17,7 +17,7 @@ class MapOpt(ct.Structure):
                 ('e2', ct.c_int32), ('sc_ambi', ct.c_int32), ('zdrop', ct.c_int32), ('zdrop_inv', ct.c_int32),
                 ('end_bonus', ct.c_int32), ('min_dp_max', ct.c_int32), ('min_ksw_len', ct.c_int32),
                 ('max_clip_ratio', ct.c_float), ('max_sw_mat', ct.c_int64), ('with_cigar', ct.c_int32),
-                ('seed', ct.c_uint32), ('host_threads', ct.c_int32)]
+                ('seed', ct.c_uint32), ('host_threads', ct.c_int32), ('out_sam', ct.c_int32)]
 
 
 COL_NAMES = ('read_idx', 'qs', 'qe', 'rev', 'rid', 'rs', 're', 'mlen', 'blen', 'mapq', 'nm', 'as_', 'primary')
@@ -49,6 +49,8 @@ def _bind():
         lib.mpn_index_mid_occ.restype = ct.c_int32
         lib.mpn_index_export.argtypes = [P, P, P, P]
         lib.mpn_index_export.restype = ct.c_int
+        lib.mpn_sam_header.argtypes = [P, ct.c_char_p, ct.c_char_p, ct.c_int64]
+        lib.mpn_sam_header.restype = ct.c_int64
         lib.mpn_index_save.argtypes = [P, ct.c_char_p]
         lib.mpn_index_save.restype = ct.c_int
         lib.mpn_index_load.argtypes = [ct.c_char_p]
@@ -117,6 +119,14 @@ class Index:
         self.h = lib.mpn_index_build(n, names, seqs, self.lens.ctypes.data, k, w)
         if not self.h:
             raise _ffi.MpnError('mpn_index_build failed: ' + _ffi.last_error())
+
+    def sam_header(self, cmdline=None):
+        cap = 64 * len(self.names) + sum(len(n) for n in self.names) + 4096 + (len(cmdline) if cmdline else 0)
+        buf = ct.create_string_buffer(cap)
+        r = _bind().mpn_sam_header(self.h, cmdline.encode() if cmdline else None, buf, cap)
+        if r < 0:
+            raise _ffi.MpnError(f'mpn_sam_header rc={r}')
+        return buf.raw[:r].decode()
 
     def save(self, path):
         """Persistent form (minimap2 `-d FILE`): load() gives back an index that maps identically."""
@@ -224,7 +234,7 @@ def map_batch(idx, opt, names, seqs):
     buf, off, lens = pack_seqs(seqs)
     n = len(seqs)
     cnames = (ct.c_char_p * n)(*[x.encode() for x in names])
-    cap = int(lens.astype(np.int64).sum()) * 4 + 4096 * n + 4096
+    cap = int(lens.astype(np.int64).sum()) * (6 if opt.out_sam else 4) + 4096 * n + 4096
     while True:
         out = ct.create_string_buffer(cap)
         r = lib.mpn_map_batch(idx.h, ct.byref(opt), n, cnames, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, out, cap)
@@ -258,7 +268,7 @@ def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True):
     lib = _bind()
     n = packed.n
     d = [0, 0, 0] if packed.dev is None else [t.data_ptr() for t in packed.dev]
-    paf_cap = packed.bases * 4 + 4096 * n + 4096 if want_paf else 0
+    paf_cap = packed.bases * (6 if opt.out_sam else 4) + 4096 * n + 4096 if want_paf else 0
     rows_cap = max(64, n * 4)
     while True:
         out = ct.create_string_buffer(paf_cap) if want_paf else None

@@ -64,6 +64,9 @@ def lib():
         L.mmo_write_paf.argtypes = [ct.c_void_p, ct.POINTER(Opt), ct.c_char_p, ct.c_int32, ct.POINTER(Reg), ct.c_int32,
                                     ct.c_int32, ct.c_char_p, ct.c_int64]
         L.mmo_write_paf.restype = ct.c_int64
+        L.mmo_write_sam.argtypes = [ct.c_void_p, ct.POINTER(Opt), ct.c_char_p, ct.c_int32, ct.c_char_p, ct.POINTER(Reg), ct.c_int32,
+                                    ct.c_int32, ct.c_char_p, ct.c_int64]
+        L.mmo_write_sam.restype = ct.c_int64
         L.mmo_extd2.argtypes = [ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int8, ct.c_int8, ct.c_int8, ct.c_int8,
                                 ct.c_int8, ct.c_int8, ct.c_int8, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(Ez)]
         _lib = L
@@ -135,6 +138,22 @@ def chain(opt, a):
     uu = np.ctypeslib.as_array(ct.cast(u, ct.POINTER(ct.c_uint64)), shape=(n_u.value,)).copy()
     lib().mmo_free(u)
     return uu, _take128(b, n_b)
+
+
+def map_read_sam(idx, opt, name, seq):
+    """-> SAM records of one read (minimap2 -a), unmapped reads included"""
+    L = lib()
+    seq = bytes(seq)
+    n = ct.c_int32()
+    rep = ct.c_int32()
+    regs = L.mmo_map_read(idx.h, ct.byref(opt), name.encode(), seq, len(seq), ct.byref(n), ct.byref(rep))
+    cap = (4096 + len(seq)) * max(n.value, 1) + sum(regs[i].n_cigar for i in range(n.value)) * 12 + 4096
+    buf = ct.create_string_buffer(cap)
+    nb = L.mmo_write_sam(idx.h, ct.byref(opt), name.encode(), len(seq), seq, regs, n.value, rep.value, buf, cap)
+    assert nb >= 0
+    if n.value > 0:
+        L.mmo_free_regs(regs, n.value)
+    return buf.raw[:nb].decode()
 
 
 def map_read(idx, opt, name, seq):

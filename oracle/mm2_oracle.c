@@ -1439,3 +1439,94 @@ int64_t mmo_write_paf(const mmo_idx *mi, const mmo_opt *o, const char *name, int
     buf[n] = 0;
     return n;
 }
+
+
+/* ---- SAM records (minimap2 2.17 -a: format.c mm_write_sam3 / write_sam_cigar / sam_write_sq), single-segment reads,
+ * no read group, qualities not carried ('*').  Unmapped reads get a flag-4 record. ---- */
+static char sam_comp(char c)
+{
+    static const char *from = "ACGTUNRYKMSWBDHVacgtunrykmswbdhv", *to = "TGCAANYRMKSWVHDBtgcaanyrmkswvhdb";
+    const char *p = strchr(from, c);
+    return p && c ? to[p - from] : c;
+}
+
+static int64_t sam_seq(char *buf, const char *seq, int32_t st, int32_t en, int rev)
+{
+    int32_t i, n = 0;
+    if (!rev) for (i = st; i < en; ++i) buf[n++] = seq[i];
+    else for (i = en - 1; i >= st; --i) buf[n++] = sam_comp(seq[i]);
+    return n;
+}
+
+int64_t mmo_write_sam(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const char *seq, const mmo_reg *regs,
+                      int32_t n_regs, int32_t rep_len, char *buf, int64_t cap)
+{
+    int64_t n = 0;
+    int32_t i, j, k;
+    (void)o;
+    if (n_regs == 0) {
+        if ((int64_t)strlen(name) + qlen + 64 > cap) return -1;
+        n += sprintf(buf + n, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t", name);
+        n += sam_seq(buf + n, seq, 0, qlen, 0);
+        n += sprintf(buf + n, "\t*\trl:i:%d\n", rep_len);
+        buf[n] = 0;
+        return n;
+    }
+    for (i = 0; i < n_regs; ++i) {
+        const mmo_reg *r = &regs[i];
+        int flag = 0, type = r->id == r->parent ? (r->inv ? 'I' : 'P') : (r->inv ? 'i' : 'S');
+        int64_t need = 1024 + (int64_t)strlen(name) + (int64_t)strlen(mi->name[r->rid]) + (int64_t)r->n_cigar * 12 + qlen + (int64_t)n_regs * 128;
+        if (n + need > cap) return -1;
+        if (r->rev) flag |= 0x10;
+        if (r->parent != r->id) flag |= 0x100;
+        else if (!r->sam_pri) flag |= 0x800;
+        n += sprintf(buf + n, "%s\t%d\t%s\t%d\t%d\t", name, flag, mi->name[r->rid], r->rs + 1, r->mapq);
+        if (!r->has_p) buf[n++] = '*';
+        else {
+            int32_t clip0 = r->rev ? qlen - r->qe : r->qs, clip1 = r->rev ? r->qs : qlen - r->qe;
+            int clip_char = (flag & 0x800) ? 'H' : 'S';
+            if (clip0) n += sprintf(buf + n, "%d%c", clip0, clip_char);
+            for (k = 0; k < r->n_cigar; ++k) n += sprintf(buf + n, "%d%c", r->cigar[k] >> 4, "MIDNSH"[r->cigar[k] & 0xf]);
+            if (clip1) n += sprintf(buf + n, "%d%c", clip1, clip_char);
+        }
+        n += sprintf(buf + n, "\t*\t0\t0\t");
+        if ((flag & 0x900) == 0) { n += sam_seq(buf + n, seq, 0, qlen, r->rev); n += sprintf(buf + n, "\t*"); }
+        else if (flag & 0x100) n += sprintf(buf + n, "*\t*");
+        else { n += sam_seq(buf + n, seq, r->qs, r->qe, r->rev); n += sprintf(buf + n, "\t*"); }
+        if (r->has_p)
+            n += sprintf(buf + n, "\tNM:i:%d\tms:i:%d\tAS:i:%d\tnn:i:%d", r->blen - r->mlen + r->n_ambi, r->dp_max, r->dp_score, r->n_ambi);
+        n += sprintf(buf + n, "\ttp:A:%c\tcm:i:%d\ts1:i:%d", type, r->cnt, r->score);
+        if (r->parent == r->id) n += sprintf(buf + n, "\ts2:i:%d", r->subsc);
+        if (r->has_p) {
+            double div = 1.0 - event_identity(r);
+            if (div == 0.0) n += sprintf(buf + n, "\tde:f:0");
+            else n += sprintf(buf + n, "\tde:f:%.4f", div);
+        }
+        if (r->split) n += sprintf(buf + n, "\tzd:i:%d", r->split);
+        if (r->parent == r->id && r->has_p && n_regs > 1) {  /* SA: the other non-secondary hits with a CIGAR */
+            int n_sa = 0;
+            for (j = 0; j < n_regs; ++j) if (j != i && regs[j].parent == regs[j].id && regs[j].has_p) ++n_sa;
+            if (n_sa > 0) {
+                n += sprintf(buf + n, "\tSA:Z:");
+                for (j = 0; j < n_regs; ++j) {
+                    const mmo_reg *q = &regs[j];
+                    int32_t l_M, l_I = 0, l_D = 0, c5, c3;
+                    if (j == i || q->parent != q->id || !q->has_p) continue;
+                    if (q->qe - q->qs < q->re - q->rs) { l_M = q->qe - q->qs; l_D = (q->re - q->rs) - l_M; }
+                    else { l_M = q->re - q->rs; l_I = (q->qe - q->qs) - l_M; }
+                    c5 = q->rev ? qlen - q->qe : q->qs; c3 = q->rev ? q->qs : qlen - q->qe;
+                    n += sprintf(buf + n, "%s,%d,%c,", mi->name[q->rid], q->rs + 1, "+-"[q->rev]);
+                    if (c5) n += sprintf(buf + n, "%dS", c5);
+                    if (l_M) n += sprintf(buf + n, "%dM", l_M);
+                    if (l_I) n += sprintf(buf + n, "%dI", l_I);
+                    if (l_D) n += sprintf(buf + n, "%dD", l_D);
+                    if (c3) n += sprintf(buf + n, "%dS", c3);
+                    n += sprintf(buf + n, ",%d,%d;", q->mapq, q->blen - q->mlen + q->n_ambi);
+                }
+            }
+        }
+        n += sprintf(buf + n, "\trl:i:%d\n", rep_len);
+    }
+    buf[n] = 0;
+    return n;
+}

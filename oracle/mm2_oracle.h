@@ -84,6 +84,9 @@ void mmo_free_regs(mmo_reg *r, int32_t n);
 /* PAF line(s) for one read into buf (NUL terminated); returns bytes written (excluding NUL) or -1 if cap too small */
 int64_t mmo_write_paf(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const mmo_reg *regs,
                       int32_t n_regs, int32_t rep_len, char *buf, int64_t cap);
+/* SAM records of one read (-a), incl. the flag-4 record of an unmapped read; same buffer contract as mmo_write_paf */
+int64_t mmo_write_sam(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const char *seq, const mmo_reg *regs,
+                      int32_t n_regs, int32_t rep_len, char *buf, int64_t cap);
 
 /* standalone banded dual-affine extension (ksw2-style, difference recurrences on anti-diagonals) */
 typedef struct {

@@ -91,6 +91,11 @@ def test_align_mirror_schema_join_and_tiebreak(files):
     # side file: PAF text identical to the oracle's
     paf = open(d / 'out.species.paf').read()
     assert paf == ''.join(mb.map_read(oidx, oopt, r['name'], r['seq'])[2] for r in reads)
+    # ... and <prefix>.sam (the reference's -a run, aligner.py:183-184,219-227): header + the oracle's records
+    sam = open(d / 'out.species.sam').read().splitlines(keepends=True)
+    hdr = [l for l in sam if l.startswith('@')]
+    assert len(hdr) == len(target) + 1 and hdr[-1].startswith('@PG')
+    assert ''.join(sam[len(hdr):]) == ''.join(mb.map_read_sam(oidx, oopt, r['name'], r['seq']) for r in reads)
     oidx.close()
 
 

@@ -198,3 +198,43 @@ def test_edge_inputs_match_oracle(world):
     # a batch in which nothing maps
     none = [dict(name=f'x{i}', seq=synth.ALPHA[rng.integers(0, 4, size=900)]) for i in range(5)]
     assert mapper.map_batch(gidx, opt, [r['name'] for r in none], [r['seq'] for r in none]) == ''.join(oracle_paf(oidx, oopt, none)) == ''
+
+
+def test_sam_output_matches_oracle(world):
+    """-a: SAM records (flags, soft/hard clips, SEQ on the hit's strand, '*' for secondaries, SA tags, flag-4 records for
+    unmapped reads) against the oracle's restatement of minimap2's writer; the header lists every target."""
+    from map_cases import hard_reads
+    from megapath_nano_amd import mapper, synth
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    rng = np.random.default_rng(4)
+    extra = [dict(name='nowhere', seq=synth.ALPHA[rng.integers(0, 4, size=3000)]), dict(name='tiny', seq=synth.ALPHA[rng.integers(0, 4, size=9)])]
+    rs = list(reads[:25]) + hard_reads(gen) + extra
+    names, seqs = [r['name'] for r in rs], [r['seq'] for r in rs]
+    for best_n, pri in ((5, 0.8), (50, 1.0)):
+        gopt = mapper.default_opt(best_n=best_n, pri_ratio=pri, out_sam=1)
+        oopt = mb.default_opt(best_n=best_n, pri_ratio=pri)
+        got = mapper.map_batch(gidx, gopt, names, seqs)
+        want = ''.join(mb.map_read_sam(oidx, oopt, r['name'], r['seq']) for r in rs)
+        assert got == want
+    # a world with a 99 %-identity strain copy: secondary records (flag 0x100, SEQ '*')
+    gen2 = synth.make_genomes(5, 4, 60000, strain_pairs=1)
+    reads2 = synth.make_reads(6, gen2, 12, mean_len=2000)
+    gidx2, oidx2 = mapper.Index(gen2), mb.Index(gen2)
+    got2 = mapper.map_batch(gidx2, mapper.default_opt(best_n=50, pri_ratio=1.0, out_sam=1), [r['name'] for r in reads2], [r['seq'] for r in reads2])
+    assert got2 == ''.join(mb.map_read_sam(oidx2, mb.default_opt(best_n=50, pri_ratio=1.0), r['name'], r['seq']) for r in reads2)
+    gidx2.close()
+    oidx2.close()
+    lines = got.splitlines() + got2.splitlines()
+    flags = [int(l.split('\t')[1]) for l in lines]
+    assert any(f & 0x800 for f in flags) and any(f & 0x100 for f in flags) and any(f & 0x10 for f in flags) and flags.count(4) >= 2
+    assert all(l.split('\t')[9] == '*' for l, f in zip(lines, flags) if f & 0x100)
+    assert any('\tSA:Z:' in l for l in lines)
+    for l in lines:
+        f = l.split('\t')
+        if f[5] != '*' and f[9] != '*':   # CIGAR query length == SEQ length (hard clips excluded)
+            import re
+            qlen = sum(int(n) for n, op in re.findall(r'(\d+)([MIDNSH])', f[5]) if op in 'MIS')
+            assert qlen == len(f[9]), f[0]
+    hdr = gidx.sam_header('mpn-aligner -a test')
+    assert hdr.count('@SQ\t') == len(gen) and hdr.splitlines()[-1].startswith('@PG\tID:mpn-aligner') and f'SN:{gen[0][0]}\tLN:{len(gen[0][1])}' in hdr
