@@ -828,6 +828,14 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     const ExtJob jb = jobs[jid];
     if (!(jb.flag & EZ_APPROX_MAX)) return;  // only gap fills are tested
     const ExtRes r = res[jid];
+    // No walk needed when a drop of more than zdrop is impossible: prefix scores satisfy S(i) <= a * (matches up to i)
+    // and S(j) >= F - a * (matches after j), so S(i) - S(j) <= a * min(qlen, tlen) - F for the window's final score F.
+    // (Only for the strip kernel, whose corner score is exact.)
+    if (jb.layout == 1 && r.do_bt && !r.zdropped &&
+        (int64_t)prm.sc_mch * (jb.qlen < jb.tlen ? jb.qlen : jb.tlen) - r.score <= prm.zdrop_thres) {
+        res[jid].zcode = 0;
+        return;
+    }
     const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
     const int64_t roff = read_off[jb.read];
     const int32_t rlen = read_len[jb.read];
