@@ -885,7 +885,9 @@ __global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const in
 }
 
 // launch lists: every DP job of a group belongs to exactly one
-enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 4, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
+// (strip lists: lane-group class (16/32/64 lanes per window) x strip height 1..16; each is padded to whole waves)
+enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 48, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
+static inline int strip_windows_per_wave(int l) { return 4 >> ((l - L_STRIP) / 16); }
 
 // Run one group of DP jobs on the GPU (its scratch fits the budget).  jobs[0..nj) are completed in place (scratch
 // offsets, layout); results and CIGAR ops stay in the worker's pinned buffers: *res_out / *cig_out are valid until the
@@ -898,7 +900,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     WallTimer wt;
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     struct Acc {
-        size_t lds_need[5] = {0, 0, 0, 0, 0}, strip_lds[N_STRIP] = {0}, band_lds[4] = {64, 64, 64, 64};
+        size_t lds_need[5] = {0, 0, 0, 0, 0}, strip_lds[3] = {0, 0, 0}, band_lds[4] = {64, 64, 64, 64};
         int64_t cells = 0, strip_cells = 0;
         int too_large = 0, tl_q = 0, tl_t = 0;
     };
@@ -918,8 +920,15 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             n_col = std::min(n_col, w + 1) + 1;
             jb.n_col = n_col;
             const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
-            const bool strip = (jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && jb.tlen <= 1024 && jb.qlen <= 60000 &&
-                               w >= std::max(jb.qlen, jb.tlen) && strip_scores && (g_force_kernel == 0 || g_force_kernel == 4);
+            // strip kernel: lane-group class by target rows (16 x 16, 32 x 16, 64 x 16) and by what the queries of one wave may
+            // take in LDS (1024 / 2048 / 4096 bases per window)
+            int glc = -1;
+            if ((jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed && w >= std::max(jb.qlen, jb.tlen) &&
+                strip_scores && (g_force_kernel == 0 || g_force_kernel == 4)) {
+                for (int c = 0; c < 3 && glc < 0; ++c)
+                    if (jb.tlen <= (256 << c) && jb.qlen <= (1024 << c)) glc = c;
+            }
+            const bool strip = glc >= 0;
             const size_t seqb = (size_t)((jb.qlen + 3) & ~3) + (size_t)((jb.tlen + 3) & ~3);
             // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
             int bv = n_col <= 128 ? 0 : n_col <= 256 ? 1 : n_col <= 512 ? 2 : n_col <= 1024 ? 3 : -1;
@@ -929,7 +938,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             band_v[j] = (int8_t)bv; band_c[j] = (int8_t)bc;
             if (bv >= 0) A.band_lds[bc] = std::max(A.band_lds[bc], seqb);
             jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
-            jb.strip_s = std::max(1, std::min(16, (jb.tlen + 63) / 64));  // strip height: the window's rows over all 64 lanes
+            const int strip_gl = 16 << std::max(glc, 0);
+            jb.strip_s = std::max(1, std::min(16, (jb.tlen + strip_gl - 1) / strip_gl));  // strip height: the window's rows over its lane group
             const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
             jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << std::max(bv, 0);  // row width of the direction matrix (layouts 1, 2)
             const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
@@ -946,7 +956,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             const bool use_wg = g_force_kernel == 3 || (g_force_kernel != 1 && n_col - 1 > 128);
             const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
             redo_list[j] = (int8_t)(bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls);
-            if (strip) { const int rc = (jb.strip_s - 1) / 4; lid = L_STRIP + rc; A.strip_lds[rc] = std::max(A.strip_lds[rc], (size_t)((jb.qlen + 15) & ~15)); }
+            if (strip) { lid = L_STRIP + glc * 16 + jb.strip_s - 1; A.strip_lds[glc] = std::max(A.strip_lds[glc], (size_t)((jb.qlen + 15) & ~15)); }
             else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
             else lid = redo_list[j];
             if (bv < 0) {  // the LDS-state kernels may run this window (now or in the second pass)
@@ -962,7 +972,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     Acc M;
     for (const Acc &A : accs) {
         for (int c = 0; c < 5; ++c) M.lds_need[c] = std::max(M.lds_need[c], A.lds_need[c]);
-        for (int c = 0; c < N_STRIP; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
+        for (int c = 0; c < 3; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
         for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
         M.cells += A.cells; M.strip_cells += A.strip_cells;
         if (A.too_large) { set_error("DP window too large for LDS staging (%d x %d)", A.tl_q, A.tl_t); return -4; }
@@ -979,15 +989,22 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         jb.state_off = state_tot; state_tot += st_bytes[j];
         ++cnt[(int)list_id[j]];
     }
+    // strip lists are padded to whole waves (entries of -1), so that the strip height is uniform per wave
     base[0] = 0;
-    for (int l = 0; l < N_LISTS; ++l) base[l + 1] = base[l] + cnt[l];
+    for (int l = 0; l < N_LISTS; ++l) {
+        int c = cnt[l];
+        if (l >= L_STRIP && l < L_BAND) { const int per = strip_windows_per_wave(l); c = (c + per - 1) / per * per; }
+        base[l + 1] = base[l] + c;
+    }
+    const int n_flat = base[N_LISTS];
     g_stats[4] += nj; g_stats[5] += M.cells; g_stats[31] += M.strip_cells;
     Slot &SL = *tl_slot;
-    if (SL.pin_order.ensure((size_t)nj * 4 + 16) || SL.pin_jobs.ensure((size_t)nj * sizeof(ExtJob))) return -1;
+    if (SL.pin_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_jobs.ensure((size_t)nj * sizeof(ExtJob))) return -1;
     int32_t *flat = SL.pin_order.as<int32_t>();
     {
         int cur[N_LISTS];
         memcpy(cur, base, sizeof(cur));
+        for (int l = L_STRIP; l < L_BAND; ++l) for (int k = base[l] + cnt[l]; k < base[l + 1]; ++k) flat[k] = -1;
         for (int j = 0; j < nj; ++j) flat[cur[(int)list_id[j]]++] = j;
     }
     if (getenv("MPN_DEBUG_JOBS")) {
@@ -995,7 +1012,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         for (int l = 0; l < N_LISTS; ++l) {
             if (!cnt[l]) continue;
             int64_t c = 0, mx = 0, ext = 0;
-            for (int k = base[l]; k < base[l + 1]; ++k) {
+            for (int k = base[l]; k < base[l] + cnt[l]; ++k) {
                 const ExtJob &jb = jobs[flat[k]];
                 const int64_t z = ((int64_t)jb.qlen + jb.tlen - 1) * jb.n_col;
                 c += z; mx = std::max(mx, z); ext += (jb.flag & EZ_EXTZ_ONLY) != 0;
@@ -1006,7 +1023,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     }
     if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || SL.pool_P.ensure((size_t)p_tot) || SL.pool_OFF.ensure((size_t)row_tot * 2 * 4 + 16) ||
         SL.pool_state.ensure((size_t)state_tot + 16) || SL.pool_CIG.ensure((size_t)cig_tot * 4) || SL.pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
-        SL.pool_order.ensure((size_t)nj * 4) || SL.pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || SL.pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
+        SL.pool_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || SL.pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
         SL.pool_used.ensure(16))
         return -1;
     // the H2D copies leave from pinned memory, so they are truly asynchronous
@@ -1023,7 +1040,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     unsigned long long *d_used = SL.pool_used.as<unsigned long long>();
     MPN_HIP_CHECK(hipMemsetAsync(d_used, 0, 16, st));
     MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, SL.pin_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(d_order.p, flat, (size_t)nj * 4, hipMemcpyHostToDevice, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(d_order.p, flat, (size_t)n_flat * 4, hipMemcpyHostToDevice, st));
     ExtParams prm;
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
@@ -1046,11 +1063,13 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             } while (0)
             if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
 #undef MPN_WG_LAUNCH
-        } else if (l < L_BAND) {
-            const size_t lds = std::max<size_t>(M.strip_lds[l - L_STRIP], 64);
-#define MPN_STRIP_LAUNCH(GG) case GG: hipLaunchKernelGGL(ext_dp_strip_kernel<GG>, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p); break
-            switch (l - L_STRIP) { MPN_STRIP_LAUNCH(0); MPN_STRIP_LAUNCH(1); MPN_STRIP_LAUNCH(2); MPN_STRIP_LAUNCH(3); }
-#undef MPN_STRIP_LAUNCH
+        } else if (l < L_BAND) {  // called once per lane-group class with the class's whole (padded) range: l = first list of the class
+            const int glc = (l - L_STRIP) / 16, per = 4 >> glc;
+            const int stride = (int)std::max<size_t>(M.strip_lds[glc], 16);
+            const size_t lds = (size_t)stride * per;
+            if (glc == 0) hipLaunchKernelGGL(ext_dp_strip_kernel<16>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
+            else if (glc == 1) hipLaunchKernelGGL(ext_dp_strip_kernel<32>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
+            else hipLaunchKernelGGL(ext_dp_strip_kernel<64>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
         } else {
             const int bvar = (l - L_BAND) / 4;
             const size_t lds = M.band_lds[(l - L_BAND) % 4];
@@ -1082,16 +1101,18 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     for (int l = N_LISTS - 1; l >= 0; --l) {  // wide before narrow, strips (the bulk) in the middle
         if (on_side(l)) continue;
         if (l == L_BAND - 1) ev.mark(15);  // the strip launches are timed on their own ([9]): the roofline kernel of bench.py
-        if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
+        if (l >= L_STRIP && l < L_BAND) {  // one launch per lane-group class: its 16 height lists are contiguous
+            if ((l - L_STRIP) % 16 == 0 && launch_list(l, d_order.p + base[l], base[l + 16] - base[l], st)) return -1;
+        } else if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
         if (l == L_STRIP) ev.mark(9);
     }
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
     ev.mark(15);
-    hipLaunchKernelGGL(ext_bt_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
+    hipLaunchKernelGGL(ext_bt_kernel, dim3((n_flat + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, n_flat, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(25);
     // z-drop test of the gap-fill CIGARs (the kernel skips the other windows); flagged ones are recomputed with the exact maximum
-    hipLaunchKernelGGL(ext_ztest_kernel, dim3((nj + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, nj, prm, d_reads, d_read_off, d_read_len,
+    hipLaunchKernelGGL(ext_ztest_kernel, dim3((n_flat + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, n_flat, prm, d_reads, d_read_off, d_read_len,
                        rv, CIG.p, d_res.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(26);

@@ -603,8 +603,8 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
     if (tid == 0) res[jid] = out;
 }
 
-// Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 64*S, gaps
-// left-aligned; S = ceil(tlen / 64) = 1..16, so that the rows of a window spread over (almost) all 64 lanes): lane l owns the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l,
+// Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 1024, gaps
+// left-aligned).  A window runs on a group of GL = 16, 32 or 64 lanes (see ext_dp_strip_kernel below): lane l owns the S consecutive target rows t = l*S .. l*S+S-1 and walks the query columns j = step - l,
 // so after a ramp of n_lanes-1 steps every lane computes S cells per step -- no partially filled anti-diagonal tiles.
 // The left neighbour (t, j-1) of a cell is the lane's own previous step (u, y, y2 kept per row in VGPRs), the upper
 // neighbour (t-1, j) is the previous row of the same step or, for the first row of a strip, the bottom row lane l-1
@@ -623,24 +623,38 @@ __host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {
     return mch >= -32 && mch <= 31 && mis >= -32 && mis <= 31 && amb >= -32 && amb <= 31;
 }
 
-template <int S>
-__device__ __forceinline__ void ext_strip_job(const ExtJob &jb, const int jid, const ExtParams &prm, const uint8_t *__restrict__ reads,
-                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                              const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem) {
-    const int lane = threadIdx.x;
-    const int qlen = jb.qlen, tlen = jb.tlen;
+template <int S, int GL>
+__device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, const int first,
+                                               const int n_list, const ExtParams &prm, const uint8_t *__restrict__ reads,
+                                               const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                               const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem,
+                                               const int lds_stride) {
+    constexpr int NG = 64 / GL;  // windows per wave: each takes a group of GL lanes
+    const int lane = threadIdx.x, g = lane / GL, gl = lane % GL;
+    const int jid = first + g < n_list ? order[first + g] : -1;  // -1: padding at the end of a launch list
     int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
     if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
     const int qe = q + e, qe2 = q2 + e2;
-    ExtRes out;
-    out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
-    out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
-    if (qlen <= 0 || tlen <= 0 || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
-    uint8_t *qs_ = smem;  // 6 * base code: the bit offset of the score field
-    {
-        const int64_t roff = read_off[jb.read];
-        const int32_t rlen = read_len[jb.read];
-        for (int i = lane; i < qlen; i += 64) qs_[i] = (uint8_t)(6 * ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i)));
+    // the group's window, one copy per lane
+    int qlen = 0, tlen = 0, W = 0, rd = 0, rid = 0, rev = 0, qs = 0, ts = 0;
+    int64_t p_off = 0;
+    if (jid >= 0) {
+        const ExtJob &jb = jobs[jid];
+        qlen = jb.qlen; tlen = jb.tlen; W = jb.qstride; rd = jb.read; rid = jb.rid; rev = jb.rev; qs = jb.qs; ts = jb.ts; p_off = jb.p_off;
+    }
+    const bool ok = jid >= 0 && qlen > 0 && tlen > 0 && !(-prm.sc_mis > 2 * (q + e));
+    if (!ok) { qlen = 0; tlen = 0; }
+    // queries -> LDS as 6 * base code (the bit offset of the score field), one region per group, staged by the whole wave
+#pragma unroll
+    for (int g2 = 0; g2 < NG; ++g2) {
+        const int ql = __builtin_amdgcn_readlane(qlen, g2 * GL);
+        if (ql > 0) {
+            const int r2 = __builtin_amdgcn_readlane(rd, g2 * GL), rv2 = __builtin_amdgcn_readlane(rev, g2 * GL),
+                      qs2 = __builtin_amdgcn_readlane(qs, g2 * GL);
+            const int64_t roff = read_off[r2];
+            const int32_t rlen = read_len[r2];
+            for (int i = lane; i < ql; i += 64) smem[g2 * lds_stride + i] = (uint8_t)(6 * ext_qbase(reads, roff, rlen, rv2, qs2 + i));
+        }
     }
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
@@ -649,13 +663,13 @@ __device__ __forceinline__ void ext_strip_job(const ExtJob &jb, const int jid, c
     // UL: u of the previous column; YL, Y2L: y + (q+e), y2 + (q2+e2) of the previous column (both start at 0)
     int UL[S], YL[S], Y2L[S];
     uint32_t TB[S];
-    const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
-    const int t0 = lane * S;
+    const int64_t g0 = ok ? rv.seq_off[rid] + ts : 0;
+    const int t0 = gl * S;
     const uint32_t f_mch = (uint32_t)prm.sc_mch & 63, f_mis = (uint32_t)prm.sc_mis & 63, f_n = (uint32_t)prm.sc_n & 63;
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const int t = t0 + k;
-        const int sq = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
+        const int sq = t < tlen ? ref_code(rv, g0 + t) : 4;
         uint32_t tab = f_n << 24;
 #pragma unroll
         for (int c = 0; c < 4; ++c) tab |= (sq == 4 ? f_n : sq == c ? f_mch : f_mis) << (6 * c);
@@ -665,21 +679,23 @@ __device__ __forceinline__ void ext_strip_job(const ExtJob &jb, const int jid, c
     }
     __syncthreads();
     const int n_lanes = (tlen + S - 1) / S;
-    const int n_steps = qlen + n_lanes - 1;
-    const int W = jb.qstride;
-    uint8_t *prow = P + jb.p_off + t0;
+    const int max_steps = wave_reduce_max(ok ? qlen + n_lanes - 1 : 0);
+    const uint8_t *qrow = smem + g * lds_stride;
+    uint8_t *prow = P + p_off + t0;
     int out_v = 0, out_x = 0, out_x2 = 0, qsh = 24;
-    int32_t row0 = 0;  // lane 0: sum of the horizontal differences of row 0
+    int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
     const int mqe_ = -qe, mqe2_ = -qe2, mch = prm.sc_mch;
-    for (int step = 0; step < n_steps; ++step) {
-        // query bases and bottom-row states move one lane to the right
-        const int q_in = step < qlen ? (int)qs_[step] : 24;
-        qsh = wave_shr1(qsh, q_in);
-        int v_up = wave_shr1(out_v, 0), x_up = wave_shr1(out_x, 0), x2_up = wave_shr1(out_x2, 0);
-        const int j = step - lane;
-        const int bj = MPN_BND(step);  // lane 0: j = step
-        v_up = lane == 0 ? bj : v_up; x_up = lane == 0 ? 0 : x_up; x2_up = lane == 0 ? 0 : x2_up;
-        if (j >= 0 && j < qlen && lane < n_lanes) {
+    const bool head = gl == 0;
+    for (int step = 0; step < max_steps; ++step) {
+        // query bases and bottom-row states move one lane to the right; the first lane of a group takes the boundary
+        const int q_in = step < qlen ? (int)qrow[step] : 24;
+        const int qsh_s = wave_shr1(qsh, 24);
+        const int v_s = wave_shr1(out_v, 0), x_s = wave_shr1(out_x, 0), x2_s = wave_shr1(out_x2, 0);
+        const int j = step - gl;
+        const int bj = MPN_BND(step);  // first lane: j = step
+        qsh = head ? q_in : qsh_s;
+        int v_up = head ? bj : v_s, x_up = head ? 0 : x_s, x2_up = head ? 0 : x2_s;
+        if (j >= 0 && j < qlen && gl < n_lanes) {
             uint32_t dw[(S + 3) / 4];
 #pragma unroll
             for (int k = 0; k < (S + 3) / 4; ++k) dw[k] = 0;
@@ -722,32 +738,39 @@ __device__ __forceinline__ void ext_strip_job(const ExtJob &jb, const int jid, c
     }
 #undef MPN_BND
     // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1); a lane's UL froze at its last column
-    int32_t tot = lane == 0 ? row0 - qe : 0;
+    int32_t tot = head ? row0 - qe : 0;
 #pragma unroll
     for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? UL[k] : 0;
-    for (int dlt = 32; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
-    out.score = tot;
-    out.r_done = qlen + tlen - 2;
-    out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1;
-    if (lane == 0) res[jid] = out;
+#pragma unroll
+    for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
+    if (head && jid >= 0) {
+        ExtRes out;
+        out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = ok ? tot : NEG_INF;
+        out.reach_end = 0; out.n_cigar = 0; out.r_done = ok ? qlen + tlen - 2 : -1; out.zcode = 0; out.cig_pos = 0;
+        out.do_bt = ok ? 1 : 0; out.bt_i = ok ? tlen - 1 : -1; out.bt_j = ok ? qlen - 1 : -1;
+        res[jid] = out;
+    }
 }
 
-// One launch per group of four strip heights (G = 0..3: S = 4G+1 .. 4G+4): few launches with many windows each keep
-// the tail of a launch short, and the register budget of a launch is that of its tallest strip only.
-template <int G>
-__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+// One launch per lane-group width.  GL = 16 / 32 / 64 lanes per window (4 / 2 / 1 windows per wave) for targets up to
+// 256 / 512 / 1024 rows: the ramp of the systolic array costs n_lanes - 1 steps per window, so a window should use as few
+// lanes -- as tall a strip, S <= 16 -- as it can.  The launch list is grouped by S and every group is padded to whole
+// waves, so S is uniform per wave (read from its first window).
+template <int GL>
+__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_list,
                                                           ExtParams prm, const uint8_t *__restrict__ reads,
                                                           const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
+                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, int lds_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int jid = order[blockIdx.x];
-    const ExtJob jb = jobs[jid];
-    switch (jb.strip_s - 4 * G) {
-        case 1: ext_strip_job<4 * G + 1>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
-        case 2: ext_strip_job<4 * G + 2>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
-        case 3: ext_strip_job<4 * G + 3>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
-        default: ext_strip_job<4 * G + 4>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem); break;
+    const int first = blockIdx.x * (64 / GL);
+    const int S = jobs[order[first]].strip_s;
+#define MPN_CASE(SS) case SS: ext_strip_pack<SS, GL>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride); break
+    switch (S) {
+        MPN_CASE(1); MPN_CASE(2); MPN_CASE(3); MPN_CASE(4); MPN_CASE(5); MPN_CASE(6); MPN_CASE(7); MPN_CASE(8);
+        MPN_CASE(9); MPN_CASE(10); MPN_CASE(11); MPN_CASE(12); MPN_CASE(13); MPN_CASE(14); MPN_CASE(15);
+        default: ext_strip_pack<16, GL>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride); break;
     }
+#undef MPN_CASE
 }
 
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
@@ -758,6 +781,7 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
     const int jid = order[k];
+    if (jid < 0) return;  // padding of a strip launch list
     const ExtJob jb = jobs[jid];
     ExtRes r = res[jid];
     if (!r.do_bt) { res[jid].cig_pos = 0; return; }
@@ -825,6 +849,7 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
     const int jid = order[k];
+    if (jid < 0) return;  // padding of a strip launch list
     const ExtJob jb = jobs[jid];
     if (!(jb.flag & EZ_APPROX_MAX)) return;  // only gap fills are tested
     const ExtRes r = res[jid];
