@@ -123,6 +123,8 @@ typedef struct {
     int32_t *read_idx, *qs, *qe, *rev, *rid, *rs, *re, *mlen, *blen, *mapq, *nm, *as, *primary;
 } mpn_aln_cols;
 
+/* d_seqs (when given): the reads on the device; 4-byte aligned and padded so that the aligned 32-bit word around the
+ * last base may be read (any allocation rounded up to 4 bytes will do). */
 int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
                          const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs,
                          const int64_t *d_off, const int32_t *d_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols);

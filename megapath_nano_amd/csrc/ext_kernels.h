@@ -866,11 +866,13 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     const int32_t rlen = read_len[jb.read];
     const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
-    for (int c = 0; c < r.n_cigar; ++c) {
+    RefCursor tc(rv);
+    ReadCursor qc(reads, roff, rlen, jb.rev);
+    for (int c = 0; c < r.n_cigar && max_zdrop <= prm.zdrop_thres; ++c) {  // (only "above the threshold or not" is reported)
         const uint32_t op = cig[c] & 0xf, len = cig[c] >> 4;
         if (op == 0) {
             for (uint32_t l = 0; l < len; ++l) {
-                const int ct = ref_code(rv, g0 + i + l), cq = ext_qbase(reads, roff, rlen, jb.rev, jb.qs + j + l);
+                const int ct = tc.at(g0 + i + l), cq = qc.at(jb.qs + j + (int)l);
                 score += (ct == 4 || cq == 4) ? prm.sc_n : ct == cq ? prm.sc_mch : prm.sc_mis;
                 if (score < mx) {
                     const int li = i + (int)l - max_i, lj = j + (int)l - max_j, diff = li > lj ? li - lj : lj - li;

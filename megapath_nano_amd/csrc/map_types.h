@@ -30,4 +30,46 @@ __device__ __forceinline__ int ref_code(const RefView &rv, int64_t g) {
     return c;
 }
 
+// Sequential reader of target codes for a lane that walks along a target (CIGAR walks): the current 16-base word and the
+// ambiguous-run / run-free interval around the position stay in registers, so a step costs a shift instead of a word
+// load plus a binary search.
+struct RefCursor {
+    const RefView &rv;
+    int64_t widx = -1, run_s = 1, run_e = 0, clear_s = 1, clear_e = 0;
+    uint32_t word = 0;
+    __device__ __forceinline__ explicit RefCursor(const RefView &r) : rv(r) {}
+    __device__ __forceinline__ int at(int64_t g) {
+        const int64_t wi = g >> 4;
+        if (wi != widx) { word = rv.seq2[wi]; widx = wi; }
+        int c = (int)((word >> (2 * (int)(g & 15))) & 3u);
+        if (rv.n_runs > 0) {
+            if (g >= run_s && g < run_e) c = 4;
+            else if (!(g >= clear_s && g < clear_e)) {
+                int lo = 0, hi = rv.n_runs;  // last run with start <= g
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (rv.nrun_s[mid] <= g) lo = mid + 1; else hi = mid; }
+                if (lo > 0 && g < rv.nrun_e[lo - 1]) { run_s = rv.nrun_s[lo - 1]; run_e = rv.nrun_e[lo - 1]; c = 4; }
+                else { clear_s = lo > 0 ? rv.nrun_e[lo - 1] : INT64_MIN; clear_e = lo < rv.n_runs ? rv.nrun_s[lo] : INT64_MAX; }
+            }
+        }
+        return c;
+    }
+};
+
+// Sequential reader of read bases on the hit's strand (0..4 codes): four ASCII bytes per load.  The reads buffer is 4-byte
+// aligned and padded (mpn_map.h), so the aligned word around any base may be read.
+struct ReadCursor {
+    const uint32_t *words;
+    int64_t roff, widx = -1;
+    int32_t rlen, rev;
+    uint32_t word = 0;
+    __device__ __forceinline__ ReadCursor(const uint8_t *reads, int64_t roff_, int32_t rlen_, int rev_)
+        : words(reinterpret_cast<const uint32_t *>(reads)), roff(roff_), rlen(rlen_), rev(rev_) {}
+    __device__ __forceinline__ int at(int x) {
+        const int64_t a = roff + (rev ? rlen - 1 - x : x), wi = a >> 2;
+        if (wi != widx) { word = words[wi]; widx = wi; }
+        const int c = nt4_code((uint8_t)(word >> (8 * (int)(a & 3))));
+        return rev ? (c < 4 ? 3 - c : 4) : c;
+    }
+};
+
 }  // namespace mpn
