@@ -1007,6 +1007,14 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         for (int l = L_STRIP; l < L_BAND; ++l) for (int k = base[l] + cnt[l]; k < base[l + 1]; ++k) flat[k] = -1;
         for (int j = 0; j < nj; ++j) flat[cur[(int)list_id[j]]++] = j;
     }
+    // the windows that share a wave should need the same number of steps: longest queries first within each strip list
+    parallel_for(N_STRIP, nt, [&](int k, int) {
+        const int l = L_STRIP + k;
+        if (strip_windows_per_wave(l) > 1 && cnt[l] > 1)
+            std::sort(flat + base[l], flat + base[l] + cnt[l], [&](int32_t x, int32_t y) {
+                return jobs[x].qlen != jobs[y].qlen ? jobs[x].qlen > jobs[y].qlen : x < y;
+            });
+    });
     if (getenv("MPN_DEBUG_JOBS")) {
         static const char *const fam[] = {"lds", "wg", "strip", "band"};
         for (int l = 0; l < N_LISTS; ++l) {
