@@ -1,12 +1,13 @@
-// Base-level extension kernels (gfx950): banded dual-affine-gap DP with z-drop on anti-diagonals
-// (the ksw2 formulation minimap2 uses for `-c`), traceback, and the z-drop test of a finished CIGAR.
+// Base-level extension kernels (gfx950): banded dual-affine-gap DP with z-drop (the ksw2 formulation minimap2 uses
+// for `-c`), traceback, and the z-drop test of a finished CIGAR.  Integer VALU + LDS work: no MFMA.
 //
-// One wavefront per DP job.  Anti-diagonal r is processed 64 cells (target positions t) at a time across the
-// lanes; the Suzuki-Kasahara difference states u,v,x,y,x2,y2 (one int8 per target position) and the 32-bit H row
-// live in LDS next to the staged query/target windows; the left neighbour (t-1) of the previous anti-diagonal
-// arrives by DPP wave_shr (lane 0 takes the carry of the previous tile).  Direction codes (1 B/cell) stream to an
-// HBM scratch in coalesced 64-byte rows.  Integer VALU + LDS work: no MFMA.
-// Traceback is latency bound and serial per job, so it runs in a second kernel with one LANE per job.
+//   ext_dp_strip_kernel<GL>   gap fills whose band never clips (the bulk of the cells): systolic, several windows per wave,
+//                             all state in VGPRs, 1 B/cell of direction codes in a step-major matrix
+//   ext_dp_band_kernel<NW,T>  every other window whose band fits 1024 slots (end extensions with exact max + z-drop,
+//                             clipped fills, the exact second pass): band in registers, one barrier per anti-diagonal
+//   ext_dp_kernel, ext_dp_wg_kernel<NT>   fallbacks (wider bands, windows beyond LDS): Suzuki-Kasahara states u,v,x,y,x2,y2
+//                             and the H row in LDS or global scratch, one wave or one workgroup per window
+//   ext_bt_kernel, ext_ztest_kernel        one LANE per window: traceback is a serial pointer chase, the z-drop test a CIGAR walk
 #pragma once
 #include "mpn_common.h"
 #include "map_types.h"
