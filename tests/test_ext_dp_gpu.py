@@ -141,3 +141,21 @@ def test_band_kernel_slot_variants(opt):
     qs, ts = make_pairs(14, [1800, 2600], ambig=True, big_indel=True)
     check(opt, qs, ts, 300, 100, -1, 0, [1, 5])
     check(opt, qs, ts, 300, 100, -1, APPROX | RIGHT, [1, 5])
+
+
+def test_lopsided_windows_dispatch(opt):
+    """Windows far from square: long query x short target and the reverse, around the strip kernel's class limits
+    (query 1024 / 2048 / 4096 bases per lane-group class, target 256 / 512 / 1024 rows): whatever kernel the dispatcher
+    picks (0) must agree with the oracle, like the LDS fallback (1)."""
+    rng = np.random.default_rng(31)
+    qs, ts = [], []
+    for qlen, tlen in ((5000, 300), (300, 5000), (1024, 256), (1025, 256), (2048, 512), (2049, 300), (4096, 1024), (4097, 1000),
+                       (40, 1024), (1500, 17), (17, 1500), (3, 900)):
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        q = rng.integers(0, 4, size=qlen).astype(np.uint8)
+        n = min(qlen, tlen)
+        q[:n] = np.where(rng.random(n) < 0.88, t[:n], q[:n])   # a homologous prefix, the rest unrelated
+        qs.append(q)
+        ts.append(t)
+    check(opt, qs, ts, 6000, 400, -1, APPROX, [0, 4, 1])
+    check(opt, qs, ts, 6000, 400, -1, 0, [0, 5])
