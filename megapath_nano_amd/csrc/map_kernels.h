@@ -158,14 +158,28 @@ __global__ __launch_bounds__(1024) void scan_i64_kernel(const int64_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// seeds: one lane per read minimizer; binary search in the sorted key array
+// seeds: one lane per read minimizer.  A bucket table over the top bits of the hash (bucket_start[b] = first key of bucket
+// b, 2^bucket_bits + 1 entries) narrows the binary search in the sorted key array to the dozen keys of one bucket:
+// two or three sectors per lookup instead of ~18 uncached probes over the whole array.
+__global__ __launch_bounds__(256) void idx_bucket_table_kernel(const uint64_t *__restrict__ keys, int64_t n_keys, int shift, int64_t n_buckets,
+                                                               int64_t *__restrict__ bucket_start) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_keys; i += (int64_t)gridDim.x * blockDim.x) {
+        // entry i closes the buckets (b_prev, b_i]: they all start at key i
+        const int64_t b_prev = i > 0 ? (int64_t)(keys[i - 1] >> shift) : -1;
+        const int64_t b_i = i < n_keys ? (int64_t)(keys[i] >> shift) : n_buckets;
+        for (int64_t b = b_prev + 1; b <= b_i; ++b) bucket_start[b] = i;
+    }
+}
+
 __global__ __launch_bounds__(256) void seed_lookup_kernel(const uint64_t *__restrict__ keys, const int64_t *__restrict__ key_off,
-                                                          int64_t n_keys, const u128 *__restrict__ mz, int64_t n_mz,
+                                                          int64_t n_keys, const int64_t *__restrict__ bucket_start, int bucket_shift,
+                                                          const u128 *__restrict__ mz, int64_t n_mz,
                                                           int32_t max_occ, int32_t *__restrict__ occ,
                                                           int64_t *__restrict__ pos_start) {
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_mz; m += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t key = mz[m].x >> 8;
-        int64_t lo = 0, hi = n_keys;
+        const int64_t b = (int64_t)(key >> bucket_shift);
+        int64_t lo = bucket_start[b], hi = bucket_start[b + 1];
         while (lo < hi) {
             int64_t mid = (lo + hi) >> 1;
             if (keys[mid] < key) lo = mid + 1; else hi = mid;

@@ -115,7 +115,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         return -1;
     if (n_mz > 0) {
         hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p,
-                           idx->n_keys, mz.p, n_mz, mid_occ, occ.p, pos_start.p);
+                           idx->n_keys, (const int64_t *)idx->bucket_start.p, idx->bucket_shift, mz.p, n_mz, mid_occ, occ.p, pos_start.p);
         MPN_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(seed_prefix_kernel, dim3(std::max(1, std::min(n, 256 * 32))), dim3(64), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
@@ -245,6 +245,8 @@ void mpn_map_opt_init(mpn_map_opt *o) {
     o->host_threads = 0;
 }
 
+static int build_bucket_table(mpn_index *idx, hipStream_t st);
+
 mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
                            int32_t k, int32_t w) {
     if (n_seq <= 0 || k < 1 || k > 28 || w < 1 || w > 255) { set_error("mpn_index_build: bad arguments"); return nullptr; }
@@ -314,7 +316,7 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
         idx->h_key_off.resize((size_t)n_keys + 1);
         if (idx->key_off.download(idx->h_key_off.data(), (size_t)n_keys + 1, st)) return fail();
         if (stream_sync(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("mpn_index_build: GPU sort failed"); return fail(); }
-        if (idx->d_seq_off.upload(off.data(), off.size(), st)) return fail();
+        if (build_bucket_table(idx, st) || idx->d_seq_off.upload(off.data(), off.size(), st)) return fail();
     }
     {
         std::vector<uint32_t> words;
@@ -327,6 +329,18 @@ mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *
     }
     if (stream_sync(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
     return idx;
+}
+
+// bucket table over the sorted keys (see seed_lookup_kernel); rebuilt from the keys, so it is not part of the file format
+static int build_bucket_table(mpn_index *idx, hipStream_t st) {
+    const int hbits = 2 * idx->k, bbits = std::min(24, hbits);
+    idx->bucket_shift = hbits - bbits;
+    const int64_t nb = (int64_t)1 << bbits;
+    if (idx->bucket_start.alloc((size_t)nb + 1)) return -1;
+    hipLaunchKernelGGL(idx_bucket_table_kernel, dim3(grid_1d(idx->n_keys + 1, 256)), dim3(256), 0, st, idx->keys.p, idx->n_keys,
+                       idx->bucket_shift, nb, idx->bucket_start.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ---- persistent form of the index (minimap2 -d) ----------------------------------------------------
@@ -417,7 +431,7 @@ mpn_index *mpn_index_load(const char *path) {
     if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(idx->h_key_off.data(), idx->h_key_off.size(), st) ||
         idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq_off.upload(idx->seq_off.data(), idx->seq_off.size(), st) ||
         idx->d_seq2.upload(words.data(), words.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
-        idx->d_nrun_e.upload(ne.data(), ne.size(), st) || stream_sync(st) != hipSuccess) {
+        idx->d_nrun_e.upload(ne.data(), ne.size(), st) || build_bucket_table(idx, st) || stream_sync(st) != hipSuccess) {
         delete idx;  // (the failing HIP call has set the error text)
         return nullptr;
     }

@@ -25,6 +25,8 @@ struct mpn_index {
     int64_t n_keys = 0, n_mz = 0;
     mpn::DevBuf<uint64_t> keys, pos;
     mpn::DevBuf<int64_t> key_off;
+    mpn::DevBuf<int64_t> bucket_start;  // first key of every hash bucket (top bucket_bits of the 2k-bit hash), + end sentinel
+    int bucket_shift = 0;
     mpn::DevBuf<uint32_t> d_seq2;     // device: targets packed 2 bits per base
     mpn::DevBuf<int64_t> d_seq_off, d_nrun_s, d_nrun_e;  // + ambiguous-base runs (concatenated coordinates)
     int32_t n_nruns = 0;
