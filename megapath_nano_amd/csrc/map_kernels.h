@@ -373,7 +373,9 @@ __device__ __forceinline__ int ilog2_32(uint32_t v) { return 31 - __clz((int)v);
 // predecessor range needs no state: a predecessor is in range iff its reference coordinate is within max_dist_x and it
 // is at most max_iter anchors back, and the anchors are sorted.  Single-wave workgroup: LDS accesses of one wave are
 // ordered, so only a compiler/LDS fence separates the phases (a full __syncthreads would also drain the global stores).
-constexpr int CHAIN_CW = 512;
+// CW = 128 (4 KB of LDS per wave): the kernel is latency-bound, its throughput is the number of resident waves; a
+// 512-entry ring limited a CU to 9 waves and cost 25 % of the kernel's time, 64 entries gain nothing more.
+constexpr int CHAIN_CW = 128;
 #define MPN_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
