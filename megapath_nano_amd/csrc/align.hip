@@ -1105,6 +1105,27 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     auto on_side = [](int l) { return (l >= L_WG && l < L_STRIP) || l >= L_BAND + 8; };  // workgroup windows, 512- and 1024-slot bands
     for (int l = N_LISTS - 1; l >= 0; --l)
         if (on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], SL.st2)) return -1;
+    // The long windows are also the long pole of the two lane-per-window kernels (traceback, z-drop test): those of the side
+    // lists run on the side stream as soon as their DP is done, beside the strip DP of the main stream.
+    const int side_lo[2] = {base[L_WG], base[L_BAND + 8]}, side_hi[2] = {base[L_STRIP], base[N_LISTS]};
+    const int main_lo[2] = {0, base[L_STRIP]}, main_hi[2] = {base[L_WG], base[L_BAND + 8]};
+    auto bt_ztest = [&](const int *lo, const int *hi, hipStream_t s, bool timed) -> int {
+        for (int k = 0; k < 2; ++k) {
+            const int n = hi[k] - lo[k];
+            if (n > 0) hipLaunchKernelGGL(ext_bt_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
+        }
+        MPN_HIP_CHECK(hipGetLastError());
+        if (timed) ev.mark(25);
+        // z-drop test of the gap-fill CIGARs (the kernel skips the other windows); flagged ones are recomputed with the exact maximum
+        for (int k = 0; k < 2; ++k) {
+            const int n = hi[k] - lo[k];
+            if (n > 0) hipLaunchKernelGGL(ext_ztest_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, prm, d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p);
+        }
+        MPN_HIP_CHECK(hipGetLastError());
+        if (timed) ev.mark(26);
+        return 0;
+    };
+    if (bt_ztest(side_lo, side_hi, SL.st2, false)) return -1;
     MPN_HIP_CHECK(hipEventRecord(SL.ev_b, SL.st2));
     for (int l = N_LISTS - 1; l >= 0; --l) {  // wide before narrow, strips (the bulk) in the middle
         if (on_side(l)) continue;
@@ -1114,16 +1135,9 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         } else if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
         if (l == L_STRIP) ev.mark(9);
     }
-    MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
     ev.mark(15);
-    hipLaunchKernelGGL(ext_bt_kernel, dim3((n_flat + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, n_flat, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
-    MPN_HIP_CHECK(hipGetLastError());
-    ev.mark(25);
-    // z-drop test of the gap-fill CIGARs (the kernel skips the other windows); flagged ones are recomputed with the exact maximum
-    hipLaunchKernelGGL(ext_ztest_kernel, dim3((n_flat + 63) / 64), dim3(64), 0, st, d_jobs.p, d_order.p, n_flat, prm, d_reads, d_read_off, d_read_len,
-                       rv, CIG.p, d_res.p);
-    MPN_HIP_CHECK(hipGetLastError());
-    ev.mark(26);
+    if (bt_ztest(main_lo, main_hi, st, true)) return -1;
+    MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
     ExtRes *h_res = SL.pin_res.as<ExtRes>();
     unsigned long long *h_used = (unsigned long long *)((char *)SL.pin_res.p + (size_t)nj * sizeof(ExtRes));
     MPN_HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
