@@ -97,3 +97,30 @@ def test_step_counts_and_shard_invariance(big):
     assert int(outs[0]['read_count'].sum()) == int(full['read_count'].sum())
     assert np.abs(outs[0]['read_count'] - full['read_count']).sum() <= 4  # only exact-score ties may move
     assert np.array_equal(outs[0]['aligned_bp'], outs[1]['aligned_bp'])
+
+
+def test_very_long_reads_match_oracle(big):
+    """Reads far beyond the typical 8 kb: a 390 kb read covering almost a whole target (forward), a 250 kb one from the
+    reverse strand, and a 120 kb chimera of two targets -- thousands of DP windows and tens of thousands of anchors per read,
+    alone in their own sub-batches; PAF identical to the oracle's."""
+    from megapath_nano_amd import mapper, synth
+    from oracle import mm2_bindings as mb
+    gen, _, idx, _ = big
+    rng = np.random.default_rng(123)
+    g3 = np.frombuffer(bytes(gen[3][1]), dtype=np.uint8)
+    g5 = np.frombuffer(bytes(gen[5][1]), dtype=np.uint8)
+    g7 = np.frombuffer(bytes(gen[7][1]), dtype=np.uint8)
+    long_reads = [
+        dict(name='long_fwd_390k', seq=synth.ont_errors(rng, g3[5000:395000].copy())),
+        dict(name='long_rev_250k', seq=synth.ont_errors(rng, synth.COMP[g5[100000:350000][::-1]])),
+        dict(name='chimera_120k', seq=synth.ont_errors(rng, np.concatenate([g7[10000:70000], g3[200000:260000]]))),
+    ]
+    opt, oopt = mapper.default_opt(best_n=50, pri_ratio=1.0), mb.default_opt(best_n=50, pri_ratio=1.0)
+    got = mapper.map_batch(idx, opt, [r['name'] for r in long_reads], [r['seq'] for r in long_reads])
+    oidx = mb.Index(gen)
+    want = ''.join(mb.map_read(oidx, oopt, r['name'], r['seq'])[2] for r in long_reads)
+    oidx.close()
+    assert got == want
+    prim = {l.split('\t')[0]: l.split('\t') for l in got.splitlines() if '\ttp:A:P' in l}
+    assert int(prim['long_fwd_390k'][3]) - int(prim['long_fwd_390k'][2]) > 0.95 * len(long_reads[0]['seq'])
+    assert prim['long_rev_250k'][4] == '-'
