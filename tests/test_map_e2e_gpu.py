@@ -238,3 +238,29 @@ def test_sam_output_matches_oracle(world):
             assert qlen == len(f[9]), f[0]
     hdr = gidx.sam_header('mpn-aligner -a test')
     assert hdr.count('@SQ\t') == len(gen) and hdr.splitlines()[-1].startswith('@PG\tID:mpn-aligner') and f'SN:{gen[0][0]}\tLN:{len(gen[0][1])}' in hdr
+
+
+@pytest.mark.parametrize('k,w,kw', [
+    (15, 15, dict(a=1, b=4, q=1, e=2, min_dp_max=50, zdrop=50, zdrop_inv=50, best_n=1000, pri_ratio=0.0)),   # megapath_nano.py:221-241
+    (13, 8, dict(a=3, b=5, q=6, e=3, q2=30, e2=1, best_n=5, pri_ratio=0.8)),
+    (15, 10, dict(a=2, b=40, q=4, e=2, best_n=5, pri_ratio=0.8)),   # mismatch score outside the strip kernel's 6-bit fields
+])
+def test_other_index_and_scoring_options(world, k, w, kw):
+    """The genome-similarity option sets of the reference (-k15 -w15 -A1 -B4 -O1 -E2 -s50 -z50 -N 1000 -p 0) and other k/w/scores:
+    same PAF as the oracle (the strip kernel's score table takes 6-bit scores; beyond that the dispatcher uses the band kernel)."""
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, _, _ = world
+    gidx, oidx = mapper.Index(gen, k=k, w=w), mb.Index(gen, k=k, w=w)
+    try:
+        gopt, oopt = mapper.default_opt(**kw), mb.default_opt(**kw)
+        sub = reads[:30]
+        names = [r['name'] for r in sub]
+        got = split_by_read(mapper.map_batch(gidx, gopt, names, [r['seq'] for r in sub]), names)
+        want = oracle_paf(oidx, oopt, sub)
+        for r, g, x in zip(sub, got, want):
+            assert g == x, (r['name'], k, w)
+        assert sum(x.count('\n') for x in want) >= len(sub) // 2
+    finally:
+        gidx.close()
+        oidx.close()
