@@ -80,8 +80,10 @@ def cpu_baseline(genomes, reads, opt_kw, seconds_target=15.0):
     dt = time.time() - t0
     bases = sum(len(r['seq']) for r in sample)
     oidx.close()
+    import shutil
     return dict(value=bases / dt * 60 / 1e9, unit='Gbp/min', cores=cores, kind='port',
-                sample=f'{n} reads ({bases} bp) of the step batch, oracle/mm2_oracle.c seed-chain-extend, {dt:.1f} s wall')
+                sample=f'{n} reads ({bases} bp) of the step batch, oracle/mm2_oracle.c seed-chain-extend, {dt:.1f} s wall',
+                minimap2_on_box=shutil.which('minimap2'))   # a real binary would be timed beside the port; none ships in the image
 
 
 def main():
