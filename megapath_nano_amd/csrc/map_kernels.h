@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                                                              uint64_t *__restrict__ Uc, unsigned long long *__restrict__ used,
                                                              int64_t *__restrict__ u_pos, int64_t *__restrict__ b_pos,
                                                              int32_t *__restrict__ n_chain, int64_t *__restrict__ n_chained) {
-    __shared__ int s_k, s_nv;
+    __shared__ int s_k;
     __shared__ unsigned long long s_up, s_bp;
     const int lane = threadIdx.x;
     for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                 }
                 if (k0 == k) n_v = n_v0;
             }
-            s_k = k; s_nv = n_v;
+            s_k = k;
             n_chain[read] = k;
             n_chained[read] = n_v;
             // compact pools: only chains that survived travel to the host
