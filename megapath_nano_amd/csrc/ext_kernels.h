@@ -661,8 +661,13 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 #define MPN_BND(R) ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2)
-    // UL: u of the previous column; YL, Y2L: y + (q+e), y2 + (q2+e2) of the previous column (both start at 0)
-    int UL[S], YL[S], Y2L[S];
+    // Difference states as pairs of 16-bit lanes of one register (they are small integers): the two gap types of a cell go
+    // through v_pk_add/sub/max/min_i16 together.  UL: u of the previous column, both halves equal; YL: (y + (q+e) | y2 + (q2+e2))
+    // of the previous column, both start at 0.  Vp: v of the row above, both halves equal; Xp: (x + (q+e) | x2 + (q2+e2)).
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto bcast = [](int x) { return s16x2{(short)x, (short)x}; };
+    s16x2 UL[S], YL[S];
     uint32_t TB[S];
     const int64_t g0 = ok ? rv.seq_off[rid] + ts : 0;
     const int t0 = gl * S;
@@ -675,27 +680,29 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
 #pragma unroll
         for (int c = 0; c < 4; ++c) tab |= (sq == 4 ? f_n : sq == c ? f_mch : f_mis) << (6 * c);
         TB[k] = tab;
-        UL[k] = MPN_BND(t);   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
-        YL[k] = 0; Y2L[k] = 0;
+        UL[k] = bcast(MPN_BND(t));   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
+        YL[k] = s16x2{0, 0};
     }
     __syncthreads();
     const int n_lanes = (tlen + S - 1) / S;
     const int max_steps = wave_reduce_max(ok ? qlen + n_lanes - 1 : 0);
     const uint8_t *qrow = smem + g * lds_stride;
     uint8_t *prow = P + p_off + t0;
-    int out_v = 0, out_x = 0, out_x2 = 0, qsh = 24;
+    int out_v = 0, out_x = 0, qsh = 24;
     int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
-    const int mqe_ = -qe, mqe2_ = -qe2, mch = prm.sc_mch;
+    const s16x2 MQ = {(short)-qe, (short)-qe2}, Qp = {(short)q, (short)q2}, ZERO = {0, 0};
+    const u16x2 K7FFF = {0x7fff, 0x7fff}, SH15 = {15, 15};
+    const int mch = prm.sc_mch;
     const bool head = gl == 0;
     for (int step = 0; step < max_steps; ++step) {
         // query bases and bottom-row states move one lane to the right; the first lane of a group takes the boundary
         const int q_in = step < qlen ? (int)qrow[step] : 24;
         const int qsh_s = wave_shr1(qsh, 24);
-        const int v_s = wave_shr1(out_v, 0), x_s = wave_shr1(out_x, 0), x2_s = wave_shr1(out_x2, 0);
+        const int v_s = wave_shr1(out_v, 0), x_s = wave_shr1(out_x, 0);
         const int j = step - gl;
         const int bj = MPN_BND(step);  // first lane: j = step
         qsh = head ? q_in : qsh_s;
-        int v_up = head ? bj : v_s, x_up = head ? 0 : x_s, x2_up = head ? 0 : x2_s;
+        s16x2 Vp = head ? bcast(bj) : __builtin_bit_cast(s16x2, v_s), Xp = head ? ZERO : __builtin_bit_cast(s16x2, x_s);
         if (j >= 0 && j < qlen && gl < n_lanes) {
             uint32_t dw[(S + 3) / 4];
 #pragma unroll
@@ -704,26 +711,30 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 const int sc = __builtin_amdgcn_sbfe((int)TB[k], qsh, 6);
-                const int ut = UL[k];
-                int a = x_up + v_up + mqe_, b = YL[k] + ut + mqe_, a2 = x2_up + v_up + mqe2_, b2 = Y2L[k] + ut + mqe2_;
-                int z = max(max(sc, a), b);
-                z = max(max(z, a2), b2);
+                const s16x2 Up = UL[k];
+                s16x2 A = Xp + Vp + MQ, B = YL[k] + Up + MQ;     // (a | a2), (b | b2)
+                const s16x2 M = __builtin_elementwise_max(A, B);
+                const int z0 = max(max((int)M.x, (int)M.y), sc);
                 int d = 4;                 // first operand (sc, a, b, a2, b2) that equals the maximum
-                d = a2 == z ? 3 : d;
-                d = b == z ? 2 : d;
-                d = a == z ? 1 : d;
-                d = sc == z ? 0 : d;
-                z = min(z, mch);
-                const int nu = z - v_up, nv = z - ut;
-                const int zq = z - q, zq2 = z - q2;
-                a = max(a - zq, 0); b = max(b - zq, 0); a2 = max(a2 - zq2, 0); b2 = max(b2 - zq2, 0);
-                d |= min(a, 1) << 3; d |= min(b, 1) << 4; d |= min(a2, 1) << 5; d |= min(b2, 1) << 6;
-                UL[k] = nu; YL[k] = b; Y2L[k] = b2;
-                v_up = nv; x_up = a; x2_up = a2;
+                d = (int)A.y == z0 ? 3 : d;
+                d = (int)B.x == z0 ? 2 : d;
+                d = (int)A.x == z0 ? 1 : d;
+                d = sc == z0 ? 0 : d;
+                const s16x2 Zp = bcast(min(z0, mch));
+                const s16x2 nu = Zp - Vp, nv = Zp - Up, ZQ = Zp - Qp;
+                A = __builtin_elementwise_max(A - ZQ, ZERO);
+                B = __builtin_elementwise_max(B - ZQ, ZERO);
+                // (x > 0) for x >= 0, per half: (x + 0x7fff) >> 15 -- two packed ops instead of compare + select per half
+                const uint32_t H = __builtin_bit_cast(uint32_t, (__builtin_bit_cast(u16x2, A) + K7FFF) >> SH15) |
+                                   __builtin_bit_cast(uint32_t, (__builtin_bit_cast(u16x2, B) + K7FFF) >> SH15) << 1;
+                d |= (int)(H & 3u) << 3;   // a > 0, b > 0
+                d |= (int)(H >> 16) << 5;  // a2 > 0, b2 > 0
+                UL[k] = nu; YL[k] = B;
+                Vp = nv; Xp = A;
                 dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
-                if (k == 0) nv0 = nv;
+                if (k == 0) nv0 = (int)nv.x;
             }
-            out_v = v_up; out_x = x_up; out_x2 = x2_up;
+            out_v = __builtin_bit_cast(int, Vp); out_x = __builtin_bit_cast(int, Xp);
             row0 += nv0;
             uint8_t *dst = prow + (int64_t)step * W;  // p_off is 16-aligned, W and t0 are multiples of S
             if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
@@ -741,7 +752,7 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1); a lane's UL froze at its last column
     int32_t tot = head ? row0 - qe : 0;
 #pragma unroll
-    for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? UL[k] : 0;
+    for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x : 0;
 #pragma unroll
     for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
     if (head && jid >= 0) {
