@@ -157,3 +157,13 @@ def test_human_decoy_classification_rules():
     assert sorted(out['microbe_read_id_list']['read_id']) == ['m1', 'm2', 'unaligned']
     mb = out['microbe_best_align_list'].set_index('read_id')
     assert mb.loc['m1', 'assembly_id'] == 'MIC2' and mb.loc['m2', 'assembly_id'] == 'MIC1'
+
+
+def test_index_file_magic_detection(tmp_path):
+    """`Align()` / bin/mpn-aligner treat a target as a saved index only if it carries the magic (no GPU needed to tell)."""
+    from megapath_nano_amd.mapper import Index
+    fa = tmp_path / 't.fa'
+    fa.write_bytes(b'>s\nACGT\n')
+    idx = tmp_path / 't.mpi'
+    idx.write_bytes(Index.MAGIC + b'\0' * 64)
+    assert not Index.is_index_file(str(fa)) and Index.is_index_file(str(idx)) and not Index.is_index_file(str(tmp_path / 'missing'))
