@@ -174,10 +174,10 @@ def main():
         'ext_dp_band_kernel (+ fallbacks)': st['ev_ext_dp_ns'], 'ext_dp_strip_kernel': st['ev_ext_strip_ns'],
         'ext_bt_kernel': st['ev_ext_bt_ns'], 'ext_ztest_kernel': st['ev_ext_ztest_ns'],
     }
-    # Dominant kernel: ext_dp_strip_kernel<4|8|16> (the gap-fill DP: >95 % of all DP cells and the largest share of device
+    # Dominant kernel: ext_dp_strip_kernel<16|32|64> (lanes per window; the gap-fill DP: >95 % of all DP cells and the largest share of device
     # time in profiles/r01).  Algorithmic bytes: 1 direction byte written per cell (the windows read
     # are qlen + tlen bases, < 1 % of that).  One sub-batch issues the three instantiations back to back; `launches` counts
-    # those triples, `achieved` = bytes per triple / its average duration.
+    # those triples, `achieved` = bytes per triple / its average duration (HIP events on the launching stream).
     launches = max(st['dp_rounds'], 1)
     strip_ms = st['ev_ext_strip_ns'] / 1e6 / launches
     bytes_per_launch = st['strip_cells'] / launches
@@ -215,10 +215,10 @@ def main():
             'index_build_s': round(index_s, 2), 'parallelism': f'reads sharded over {world} GPU(s), index replicated',
         },
         'roofline': {
-            'bound': 'hbm', 'kernel': 'ext_dp_strip_kernel<4|8|16>', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'bound': 'hbm', 'kernel': 'ext_dp_strip_kernel<16|32|64>', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
             'launches_per_step': round(launches, 1), 'launch_ms_avg': round(strip_ms, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch),
-            'note': 'integer DP with no MFMA form: the kernel is limited by VALU issue, not by HBM (it writes 1 byte per cell after ~40 '
+            'note': 'integer DP with no MFMA form: the kernel is limited by VALU issue, not by HBM (it writes 1 byte per cell after ~34 '
                     'integer ops), so the HBM fraction is small by construction; see DESIGN.md section 5 for the VALU-rate view '
                     '(cells/s against the 16 lanes x 4 SIMD x 256 CU x clock integer rate). Durations are HIP-event spans on the '
                     'launching stream while the other 7 workers share the GPU.',
