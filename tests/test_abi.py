@@ -47,3 +47,13 @@ def test_product_does_not_import_oracle():
             assert not pat.search(open(path).read()), f'{path} uses the oracle'
     for path in (os.path.join(ROOT, 'bin', 'mpn-aligner'),):
         assert not pat.search(open(path).read())
+
+
+def test_headers_are_plain_c():
+    """The boundary is a C ABI: every header must compile as C99 on its own (and as C++)."""
+    import subprocess
+    for h in sorted(glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        for lang, std in (('c', 'c99'), ('c++', 'c++11')):
+            p = subprocess.run(['gcc', '-x', lang, f'-std={std}', '-Wall', '-Werror', '-fsyntax-only', '-'], input=f'#include "{h}"\n',
+                               capture_output=True, text=True)
+            assert p.returncode == 0, (h, lang, p.stderr[-500:])
