@@ -8,13 +8,15 @@
 A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM:
 seed-chain-extend against the resident index (HIP kernels), host hit bookkeeping, read reassignment (HIP kernels),
 best hit per read and the per-species / per-name counters, followed for N > 1 by the RCCL all-reduce of those counters.
-Workload = BASELINE.json configs[2] scaled to what the round-1 index build handles (see config.workload):
-a 10-species community (two close relatives) sampled against an index of synthetic genomes; every rank holds the
-whole index and maps its own reads (weak scaling, no data-path collective).
+Workload = BASELINE.json configs[2] at the largest index one MI355X builds inside the bench's time budget
+(config.workload states N_g): a 10-species community (incl. a 99 %-identity strain pair) sampled against an index of
+N_g synthetic genomes; every rank holds the whole index and maps its own reads (weak scaling, no data-path collective).
+Genomes and reads are generated ON THE GPU (torch); a few distinct read batches are generated once and rotated over
+the steps (the mapper keeps no state between calls, so a repeated batch costs exactly what a fresh one does).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest device time (HIP events on the stream the
-library launches on); `cpu_baseline` times the CPU oracle (oracle/mm2_oracle.c, a port) on a bounded sample of the
-same reads on this host's cores.
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest device time of THIS run (HIP events around
+each launch on the stream it is launched on); `cpu_baseline` times the CPU oracle (oracle/mm2_oracle.c, a port) on a
+bounded sample of the same reads on this host's cores.  Progress goes to stderr.
 """
 import argparse
 import json
@@ -31,83 +33,89 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+T00 = time.time()
 
 
-def build_world(args, rank):
-    from megapath_nano_amd import synth
-    from megapath_nano_amd.pipeline import Taxonomy
-    genomes = synth.make_genomes(20240901, args.genomes, args.genome_len, strain_pairs=args.strain_pairs)
-    n = len(genomes)
-    # community: 10 members with log-normal abundance, including a close-relative pair (genome 0 and its 99% copy)
+def log(msg):
+    print(f'[bench {time.time() - T00:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+def community(args):
+    """10 members with log-normal abundance, including a close-relative pair (genome 0 and its 99 % copy)."""
+    n = args.genomes
     rng = np.random.default_rng(7)
     base = n - args.strain_pairs
     members = list(range(min(9, base))) + ([base] if args.strain_pairs > 0 else [])
     weights = np.zeros(n)
     weights[members] = rng.lognormal(0.0, 1.0, size=len(members))
-    # taxonomy: every genome carries its own name and species_tax_id (the strain copy plays the close relative)
-    name_code = np.arange(n, dtype=np.int32)
-    species_code = np.arange(n, dtype=np.int32)
-    tax = Taxonomy(name_code, n, species_code, n)
-    return genomes, weights, tax
+    return members, weights
 
 
-def make_batch(genomes, weights, args, seed, device):
+def make_batch(flat, weights, args, seed, device):
+    """One batch of reads generated on the GPU -> PackedReads (device tensors + the host copy the C-ABI also takes)."""
+    import torch
     from megapath_nano_amd import synth, mapper
-    reads = synth.make_reads(seed, genomes, args.reads_per_step, mean_len=args.mean_len, weights=weights)
-    return mapper.PackedReads([r['name'] for r in reads], [r['seq'] for r in reads], device=device), reads
+    buf, off, lens = synth.make_reads_device(seed, flat, args.genome_len, args.reads_per_step, weights, device, mean_len=args.mean_len)
+    torch.cuda.synchronize()
+    names = [f'read{r:07d}' for r in range(args.reads_per_step)]
+    return mapper.PackedReads.from_arrays(names, buf.cpu().numpy(), off.cpu().numpy(), lens.cpu().numpy(), dev=(buf, off, lens))
 
 
-def cpu_baseline(genomes, reads, opt_kw, seconds_target=15.0):
-    """Oracle (port of the minimap2 path) on a bounded sample of the same reads, all host cores up to 16."""
+def cpu_baseline(genomes, packed, opt_kw, seconds_target=15.0):
+    """Oracle (port of the minimap2 path) on a bounded sample of the step batch, all host cores up to 16."""
+    import shutil
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
-    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'libmm2_oracle.so'], stdout=subprocess.DEVNULL)
     from oracle import mm2_bindings as mb
     cores = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.time()
     oidx = mb.Index(genomes)
+    idx_s = time.time() - t0
     oopt = mb.default_opt(**opt_kw)
     oopt.mid_occ = oidx.mid_occ()
-    # calibrate on a few reads, then size the sample for ~seconds_target of wall time
+    reads = [(packed.names[i], packed.seq(i)) for i in range(min(packed.n, 65536))]
     t0 = time.time()
-    for r in reads[:4]:
-        mb.map_read(oidx, oopt, r['name'], r['seq'])
+    for nm, s in reads[:4]:
+        mb.map_read(oidx, oopt, nm, s)
     per_read = (time.time() - t0) / 4
     n = int(max(8, min(len(reads), seconds_target * cores / max(per_read, 1e-4))))
     sample = reads[:n]
     t0 = time.time()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda r: mb.map_read(oidx, oopt, r['name'], r['seq'])[1], sample))
+        list(ex.map(lambda r: mb.map_read(oidx, oopt, r[0], r[1])[1], sample))
     dt = time.time() - t0
-    bases = sum(len(r['seq']) for r in sample)
+    bases = sum(len(s) for _, s in sample)
     oidx.close()
-    import shutil
-    return dict(value=bases / dt * 60 / 1e9, unit='Gbp/min', cores=cores, kind='port',
-                sample=f'{n} reads ({bases} bp) of the step batch, oracle/mm2_oracle.c seed-chain-extend, {dt:.1f} s wall',
+    return dict(value=bases / dt * 60 / 1e9, unit='Gbp/min', cores=cores, host_cpus=os.cpu_count(), kind='port',
+                sample=f'{n} reads ({bases} bp) of the step batch, oracle/mm2_oracle.c seed-chain-extend on {cores} threads, {dt:.1f} s wall; '
+                       f'its index holds only {len(genomes)} of the genomes (the community + fillers, {sum(len(g[1]) for g in genomes)} bp, built in '
+                       f'{idx_s:.1f} s): the CPU sees none of the random seed hits of the full index, which flatters the CPU',
                 minimap2_on_box=shutil.which('minimap2'))   # SURVEY 8d: a real binary would be timed beside the port; none ships in the image
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--genomes', type=int, default=250)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--genomes', type=int, default=5000)
     ap.add_argument('--genome-len', type=int, default=4000000)
     ap.add_argument('--strain-pairs', type=int, default=10)
     ap.add_argument('--reads-per-step', type=int, default=131072)
     ap.add_argument('--mean-len', type=int, default=8000)
+    ap.add_argument('--distinct-batches', type=int, default=3)
+    ap.add_argument('--pcie-steps', type=int, default=2, help='extra untimed-for-value steps fed from host buffers (PCIe-inclusive rate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
     import torch
-    from megapath_nano_amd import dist as mdist, mapper
-    from megapath_nano_amd.pipeline import align_and_assign
+    from megapath_nano_amd import dist as mdist, mapper, synth
+    from megapath_nano_amd.pipeline import Taxonomy, align_and_assign
     # MPN_DIST_BACKEND=gloo + MPN_SINGLE_DEVICE=1 rehearses the N>1 code path on a one-GPU box (all ranks on cuda:0,
     # counters reduced over gloo); the driver's real runs use nccl (= RCCL), one rank per GPU
     backend = os.environ.get('MPN_DIST_BACKEND') or None
     single = os.environ.get('MPN_SINGLE_DEVICE') == '1'
-    if single:
-        os.environ['LOCAL_RANK_SAVED'] = os.environ.get('LOCAL_RANK', '0')
     rank, world, local = mdist.init_from_env(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
@@ -118,35 +126,63 @@ def main():
     if rank == 0:
         build.build()
     mdist.barrier()
+    if rank == 0:
+        log(f'torch + libmpn ready; generating {args.genomes} x {args.genome_len} bp on the GPU')
 
-    genomes, weights, tax = build_world(args, rank)
+    # ---- targets: generated in HBM, indexed from HBM ------------------------------------------------------------
+    members, weights = community(args)
+    names, flat, lens = synth.make_genomes_device(20240901, args.genomes, args.genome_len, args.strain_pairs, device)
+    torch.cuda.synchronize()
     t0 = time.time()
-    idx = mapper.Index(genomes)
+    idx = mapper.Index.from_device(names, flat.data_ptr(), lens)
     index_s = time.time() - t0
+    if rank == 0:
+        log(f'index built in {index_s:.1f} s: {idx.n_minimizers} minimizers, {idx.n_keys} keys')
+    n = args.genomes
+    tax = Taxonomy(np.arange(n, dtype=np.int32), n, np.arange(n, dtype=np.int32), n)  # every genome its own name / species
     opt_kw = dict(best_n=50, pri_ratio=1.0)  # megapath_nano.py:1270  -N 50 -p 1 -x map-ont
     opt = mapper.default_opt(**opt_kw)
     opt.mid_occ = idx.mid_occ()
+
+    # ---- reads: a few distinct batches, generated in HBM, rotated over the steps ---------------------------------
+    n_distinct = max(1, min(args.distinct_batches, args.warmup + args.steps))
+    batches = [make_batch(flat, weights, args, 1000 * (rank + 1) + s, device) for s in range(n_distinct)]
+    # host copies of the genomes the CPU baseline indexes (the community + a few fillers), then the ASCII targets leave HBM
+    cpu_genomes = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        pick = sorted(set(members) | set(range(min(16, n))))[:max(16, len(members))]
+        view = flat.view(n, args.genome_len)
+        cpu_genomes = [(names[g], view[g].cpu().numpy()) for g in pick]
+    del flat
+    torch.cuda.empty_cache()
+    if rank == 0:
+        log(f'{n_distinct} read batches of {args.reads_per_step} reads ready ({batches[0].bases} bp each); mid_occ = {opt.mid_occ}')
+
     allreduce = mdist.make_allreduce(red_device)
     rnd = random.Random(12345)  # the same stream on every rank: tiebreakers are drawn in global row order (pipeline.sharded_tiebreak)
 
-    total = args.warmup + args.steps
-    batches = [make_batch(genomes, weights, args, 1000 * (rank + 1) + s, device) for s in range(total)]
-
-    def run(b):
-        return align_and_assign(idx, opt, b[0], tax, allreduce=allreduce, rng=rnd, shard=(rank, world))
+    def run(b, use_device=True):
+        return align_and_assign(idx, opt, b, tax, allreduce=allreduce, rng=rnd, shard=(rank, world), use_device=use_device)
 
     for s in range(args.warmup):
-        run(batches[s])
+        run(batches[s % n_distinct])
+        if rank == 0:
+            log(f'warmup step {s + 1}/{args.warmup} done')
     mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stats_acc = {}
     counts = None
-    for s in range(args.warmup, total):
-        out = run(batches[s])
+    bases = 0
+    for s in range(args.steps):
+        b = batches[(args.warmup + s) % n_distinct]
+        out = run(b)
+        bases += b.bases
         counts = out['read_count'] if counts is None else counts + out['read_count']
         for k, v in mapper.last_stats().items():
             stats_acc[k] = stats_acc.get(k, 0) + v
+        if rank == 0 and (s % 4 == 3 or s == args.steps - 1):
+            log(f'timed step {s + 1}/{args.steps} done ({(time.perf_counter() - t0) / (s + 1):.2f} s/step)')
     torch.cuda.synchronize()
     mdist.barrier()
     dt = time.perf_counter() - t0
@@ -156,41 +192,49 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=rd)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        b = torch.tensor([sum(batches[s][0].bases for s in range(args.warmup, total))], dtype=torch.int64, device=rd)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        bases = int(b.item())
-    else:
-        bases = sum(batches[s][0].bases for s in range(args.warmup, total))
+        bt = torch.tensor([bases], dtype=torch.int64, device=rd)
+        dist.all_reduce(bt, op=dist.ReduceOp.SUM)
+        bases = int(bt.item())
+    # PCIe-inclusive rate (never `value`): the same steps fed from the host buffers, read H2D inside the timed call
+    pcie = None
+    if args.pcie_steps > 0:
+        mdist.barrier()
+        t1 = time.perf_counter()
+        pb = 0
+        for s in range(args.pcie_steps):
+            b = batches[s % n_distinct]
+            run(b, use_device=False)
+            pb += b.bases
+        torch.cuda.synchronize()
+        mdist.barrier()
+        pcie = pb * world / (time.perf_counter() - t1) * 60 / 1e9
     if rank != 0:
         return
 
     K = max(1, args.steps)
     st = {k: v / K for k, v in stats_acc.items()}  # per step (rank 0)
-    # HIP-event time per stage and step (rank 0).  The events are recorded on the stream each kernel is launched on; with
-    # 8 workers in flight the spans of different streams overlap, so they do not add up to the step time.
-    kern = {
-        'sketch_kernel': st['ev_sketch_ns'], 'seed_lookup+fill': st['ev_seed_ns'], 'seg_sort_kernel': st['ev_sort_ns'],
-        'chain_segments+chain_dp_kernel': st['ev_chain_dp_ns'], 'chain_ends+backtrack': st['ev_chain_bt_ns'],
-        'ext_dp_band_kernel (+ fallbacks)': st['ev_ext_dp_ns'], 'ext_dp_strip_kernel': st['ev_ext_strip_ns'],
-        'ext_bt_kernel': st['ev_ext_bt_ns'], 'ext_ztest_kernel': st['ev_ext_ztest_ns'],
+    nsub = max(st['sub_batches'], 1)
+    rounds = max(st['dp_rounds'], 1)
+    # Candidate kernels for the roofline line: device ns from HIP events around each launch (rank 0, per step), launches per
+    # step, and ALGORITHMIC bytes per step (DESIGN.md section 5 states the per-unit figures):
+    #   sketch (count + fill pass) : 2 x 1 B per read base in + 16 B per minimizer out
+    #   seed lookup + fill         : 16 B per minimizer in, 8 B per index position gathered, 16 B per anchor out
+    #   anchor sort                : 32 B (16 in + 16 out) per record and effective radix pass (counted by the kernel)
+    #   chain DP                   : 16 B per anchor in + 16 B (f, p, t, v) out
+    #   strip DP <GL>              : 1 direction byte out per DP cell (qlen x tlen per window)
+    cand = {
+        'sketch_chunk_kernel<count|fill>': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
+        'seed_lookup_kernel+seed_fill_kernel': (st['k_seed_lookup_ns'] + st['k_seed_fill_ns'], 2 * nsub, 16 * st['minimizers'] + 24 * st['anchors']),
+        'seg_sort_kernel<4>': (st['ev_sort_ns'], nsub, 32 * st['sort_records_moved']),
+        'chain_dp_kernel': (st['k_chain_dp_ns'], nsub, 32 * st['anchors']),
+        'ext_dp_strip_kernel<16>': (st['k_strip16_ns'], rounds, st['strip16_cells']),
+        'ext_dp_strip_kernel<32>': (st['k_strip32_ns'], rounds, st['strip32_cells']),
+        'ext_dp_strip_kernel<64>': (st['k_strip64_ns'], rounds, st['strip64_cells']),
     }
-    # Dominant kernel: ext_dp_strip_kernel<16|32|64> (lanes per window; the gap-fill DP: >95 % of all DP cells and the largest share of device
-    # time in profiles/r01).  Algorithmic bytes: 1 direction byte written per cell (the windows read
-    # are qlen + tlen bases, < 1 % of that).  One sub-batch issues the three instantiations back to back; `launches` counts
-    # those triples, `achieved` = bytes per triple / its average duration (HIP events on the launching stream).
-    launches = max(st['dp_rounds'], 1)
-    strip_ms = st['ev_ext_strip_ns'] / 1e6 / launches
-    bytes_per_launch = st['strip_cells'] / launches
-    achieved = st['strip_cells'] / max(st['ev_ext_strip_ns'], 1)  # bytes/ns == GB/s
-    # HBM traffic of the same kernels from the PMC passes of the same command (profiles/r01/pmc_summary.json; separate
-    # rocprofv3 --pmc runs, FETCH_SIZE + WRITE_SIZE in KiB), per launch triple like `achieved`
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))
-        # measured HBM bytes per strip cell (1.06 at the time of writing) x the cells of one launch group of THIS run
-        traffic = pm['strip_hbm_bytes_per_cell'] * bytes_per_launch
-    except Exception:
-        pass
+    dom = max(cand, key=lambda k: cand[k][0])
+    ns, launches, abytes = cand[dom]
+    achieved = abytes / max(ns, 1)  # bytes per ns == GB/s
+    hits_per_mz = st['anchors'] / max(st['minimizers'], 1)
     line = {
         'metric': 'Gbp/min ONT reads aligned+species-assigned vs RefSeq, 1/2/4/8 MI355X',
         'value': bases / dt * 60 / 1e9,
@@ -205,32 +249,36 @@ def main():
         'dtype': 'int32',
         'data': 'synthetic',
         'config': {
-            'workload': f'configs[2] scaled: {args.reads_per_step} synthetic ONT-like reads/step/GPU (Gamma lengths, mean '
-                        f'{args.mean_len} bp, 12% errors; in-repo stand-in for badread) from a 10-member community incl. a '
-                        f'99%-identity strain pair, vs a resident index of {args.genomes} synthetic genomes x '
-                        f'{args.genome_len} bp incl. {args.strain_pairs} 99%-identity strain copies (a scaled stand-in for the full RefSeq '
-                        f'bacterial index: genomes are generated on the host per rank), '
-                        f'-N 50 -p 1 -x map-ont -c, reassignment on',
+            'workload': f'configs[2] (1M-read 10-species community vs full RefSeq bacterial, reassignment on) at N_g = {args.genomes} synthetic genomes x '
+                        f'{args.genome_len} bp = {args.genomes * args.genome_len / 1e9:.1f} Gbp of targets incl. {args.strain_pairs} 99%-identity strain '
+                        f'copies, resident on every GPU (built on the GPU in {index_s:.1f} s); {args.reads_per_step} synthetic ONT-like reads/step/GPU '
+                        f'(Gamma lengths, mean {args.mean_len} bp, 12% errors; in-repo stand-in for badread, generated on the GPU; {n_distinct} distinct '
+                        f'batches rotated over the steps), -N 50 -p 1 -x map-ont -c',
             'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': args.genomes, 'index_bp': args.genomes * args.genome_len,
-            'index_build_s': round(index_s, 2), 'parallelism': f'reads sharded over {world} GPU(s), index replicated',
+            'index_build_s': round(index_s, 2), 'index_minimizers': int(idx.n_minimizers), 'mid_occ': int(opt.mid_occ),
+            'parallelism': f'reads sharded over {world} GPU(s), index replicated', 'host_cpus': os.cpu_count(),
         },
+        'pcie_inclusive_gbp_per_min': None if pcie is None else round(pcie, 2),
         'roofline': {
-            'bound': 'hbm', 'kernel': 'ext_dp_strip_kernel<16|32|64>', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'launches_per_step': round(launches, 1), 'launch_ms_avg': round(strip_ms, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch),
-            'note': 'integer DP with no MFMA form: the kernel is limited by VALU issue, not by HBM (it writes 1 byte per cell after ~34 '
-                    'integer ops), so the HBM fraction is small by construction; see DESIGN.md section 5 for the VALU-rate view '
-                    '(cells/s against the 16 lanes x 4 SIMD x 256 CU x clock integer rate). Durations are HIP-event spans on the '
-                    'launching stream while the other 7 workers share the GPU.',
-            'kernel_ms_per_step': {k: round(v / 1e6, 2) for k, v in kern.items()},
-            'strip_gcups': round(st['strip_cells'] / max(st['ev_ext_strip_ns'], 1), 1),
+            'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+            'launches_per_step': round(launches, 1), 'launch_ms_avg': round(ns / 1e6 / launches, 3),
+            'algorithmic_bytes_per_launch': int(abytes / launches),
+            'note': 'dominant kernel = largest device time of this run among the candidates below; durations are HIP-event spans around each '
+                    'launch on its own stream while the other pipeline workers share the GPU. traffic: PMC passes are separate rocprofv3 '
+                    'runs (profiles/r02), not measured inside this process.',
+            'candidates': {k: {'ms_per_step': round(v[0] / 1e6, 2), 'launches_per_step': round(v[1], 1), 'alg_GB_per_step': round(v[2] / 1e9, 3),
+                               'GBps': round(v[2] / max(v[0], 1), 1)} for k, v in cand.items()},
+            'whole_path_alg_bytes_per_bp': round(9.73 + 13.1 * hits_per_mz + 1.75 * st['alignments'] / max(args.reads_per_step, 1), 2),
         },
         'per_step': {k: (round(v / 1e6, 2) if k.endswith('_ns') else int(v)) for k, v in st.items()},
         'reads_per_name_top': sorted(((int(c), int(i)) for i, c in enumerate(counts) if c), reverse=True)[:5],
     }
     if world == 1 and not args.no_cpu_baseline:
-        line['cpu_baseline'] = cpu_baseline(genomes, batches[args.warmup][1], opt_kw)
+        log('timing the CPU oracle on a sample')
+        line['cpu_baseline'] = cpu_baseline(cpu_genomes, batches[0], opt_kw)
     print(json.dumps(line), flush=True)
+    log('done')
 
 
 if __name__ == '__main__':

@@ -59,6 +59,12 @@ void mpn_map_opt_init(mpn_map_opt *opt);
  * HBM together with the 2-bit packed targets.  Returns NULL on failure (mpn_last_error()). */
 mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
                            int32_t k, int32_t w);
+/* The same build from targets that are already resident in HBM: d_seqs is a DEVICE pointer to the concatenated ASCII
+ * targets (target i at byte seq_off[i], seq_off[0] = 0, no gaps; seq_off and lens are host arrays).  The caller keeps
+ * ownership of d_seqs and may release it when the call returns.  This is how a target set that never exists as host
+ * strings (a decompressor or generator writing into HBM; bench.py's synthetic RefSeq stand-in) is indexed. */
+mpn_index *mpn_index_build_device(int32_t n_seq, const char *const *names, const void *d_seqs, const int64_t *seq_off,
+                                  const int32_t *lens, int32_t k, int32_t w);
 void mpn_index_destroy(mpn_index *idx);
 /* Persistent form of a built index (the reference rebuilds its index on every run: bin/lib/aligner.py:209-221; minimap2's
  * own `-d FILE` / prebuilt-index-as-target is used at bin/megapath_nano.py:1641-1645).  save: 0 or negative error;
@@ -129,6 +135,15 @@ int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
                          const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs,
                          const int64_t *d_off, const int32_t *d_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols);
 
+/* After mpn_map_batch(_ex) returned -3 the results of that call are kept by the library (process-wide, until the next
+ * mapping call): fetch them with larger buffers instead of mapping the batch again.
+ *   mpn_map_fetch_cols: cols->cap rows available; returns the number of rows, -3 if still too small (cols->n_rows = need),
+ *                       -1 if nothing is kept.
+ *   mpn_map_fetch_text: buf == NULL returns the bytes needed (incl. NUL); otherwise copies the PAF/SAM text and returns
+ *                       its length, -3 if cap is too small, -1 if nothing is kept. */
+int64_t mpn_map_fetch_cols(mpn_aln_cols *cols);
+int64_t mpn_map_fetch_text(char *buf, int64_t cap);
+
 /* Counters and timers of the last mpn_map_batch / mpn_seed_chain_batch on this thread (bench.py roofline line):
  *  [0] input bases  [1] read minimizers  [2] anchors  [3] chains  [4] DP jobs  [5] DP cells  [6] alignments reported
  *  [7] DP rounds    [8] second-pass (exact z-drop) jobs
@@ -143,6 +158,13 @@ int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
  *  [30] second pass + CIGAR download
  *  [9] device ns of the strip-kernel launches ([15] covers the other DP kernels)  [31] cells (qlen x tlen) those launches computed */
 void mpn_map_last_stats(int64_t stats[32]);
+/* the same with the slots added after round 1 (returns the number of slots the library has; copies min(n, that)):
+ *  [32] sub-batches run (= launches of every per-sub-batch kernel)
+ *  device ns of single kernels, HIP events around each launch on its stream:
+ *  [33] sketch count pass  [34] sketch fill pass  [35] seed lookup  [36] seed fill  [37] chain DP kernel alone
+ *  [38] strip DP <16>  [39] strip DP <32>  [40] strip DP <64>  and their cells [41] [42] [43]
+ *  [44] anchors that entered the sort x effective radix passes (bytes moved by the sort = 32 x this) */
+int32_t mpn_map_last_stats_ex(int64_t *stats, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -698,7 +698,12 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
     r.rs = rs1; r.re = re1;
     if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; }
     else { r.qs = qs1; r.qe = qe1; }
-    if (r.has_p) update_extra(r, qseq_strand[rev] + qs1, mi->seq4.data() + mi->seq_off[rid] + rs1, mat, (int8_t)opt->q, (int8_t)opt->e);
+    if (r.has_p) {
+        static thread_local std::vector<uint8_t> tbuf;  // target codes of the aligned interval
+        tbuf.resize((size_t)std::max(0, re1 - rs1) + 1);
+        mi->fetch_codes(mi->seq_off[rid] + rs1, re1 - rs1, tbuf.data());
+        update_extra(r, qseq_strand[rev] + qs1, tbuf.data(), mat, (int8_t)opt->q, (int8_t)opt->e);
+    }
     r.aligned = 1;
     return has_r2;
 }
@@ -863,6 +868,8 @@ struct Slot {
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
 
+static struct Kept { std::vector<int32_t> cols; int64_t n_rows = -1; std::string text; bool has_text = false; } g_kept;  // see mpn_map_batch_ex
+
 static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 3 workgroup kernel, 4 strip (else band), 5 band
 
 static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn) {
@@ -901,7 +908,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     struct Acc {
         size_t lds_need[5] = {0, 0, 0, 0, 0}, strip_lds[3] = {0, 0, 0}, band_lds[4] = {64, 64, 64, 64};
-        int64_t cells = 0, strip_cells = 0;
+        int64_t cells = 0, strip_cells = 0, strip_cells_c[3] = {0, 0, 0};
         int too_large = 0, tl_q = 0, tl_t = 0;
     };
     const int nt = std::max(1, n_threads);
@@ -946,7 +953,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             // (the rare exact second pass of a strip window gets its direction matrix from a pool of its own)
             p_bytes[j] = ((strip ? strip_bytes : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~(int64_t)15;
             A.cells += n_r * n_col;
-            if (strip) A.strip_cells += (int64_t)jb.qlen * jb.tlen;
+            if (strip) { A.strip_cells += (int64_t)jb.qlen * jb.tlen; A.strip_cells_c[glc] += (int64_t)jb.qlen * jb.tlen; }
             const size_t stateb = (size_t)(((size_t)6 * jb.tlen + 3) & ~(size_t)3) + (size_t)4 * jb.tlen;
             int cls = 4;
             for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
@@ -975,6 +982,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         for (int c = 0; c < 3; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
         for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
         M.cells += A.cells; M.strip_cells += A.strip_cells;
+        for (int c = 0; c < 3; ++c) M.strip_cells_c[c] += A.strip_cells_c[c];
         if (A.too_large) { set_error("DP window too large for LDS staging (%d x %d)", A.tl_q, A.tl_t); return -4; }
     }
     // pass B (serial, a few adds per window): scratch offsets and the launch lists (stable in job order)
@@ -998,6 +1006,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     }
     const int n_flat = base[N_LISTS];
     g_stats[4] += nj; g_stats[5] += M.cells; g_stats[31] += M.strip_cells;
+    for (int c = 0; c < 3; ++c) g_stats[41 + c] += M.strip_cells_c[c];
     Slot &SL = *tl_slot;
     if (SL.pin_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_jobs.ensure((size_t)nj * sizeof(ExtJob))) return -1;
     int32_t *flat = SL.pin_order.as<int32_t>();
@@ -1131,9 +1140,11 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         if (on_side(l)) continue;
         if (l == L_BAND - 1) ev.mark(15);  // the strip launches are timed on their own ([9]): the roofline kernel of bench.py
         if (l >= L_STRIP && l < L_BAND) {  // one launch per lane-group class: its 16 height lists are contiguous
-            if ((l - L_STRIP) % 16 == 0 && launch_list(l, d_order.p + base[l], base[l + 16] - base[l], st)) return -1;
+            if ((l - L_STRIP) % 16 == 0) {
+                if (launch_list(l, d_order.p + base[l], base[l + 16] - base[l], st)) return -1;
+                ev.mark(9, 38 + (l - L_STRIP) / 16);  // every strip instantiation is timed on its own
+            }
         } else if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
-        if (l == L_STRIP) ev.mark(9);
     }
     ev.mark(15);
     if (bt_ztest(main_lo, main_hi, st, true)) return -1;
@@ -1460,14 +1471,17 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     {
         // every worker holds its own scratch (direction matrices above all): about 400 bytes per base of a sub-batch
         // with map-ont settings.  Do not start more workers than the free HBM (plus what the slots already hold) covers.
-        size_t free_b = 0, total_b = 0, held = 0;
+        size_t free_b = 0, total_b = 0, held = 0, held_max = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             for (const Slot &S : g_slots) {
-                held += S.pool_P.cap + S.pool_P2.cap + S.pool_CIG.cap + S.pool_compact.cap + S.pool_jobs.cap + S.pool_res.cap;
-                for (const auto &c : S.arena.chunks) held += c.cap;
+                size_t h = S.pool_P.cap + S.pool_P2.cap + S.pool_CIG.cap + S.pool_compact.cap + S.pool_jobs.cap + S.pool_res.cap;
+                for (const auto &c : S.arena.chunks) h += c.cap;
+                held += h;
+                held_max = std::max(held_max, h);
             }
             const int64_t largest = n_sub > 0 ? (bases + n_sub - 1) / n_sub : bases;
-            const double per_worker = 400.0 * (double)std::max<int64_t>(largest, 1) + 2e9;
+            // what a worker took in earlier calls (anchor-heavy target sets need far more than the DP scratch) is the better guide
+            const double per_worker = std::max(400.0 * (double)std::max<int64_t>(largest, 1) + 2e9, 1.2 * (double)held_max);
             const int fit = (int)std::max(1.0, 0.9 * (double)(free_b + held) / per_worker);
             n_workers = std::min(n_workers, fit);
         }
@@ -1479,7 +1493,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     std::vector<std::string> lines(paf ? n : 0);
     std::atomic<int> next(0), failed(0);
     std::mutex mu;
-    int64_t tot_stats[32] = {0};
+    int64_t tot_stats[MPN_NSTATS] = {0};
     std::string err;
     const bool dbg_workers = getenv("MPN_DEBUG_WORKERS") != nullptr;
     const auto t_call = std::chrono::steady_clock::now();
@@ -1507,7 +1521,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         }
         tl_arena = nullptr;
         std::lock_guard<std::mutex> g(mu);
-        for (int k = 0; k < 32; ++k) tot_stats[k] += g_stats[k];
+        for (int k = 0; k < MPN_NSTATS; ++k) tot_stats[k] += g_stats[k];
     };
     {
         std::vector<std::thread> th;
@@ -1535,17 +1549,28 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         g_stats[0] = bases;
     }
     int64_t n_aln = g_stats[6];
+    // Results that do not fit the caller's buffers are kept (columns / text of this call) so that the caller can fetch them
+    // with larger buffers (mpn_map_fetch_cols / mpn_map_fetch_text) instead of mapping the batch again.
+    bool short_cols = false, short_text = false;
+    g_kept.cols.clear(); g_kept.text.clear(); g_kept.n_rows = -1; g_kept.has_text = false;
     if (cols) {
         cols->n_rows = n_aln;
-        if (n_aln > cols->cap) return -3;
+        short_cols = n_aln > cols->cap;
+        int32_t *dst[13] = {cols->read_idx, cols->qs, cols->qe, cols->rev, cols->rid, cols->rs, cols->re, cols->mlen, cols->blen, cols->mapq,
+                            cols->nm, cols->as, cols->primary};
+        if (short_cols) {
+            g_kept.cols.resize((size_t)n_aln * 13);
+            g_kept.n_rows = n_aln;
+            for (int c = 0; c < 13; ++c) dst[c] = g_kept.cols.data() + (size_t)c * (size_t)n_aln;
+        }
         int64_t k = 0;
         for (int i = 0; i < n; ++i)
             for (const Reg &r : rs[i].regs) {
-                cols->read_idx[k] = i; cols->qs[k] = r.qs; cols->qe[k] = r.qe; cols->rev[k] = (int32_t)r.rev; cols->rid[k] = r.rid;
-                cols->rs[k] = r.rs; cols->re[k] = r.re; cols->mlen[k] = r.mlen; cols->blen[k] = r.blen; cols->mapq[k] = (int32_t)r.mapq;
-                cols->nm[k] = r.has_p ? r.blen - r.mlen + r.n_ambi : -1;
-                cols->as[k] = r.has_p ? r.dp_score : -1;
-                cols->primary[k] = r.id == r.parent;
+                dst[0][k] = i; dst[1][k] = r.qs; dst[2][k] = r.qe; dst[3][k] = (int32_t)r.rev; dst[4][k] = r.rid;
+                dst[5][k] = r.rs; dst[6][k] = r.re; dst[7][k] = r.mlen; dst[8][k] = r.blen; dst[9][k] = (int32_t)r.mapq;
+                dst[10][k] = r.has_p ? r.blen - r.mlen + r.n_ambi : -1;
+                dst[11][k] = r.has_p ? r.dp_score : -1;
+                dst[12][k] = r.id == r.parent;
                 ++k;
             }
     }
@@ -1553,9 +1578,15 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     if (paf) {
         int64_t tot = 0;
         for (auto &l : lines) tot += (int64_t)l.size();
-        if (tot + 1 > paf_cap) return -3;
-        for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
-        paf[w] = 0;
+        short_text = tot + 1 > paf_cap;
+        if (short_text) {
+            g_kept.text.reserve((size_t)tot);
+            for (auto &l : lines) g_kept.text += l;
+            g_kept.has_text = true;
+        } else {
+            for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
+            paf[w] = 0;
+        }
     }
     // the per-read state (regs with their CIGARs, PAF lines) is a few hundred thousand small allocations: free them in parallel
     parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
@@ -1563,7 +1594,33 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     });
     whole.stop_into(g_stats[24]);
     if (dbg_workers) fprintf(stderr, "[call] done at %.1f ms\n", since());
-    return w;
+    return (short_cols || short_text) ? -3 : w;
+}
+
+extern "C" int64_t mpn_map_fetch_cols(mpn_aln_cols *cols) {
+    if (!cols || g_kept.n_rows < 0) { set_error("mpn_map_fetch_cols: no columns kept from the last call"); return -1; }
+    cols->n_rows = g_kept.n_rows;
+    if (cols->cap < g_kept.n_rows) return -3;
+    int32_t *dst[13] = {cols->read_idx, cols->qs, cols->qe, cols->rev, cols->rid, cols->rs, cols->re, cols->mlen, cols->blen, cols->mapq,
+                        cols->nm, cols->as, cols->primary};
+    for (int c = 0; c < 13; ++c)
+        if (g_kept.n_rows) memcpy(dst[c], g_kept.cols.data() + (size_t)c * (size_t)g_kept.n_rows, (size_t)g_kept.n_rows * 4);
+    const int64_t r = g_kept.n_rows;
+    std::vector<int32_t>().swap(g_kept.cols);
+    g_kept.n_rows = -1;
+    return r;
+}
+
+extern "C" int64_t mpn_map_fetch_text(char *buf, int64_t cap) {
+    if (!g_kept.has_text) { set_error("mpn_map_fetch_text: no text kept from the last call"); return -1; }
+    const int64_t need = (int64_t)g_kept.text.size();
+    if (!buf) return need + 1;  // size query
+    if (cap < need + 1) return -3;
+    memcpy(buf, g_kept.text.data(), (size_t)need);
+    buf[need] = 0;
+    std::string().swap(g_kept.text);
+    g_kept.has_text = false;
+    return need;
 }
 
 extern "C" int64_t mpn_sam_header(const mpn_index *idx, const char *cmdline, char *buf, int64_t cap) {

@@ -279,7 +279,8 @@ __device__ __forceinline__ uint32_t sort_digit(const u128 &r, int pass) {
 // NY = 4: anchors, key (x, low 32 bits of y).  NY = 8: index records, key (x, y).
 template <int NY>
 __global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, u128 *__restrict__ tmp,
-                                                       const int64_t *__restrict__ seg_off, int n_seg) {
+                                                       const int64_t *__restrict__ seg_off, int n_seg,
+                                                       unsigned long long *__restrict__ work) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t bins[256];
     __shared__ uint32_t wcnt[4][256];
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, 
             if (hist[tid] == (uint32_t)n) s_skip = 1;
             __syncthreads();
             if (s_skip) { __syncthreads(); continue; }
+            if (work && tid == 0) atomicAdd(work, (unsigned long long)n);  // records moved by this pass (bench.py: bytes of the sort)
             // exclusive scan of the histogram (256 entries, thread per bin)
             {
                 uint32_t v = hist[tid];
@@ -812,6 +814,60 @@ __global__ __launch_bounds__(256) void idx_emit_kernel(const u128 *__restrict__ 
             key_off[o] = i;
             ++o;
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Targets already resident in HBM as ASCII -> 2 bits per base (16 bases per word) + the list of ambiguous-base runs.
+// One lane per output word; a run start / end is a base whose N-ness differs from its predecessor's, so the lanes need
+// one byte of context each and no scan.  Starts and ends are appended unordered (the host sorts the two short lists:
+// the i-th smallest start pairs with the i-th smallest end).  counters[0|1] = number of starts | ends found (may exceed cap).
+__global__ __launch_bounds__(256) void idx_pack2_kernel(const uint8_t *__restrict__ seqs, int64_t total, uint32_t *__restrict__ words,
+                                                        int64_t n_words, unsigned long long *__restrict__ counters,
+                                                        int64_t *__restrict__ starts, int64_t *__restrict__ ends, int64_t cap) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(seqs) & 15) == 0;
+    for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g0 = wi * 16;
+        uint8_t b[16];
+        if (aligned && g0 + 16 <= total) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(seqs + g0);
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = (uint8_t)(q[k >> 2] >> (8 * (k & 3)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = g0 + k < total ? seqs[g0 + k] : (uint8_t)'A';
+        }
+        bool prev_n = g0 > 0 && g0 - 1 < total && nt4_code(seqs[g0 - 1]) > 3;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t g = g0 + k;
+            const int c = nt4_code(b[k]);
+            const bool isn = g < total && c > 3;
+            if (g < total && !isn) word |= (uint32_t)c << (2 * k);
+            if (isn != prev_n && g <= total) {
+                const unsigned long long p = atomicAdd(&counters[isn ? 0 : 1], 1ULL);
+                if ((int64_t)p < cap) (isn ? starts : ends)[p] = g;
+            }
+            prev_n = isn;
+        }
+        words[wi] = word;
+    }
+}
+
+// occurrence histogram of the index keys (mm_idx_cal_max_occ needs a quantile of it): bins 0..nbins-1, the last one open-ended
+__global__ __launch_bounds__(256) void idx_occ_hist_kernel(const int64_t *__restrict__ key_off, int64_t n_keys, int nbins,
+                                                           unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int local[1024];
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) local[k] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t occ = key_off[i + 1] - key_off[i];
+        if (occ < 1024) atomicAdd(&local[(int)occ], 1u);
+        else atomicAdd(&hist[occ < nbins - 1 ? occ : nbins - 1], 1ULL);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) if (local[k]) atomicAdd(&hist[k], (unsigned long long)local[k]);
 }
 
 }  // namespace mpn

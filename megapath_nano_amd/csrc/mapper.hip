@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <string.h>
+#include <sys/stat.h>
 #include <string>
 #include <vector>
 
@@ -23,7 +24,7 @@ hipError_t stream_sync(hipStream_t st) {
 }
 
 
-thread_local int64_t g_stats[32] = {0};
+thread_local int64_t g_stats[MPN_NSTATS] = {0};
 
 void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne) {
     words.assign((size_t)(n + 15) / 16 + 1, 0u);
@@ -45,7 +46,7 @@ static int grid_1d(int64_t n, int block, int cap = 256 * 16) {
 // sketch a batch that is already on the device; fills mz_off (device, n+1) and allocates mz.
 // h_len: host copy of the sequence lengths (chunk table).
 int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len, const int32_t *h_len, int n, int k, int w,
-                  uint32_t rid_base, DevBuf<int64_t> &mz_off, DevBuf<u128> &mz, int64_t *n_mz, hipStream_t st) {
+                  uint32_t rid_base, DevBuf<int64_t> &mz_off, DevBuf<u128> &mz, int64_t *n_mz, hipStream_t st, EvTimer *ev = nullptr) {
     const int C = 256;
     std::vector<int64_t> chunk_off((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) chunk_off[i + 1] = chunk_off[i] + (h_len[i] + C - 1) / C;
@@ -62,6 +63,7 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
                            (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, (const int64_t *)nullptr, (const int32_t *)nullptr,
                            chunk_cnt.p, (u128 *)nullptr, rid_base);
         MPN_HIP_CHECK(hipGetLastError());
+        if (ev) ev->mark(10, 33);
     }
     hipLaunchKernelGGL(sketch_chunk_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)d_chunk_off.p, n,
                        (const int32_t *)chunk_cnt.p, chunk_rel.p, cnt.p);
@@ -72,11 +74,13 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     MPN_HIP_CHECK(hipMemcpyAsync(&total, mz_off.p + n, 8, hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(stream_sync(st));
     if (mz.alloc((size_t)total)) return -1;
+    if (ev) ev->mark(10);
     if (n_chunks > 0 && total > 0) {
         hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(grid), dim3(64), lds, st, d_seqs, d_off, d_len, n,
                            (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, (const int64_t *)mz_off.p, (const int32_t *)chunk_rel.p,
                            (int32_t *)nullptr, mz.p, rid_base);
         MPN_HIP_CHECK(hipGetLastError());
+        if (ev) ev->mark(10, 34);
     }
     *n_mz = total;
     return 0;
@@ -104,8 +108,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<int64_t> mz_off;
     DevBuf<u128> mz;
     EvTimer ev(st);
-    if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st)) return -1;
-    ev.mark(10);
+    if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st, &ev)) return -1;
     g_stats[1] += n_mz;
     const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
     DevBuf<int32_t> occ;
@@ -117,6 +120,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p,
                            idx->n_keys, (const int64_t *)idx->bucket_start.p, idx->bucket_shift, mz.p, n_mz, mid_occ, occ.p, pos_start.p);
         MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(11, 35);
     }
     hipLaunchKernelGGL(seed_prefix_kernel, dim3(std::max(1, std::min(n, 256 * 32))), dim3(64), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
                        n_anchor_d.p, o.rep_len.p);
@@ -133,15 +137,15 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<uint64_t> Utmp;
     if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || F.alloc(n_a) || P.alloc(n_a) || T.alloc(n_a) || V.alloc(n_a) ||
         o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
-        o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(2) || o.used.zero(st))
+        o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(3) || o.used.zero(st))
         return -1;
     ev.mark(11);
     if (n_a > 0) {
         hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
                            pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, o.anchors.p);
         MPN_HIP_CHECK(hipGetLastError());
-        ev.mark(11);
-        hipLaunchKernelGGL(seg_sort_kernel<4>, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n);
+        ev.mark(11, 36);
+        hipLaunchKernelGGL(seg_sort_kernel<4>, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n, o.used.p + 2);
         MPN_HIP_CHECK(hipGetLastError());
     }
     ev.mark(12);
@@ -159,10 +163,11 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(chain_segments_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, avg_qspan.p, seg_big.p,
                        seg_small.p, seg_counters.p);
     MPN_HIP_CHECK(hipGetLastError());
+    ev.mark(13);
     hipLaunchKernelGGL(chain_dp_kernel, dim3(256 * 32), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, (const float *)avg_qspan.p,
                        (const ChainSeg *)seg_big.p, (const ChainSeg *)seg_small.p, seg_counters.p, cp, F.p, P.p, T.p, V.p);
     MPN_HIP_CHECK(hipGetLastError());
-    ev.mark(13);
+    ev.mark(13, 37);
     hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);
     MPN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(chain_sort_ends_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(256), 0, st, o.u.p, Utmp.p,
@@ -184,12 +189,14 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
 int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st) {
     h.anchor_off.resize((size_t)n + 1);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
-    unsigned long long used[2] = {0, 0};
+    unsigned long long used[3] = {0, 0, 0};
     if (o.anchor_off.download(h.anchor_off.data(), (size_t)n + 1, st) || o.n_chain.download(h.n_chain.data(), n, st) ||
         o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st) ||
-        o.u_pos.download(h.u_pos.data(), n, st) || o.b_pos.download(h.b_pos.data(), n, st) || o.used.download(used, 2, st))
+        o.u_pos.download(h.u_pos.data(), n, st) || o.b_pos.download(h.b_pos.data(), n, st) || o.used.download(used, 3, st))
         return -1;
     MPN_HIP_CHECK(stream_sync(st));
+    g_stats[44] += (int64_t)used[2];
+    ++g_stats[32];
     if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;
     if (o.u_compact.download(pin_u.as<uint64_t>(), (size_t)used[0], st) || o.chained.download(pin_b.as<u128>(), (size_t)used[1], st)) return -1;
     h.u_all = pin_u.as<uint64_t>(); h.b_all = pin_b.as<u128>();
@@ -247,87 +254,159 @@ void mpn_map_opt_init(mpn_map_opt *o) {
 
 static int build_bucket_table(mpn_index *idx, hipStream_t st);
 
-mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
-                           int32_t k, int32_t w) {
-    if (n_seq <= 0 || k < 1 || k > 28 || w < 1 || w > 255) { set_error("mpn_index_build: bad arguments"); return nullptr; }
-    mpn_index *idx = new mpn_index();
-    idx->k = k; idx->w = w; idx->n_seq = n_seq;
-    hipStream_t st = 0;
-    std::vector<int64_t> off((size_t)n_seq + 1, 0);
-    for (int i = 0; i < n_seq; ++i) {
-        idx->names.push_back(names[i]);
-        idx->lens.push_back(lens[i]);
-        off[i + 1] = off[i] + lens[i];
+// 2-bit packed targets + ambiguous-base runs from the ASCII targets resident in HBM; keeps the host copy too
+static int pack_targets_device(mpn_index *idx, const uint8_t *d_seqs, int64_t total, hipStream_t st) {
+    const int64_t n_words = (total + 15) / 16 + 1;
+    DevBuf<unsigned long long> cnt;
+    DevBuf<int64_t> starts, ends;
+    if (idx->d_seq2.alloc((size_t)n_words) || cnt.alloc(2)) return -1;
+    std::vector<int64_t> ns, ne;
+    for (int64_t cap = 1 << 16;;) {
+        if (cnt.zero(st) || starts.alloc((size_t)cap) || ends.alloc((size_t)cap)) return -1;
+        hipLaunchKernelGGL(idx_pack2_kernel, dim3(grid_1d(n_words, 256, 256 * 64)), dim3(256), 0, st, d_seqs, total, idx->d_seq2.p, n_words,
+                           cnt.p, starts.p, ends.p, cap);
+        MPN_HIP_CHECK(hipGetLastError());
+        unsigned long long h_cnt[2] = {0, 0};
+        if (cnt.download(h_cnt, 2, st)) return -1;
+        MPN_HIP_CHECK(stream_sync(st));
+        if (h_cnt[0] != h_cnt[1]) { set_error("index build: unbalanced ambiguous-base runs"); return -1; }
+        if ((int64_t)h_cnt[0] > cap) { cap = (int64_t)h_cnt[0] + 16; continue; }
+        ns.resize((size_t)h_cnt[0]); ne.resize((size_t)h_cnt[0]);
+        if (starts.download(ns.data(), ns.size(), st) || ends.download(ne.data(), ne.size(), st)) return -1;
+        MPN_HIP_CHECK(stream_sync(st));
+        break;
     }
-    idx->seq_off = off;
-    const int64_t total = off[n_seq];
-    // host copy of the targets as one code per base (the hit bookkeeping needs random access to them)
-    idx->seq4.resize((size_t)total);
-    std::vector<char> cat((size_t)total + 16);
-    for (int i = 0; i < n_seq; ++i) {
-        memcpy(cat.data() + off[i], seqs[i], (size_t)lens[i]);
-        for (int64_t j = 0; j < lens[i]; ++j) {
-            unsigned char c = (unsigned char)seqs[i][j] | 0x20;
-            idx->seq4[(size_t)(off[i] + j)] = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;
-        }
-    }
-    auto fail = [&]() { delete idx; return (mpn_index *)nullptr; };
-    DevBuf<uint8_t> d_seqs;
+    std::sort(ns.begin(), ns.end());
+    std::sort(ne.begin(), ne.end());
+    idx->n_nruns = (int32_t)ns.size();
+    idx->h_seq2.resize((size_t)n_words);
+    if (idx->d_seq2.download(idx->h_seq2.data(), (size_t)n_words, st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
+        idx->d_nrun_e.upload(ne.data(), ne.size(), st))
+        return -1;
+    MPN_HIP_CHECK(stream_sync(st));
+    idx->h_nrun_s.swap(ns); idx->h_nrun_e.swap(ne);
+    return 0;
+}
+
+// The whole build runs on the GPU from targets that are resident in HBM as concatenated ASCII (d_seqs, off[n_seq+1] on the
+// host): 2-bit packing, sketch, MSD bucket partition on the top bits of the hash, one workgroup per bucket for the
+// (hash, position) radix sort, key/offset/position arrays.  Peak HBM ~ 6 bytes per target base beside the input
+// (minimizer records twice while they are partitioned); the resident index is ~ 2.2 bytes per base.
+static int build_index_device(mpn_index *idx, const uint8_t *d_seqs, const std::vector<int64_t> &off, const int32_t *lens, hipStream_t st) {
+    const int n_seq = idx->n_seq, k = idx->k, w = idx->w;
+    const int64_t total = off[(size_t)n_seq];
+    if (pack_targets_device(idx, d_seqs, total, st)) return -1;
     DevBuf<int64_t> d_off;
     DevBuf<int32_t> d_len;
-    if (d_seqs.upload((const uint8_t *)cat.data(), (size_t)total + 16, st) || d_off.upload(off.data(), n_seq, st) ||
-        d_len.upload(lens, n_seq, st))
-        return fail();
-    // GPU sketch of every target
-    DevBuf<int64_t> mz_off;
-    DevBuf<u128> mz;
+    if (d_off.upload(off.data(), (size_t)n_seq, st) || d_len.upload(lens, (size_t)n_seq, st)) return -1;
+    DevBuf<u128> rec;
     int64_t n_mz = 0;
-    if (sketch_device(d_seqs.p, d_off.p, d_len.p, lens, n_seq, k, w, 0, mz_off, mz, &n_mz, st)) return fail();
-    // sort by (hash, position) on the GPU: MSD partition on the top bits of the hash, then one workgroup per bucket
-    idx->n_mz = n_mz;
+    const int hbits = 2 * k;
+    int bbits = 8, shift = 0, nb = 0;
+    DevBuf<int64_t> bucket_off;
+    std::vector<int64_t> h_bucket_off;
     {
-        const int hbits = 2 * k, bbits = std::min(12, hbits), shift = hbits - bbits, nb = 1 << bbits;
+        DevBuf<int64_t> mz_off;
+        DevBuf<u128> mz;
+        if (sketch_device(d_seqs, d_off.p, d_len.p, lens, n_seq, k, w, 0, mz_off, mz, &n_mz, st)) return -1;
+        idx->n_mz = n_mz;
+        // buckets of ~64k records: a bucket is sorted by one workgroup, and there should be many more buckets than CUs
+        while (bbits < 16 && ((int64_t)1 << (bbits + 16)) < n_mz) ++bbits;
+        bbits = std::min(bbits, hbits);
+        shift = hbits - bbits; nb = 1 << bbits;
         DevBuf<unsigned long long> hist, cursor;
-        DevBuf<int64_t> bucket_cnt, bucket_off, block_cnt, block_off;
-        DevBuf<u128> rec, tmp;
-        if (hist.alloc(nb) || hist.zero(st) || cursor.alloc((size_t)nb + 1) || bucket_off.alloc((size_t)nb + 1) || rec.alloc((size_t)n_mz) ||
-            tmp.alloc((size_t)n_mz))
-            return fail();
-        const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n_mz + 255) / 256, 256 * 16));
+        if (hist.alloc((size_t)nb) || hist.zero(st) || cursor.alloc((size_t)nb + 1) || bucket_off.alloc((size_t)nb + 1) || rec.alloc((size_t)n_mz))
+            return -1;
+        const int g = grid_1d(n_mz, 256);
         if (n_mz > 0) hipLaunchKernelGGL(idx_bucket_hist_kernel, dim3(g), dim3(256), 0, st, mz.p, n_mz, shift, hist.p);
         hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)hist.p, bucket_off.p, nb);
-        if (hipMemcpyAsync(cursor.p, bucket_off.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail();
-        if (n_mz > 0) {
-            hipLaunchKernelGGL(idx_bucket_scatter_kernel, dim3(g), dim3(256), 0, st, mz.p, n_mz, shift, cursor.p, rec.p);
-            hipLaunchKernelGGL(seg_sort_kernel<8>, dim3(nb), dim3(256), 0, st, rec.p, tmp.p, (const int64_t *)bucket_off.p, nb);
+        MPN_HIP_CHECK(hipMemcpyAsync(cursor.p, bucket_off.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToDevice, st));
+        if (n_mz > 0) hipLaunchKernelGGL(idx_bucket_scatter_kernel, dim3(g), dim3(256), 0, st, mz.p, n_mz, shift, cursor.p, rec.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        h_bucket_off.resize((size_t)nb + 1);
+        if (bucket_off.download(h_bucket_off.data(), (size_t)nb + 1, st)) return -1;
+        MPN_HIP_CHECK(stream_sync(st));
+    }   // the unsorted minimizers are released here
+    if (n_mz > 0) {
+        // sort the buckets in groups that share one bounce buffer of ~1/8 of the records
+        int64_t big = 0;
+        for (int b = 0; b < nb; ++b) big = std::max(big, h_bucket_off[(size_t)b + 1] - h_bucket_off[(size_t)b]);
+        const int64_t tmp_cap = std::max<int64_t>(big, (n_mz + 7) / 8);
+        DevBuf<u128> tmp;
+        if (tmp.alloc((size_t)tmp_cap)) return -1;
+        for (int b0 = 0; b0 < nb;) {
+            int b1 = b0 + 1;
+            while (b1 < nb && h_bucket_off[(size_t)b1 + 1] - h_bucket_off[(size_t)b0] <= tmp_cap) ++b1;
+            if (h_bucket_off[(size_t)b1] > h_bucket_off[(size_t)b0])
+                hipLaunchKernelGGL(seg_sort_kernel<8>, dim3(std::min(b1 - b0, 256 * 32)), dim3(256), 0, st, rec.p, tmp.p - h_bucket_off[(size_t)b0],
+                                   (const int64_t *)bucket_off.p + b0, b1 - b0, (unsigned long long *)nullptr);
+            b0 = b1;
         }
-        const int64_t n_blocks = (n_mz + 2047) / 2048;
-        if (block_cnt.alloc((size_t)n_blocks + 1) || block_off.alloc((size_t)n_blocks + 1)) return fail();
-        if (n_blocks > 0) hipLaunchKernelGGL(idx_flag_count_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_cnt.p);
-        hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, block_cnt.p, block_off.p, (int)n_blocks);
-        int64_t n_keys = 0;
-        if (hipMemcpyAsync(&n_keys, block_off.p + n_blocks, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            stream_sync(st) != hipSuccess) { set_error("mpn_index_build: key count failed: %s", hipGetErrorString(hipGetLastError())); return fail(); }
-        idx->n_keys = n_keys;
-        if (idx->keys.alloc((size_t)n_keys) || idx->key_off.alloc((size_t)n_keys + 1) || idx->pos.alloc((size_t)n_mz)) return fail();
-        if (n_blocks > 0) hipLaunchKernelGGL(idx_emit_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_off.p, idx->keys.p,
-                                             idx->key_off.p, idx->pos.p);
-        if (hipMemcpyAsync(idx->key_off.p + n_keys, &n_mz, 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail();
-        idx->h_key_off.resize((size_t)n_keys + 1);
-        if (idx->key_off.download(idx->h_key_off.data(), (size_t)n_keys + 1, st)) return fail();
-        if (stream_sync(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("mpn_index_build: GPU sort failed"); return fail(); }
-        if (build_bucket_table(idx, st) || idx->d_seq_off.upload(off.data(), off.size(), st)) return fail();
+        MPN_HIP_CHECK(hipGetLastError());
+        MPN_HIP_CHECK(stream_sync(st));
     }
-    {
-        std::vector<uint32_t> words;
-        std::vector<int64_t> ns, ne;
-        pack_2bit(idx->seq4.data(), total, words, ns, ne);
-        idx->n_nruns = (int32_t)ns.size();
-        if (idx->d_seq2.upload(words.data(), words.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
-            idx->d_nrun_e.upload(ne.data(), ne.size(), st))
-            return fail();
+    const int64_t n_blocks = (n_mz + 2047) / 2048;
+    DevBuf<int64_t> block_cnt, block_off;
+    if (block_cnt.alloc((size_t)n_blocks + 1) || block_off.alloc((size_t)n_blocks + 1)) return -1;
+    if (n_blocks > 0) hipLaunchKernelGGL(idx_flag_count_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_cnt.p);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, block_cnt.p, block_off.p, (int)n_blocks);
+    int64_t n_keys = 0;
+    MPN_HIP_CHECK(hipMemcpyAsync(&n_keys, block_off.p + n_blocks, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    idx->n_keys = n_keys;
+    if (idx->keys.alloc((size_t)n_keys) || idx->key_off.alloc((size_t)n_keys + 1) || idx->pos.alloc((size_t)n_mz)) return -1;
+    if (n_blocks > 0) hipLaunchKernelGGL(idx_emit_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rec.p, n_mz, block_off.p, idx->keys.p,
+                                         idx->key_off.p, idx->pos.p);
+    MPN_HIP_CHECK(hipMemcpyAsync(idx->key_off.p + n_keys, &n_mz, 8, hipMemcpyHostToDevice, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    MPN_HIP_CHECK(hipGetLastError());
+    if (build_bucket_table(idx, st) || idx->d_seq_off.upload(off.data(), off.size(), st)) return -1;
+    MPN_HIP_CHECK(stream_sync(st));
+    return 0;
+}
+
+static mpn_index *index_shell(int32_t n_seq, const char *const *names, const int32_t *lens, int32_t k, int32_t w) {
+    if (n_seq <= 0 || !names || !lens || k < 1 || k > 28 || w < 1 || w > 255) { set_error("mpn_index_build: bad arguments"); return nullptr; }
+    mpn_index *idx = new mpn_index();
+    idx->k = k; idx->w = w; idx->n_seq = n_seq;
+    idx->seq_off.assign((size_t)n_seq + 1, 0);
+    for (int i = 0; i < n_seq; ++i) {
+        if (lens[i] < 0) { set_error("mpn_index_build: negative length of target %d", i); delete idx; return nullptr; }
+        idx->names.push_back(names[i] ? names[i] : "*");
+        idx->lens.push_back(lens[i]);
+        idx->seq_off[(size_t)i + 1] = idx->seq_off[(size_t)i] + lens[i];
     }
-    if (stream_sync(st) != hipSuccess) { set_error("mpn_index_build: upload failed"); return fail(); }
+    return idx;
+}
+
+mpn_index *mpn_index_build(int32_t n_seq, const char *const *names, const char *const *seqs, const int32_t *lens,
+                           int32_t k, int32_t w) {
+    if (!seqs) { set_error("mpn_index_build: bad arguments"); return nullptr; }
+    mpn_index *idx = index_shell(n_seq, names, lens, k, w);
+    if (!idx) return nullptr;
+    hipStream_t st = 0;
+    const int64_t total = idx->seq_off.back();
+    // stage the targets through a bounded pinned buffer: sequence by sequence, no second host copy of the whole set
+    DevBuf<uint8_t> d_seqs;
+    if (d_seqs.alloc((size_t)total + 16)) { delete idx; return nullptr; }
+    for (int i = 0; i < n_seq; ++i)
+        if (lens[i] > 0 && hipMemcpyAsync(d_seqs.p + idx->seq_off[(size_t)i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice, st) != hipSuccess) {
+            set_error("mpn_index_build: upload of target %d failed", i);
+            delete idx;
+            return nullptr;
+        }
+    if (stream_sync(st) != hipSuccess || build_index_device(idx, d_seqs.p, idx->seq_off, lens, st)) { delete idx; return nullptr; }
+    return idx;
+}
+
+mpn_index *mpn_index_build_device(int32_t n_seq, const char *const *names, const void *d_seqs, const int64_t *seq_off, const int32_t *lens,
+                                  int32_t k, int32_t w) {
+    if (!d_seqs || !seq_off) { set_error("mpn_index_build_device: bad arguments"); return nullptr; }
+    mpn_index *idx = index_shell(n_seq, names, lens, k, w);
+    if (!idx) return nullptr;
+    for (int i = 0; i < n_seq; ++i)
+        if (seq_off[i] != idx->seq_off[(size_t)i]) { set_error("mpn_index_build_device: targets must be concatenated without gaps (target %d)", i); delete idx; return nullptr; }
+    if (build_index_device(idx, (const uint8_t *)d_seqs, idx->seq_off, lens, 0)) { delete idx; return nullptr; }
     return idx;
 }
 
@@ -352,11 +431,13 @@ int mpn_index_save(const mpn_index *idx, const char *path) {
     if (!idx || !path) { set_error("mpn_index_save: null argument"); return -1; }
     hipStream_t st = 0;
     const int64_t total = idx->seq_off.empty() ? 0 : idx->seq_off.back();
-    std::vector<uint32_t> words;
-    std::vector<int64_t> ns, ne;
-    pack_2bit(idx->seq4.data(), total, words, ns, ne);
+    const std::vector<uint32_t> &words = idx->h_seq2;
+    const std::vector<int64_t> &ns = idx->h_nrun_s, &ne = idx->h_nrun_e;
     std::vector<uint64_t> keys((size_t)idx->n_keys), pos((size_t)idx->n_mz);
-    if (idx->keys.download(keys.data(), keys.size(), st) || idx->pos.download(pos.data(), pos.size(), st)) return -1;
+    std::vector<int64_t> h_key_off((size_t)idx->n_keys + 1);
+    if (idx->keys.download(keys.data(), keys.size(), st) || idx->pos.download(pos.data(), pos.size(), st) ||
+        idx->key_off.download(h_key_off.data(), h_key_off.size(), st))
+        return -1;
     MPN_HIP_CHECK(stream_sync(st));
     FILE *f = fopen(path, "wb");
     if (!f) { set_error("mpn_index_save: cannot open %s", path); return -1; }
@@ -370,7 +451,7 @@ int mpn_index_save(const mpn_index *idx, const char *path) {
     put(ns.data(), ns.size() * 8); put(ne.data(), ne.size() * 8);
     put(words.data(), words.size() * 4);
     put(keys.data(), keys.size() * 8);
-    put(idx->h_key_off.data(), idx->h_key_off.size() * 8);
+    put(h_key_off.data(), h_key_off.size() * 8);
     put(pos.data(), pos.size() * 8);
     if (fclose(f) != 0) ok = false;
     if (!ok) { set_error("mpn_index_save: short write to %s", path); return -1; }
@@ -384,7 +465,7 @@ mpn_index *mpn_index_load(const char *path) {
     mpn_index *idx = new mpn_index();
     bool ok = true;
     auto get = [&](void *p, size_t bytes) { if (bytes && fread(p, 1, bytes, f) != bytes) ok = false; };
-    auto fail = [&](const char *why) { set_error("mpn_index_load: %s (%s)", why, path); fclose(f); delete idx; return (mpn_index *)nullptr; };
+    auto fail = [&](const char *why) { set_error("mpn_index_load: %s (%s)", why, path); if (f) fclose(f); delete idx; return (mpn_index *)nullptr; };
     char magic[8];
     int32_t h32[4];
     int64_t h64[4];
@@ -393,16 +474,23 @@ mpn_index *mpn_index_load(const char *path) {
     idx->k = h32[0]; idx->w = h32[1]; idx->n_seq = h32[2]; idx->n_nruns = h32[3];
     idx->n_keys = h64[0]; idx->n_mz = h64[1];
     const int64_t total = h64[2], n_words = h64[3];
-    if (idx->k < 1 || idx->k > 28 || idx->n_seq <= 0 || idx->n_keys < 0 || idx->n_mz < idx->n_keys || total < 0 || n_words < (total + 15) / 16 || n_words > (total + 15) / 16 + 1 ||
-        idx->n_nruns < 0)
+    if (idx->k < 1 || idx->k > 28 || idx->w < 1 || idx->w > 255 || idx->n_seq <= 0 || idx->n_keys < 0 || idx->n_mz < idx->n_keys || total < 0 ||
+        n_words < (total + 15) / 16 || n_words > (total + 15) / 16 + 1 || idx->n_nruns < 0)
         return fail("corrupt header");
+    {   // the counts of the header must agree with the size of the file before anything is allocated from them
+        struct stat sb;
+        if (fstat(fileno(f), &sb) != 0) return fail("cannot stat");
+        const int64_t fixed = 8 + 16 + 32 + (int64_t)idx->n_seq * 8 /* lens + name length words */ + (int64_t)idx->n_nruns * 16 + n_words * 4 +
+                              idx->n_keys * 8 + (idx->n_keys + 1) * 8 + idx->n_mz * 8;
+        if ((int64_t)sb.st_size < fixed) return fail("truncated file");
+    }
     idx->lens.resize((size_t)idx->n_seq);
     get(idx->lens.data(), idx->lens.size() * 4);
     idx->seq_off.assign((size_t)idx->n_seq + 1, 0);
     for (int i = 0; i < idx->n_seq && ok; ++i) {
         uint32_t l = 0;
         get(&l, 4);
-        if (!ok || l > (1u << 20)) return fail("corrupt name table");
+        if (!ok || l > (1u << 20) || idx->lens[(size_t)i] < 0) return fail("corrupt name table");
         std::string nm(l, '\0');
         get(&nm[0], l);
         idx->names.push_back(nm);
@@ -410,31 +498,39 @@ mpn_index *mpn_index_load(const char *path) {
     }
     if (!ok || idx->seq_off.back() != total) return fail("corrupt sequence table");
     std::vector<int64_t> ns((size_t)idx->n_nruns), ne((size_t)idx->n_nruns);
-    std::vector<uint32_t> words((size_t)n_words);
+    idx->h_seq2.resize((size_t)n_words);
     std::vector<uint64_t> keys((size_t)idx->n_keys), pos((size_t)idx->n_mz);
-    idx->h_key_off.resize((size_t)idx->n_keys + 1);
+    std::vector<int64_t> h_key_off((size_t)idx->n_keys + 1);
     get(ns.data(), ns.size() * 8); get(ne.data(), ne.size() * 8);
-    get(words.data(), words.size() * 4);
+    get(idx->h_seq2.data(), idx->h_seq2.size() * 4);
     get(keys.data(), keys.size() * 8);
-    get(idx->h_key_off.data(), idx->h_key_off.size() * 8);
+    get(h_key_off.data(), h_key_off.size() * 8);
     get(pos.data(), pos.size() * 8);
-    if (!ok || idx->h_key_off.back() != idx->n_mz) return fail("truncated file");
-    // host copy of the targets as one code per base (the hit bookkeeping needs random access to them)
-    idx->seq4.resize((size_t)total);
-    for (int64_t i = 0; i < total; ++i) idx->seq4[(size_t)i] = (uint8_t)(words[(size_t)(i >> 4)] >> (2 * (i & 15)) & 3);
-    for (size_t r = 0; r < ns.size(); ++r) {
-        if (ns[r] < 0 || ne[r] > total || ns[r] > ne[r]) return fail("corrupt N runs");
-        for (int64_t i = ns[r]; i < ne[r]; ++i) idx->seq4[(size_t)i] = 4;
+    if (!ok || h_key_off.back() != idx->n_mz) return fail("truncated file");
+    // the kernels index with these arrays: reject anything that would send them out of bounds
+    for (size_t r = 0; r < ns.size(); ++r)
+        if (ns[r] < 0 || ne[r] > total || ns[r] >= ne[r] || (r > 0 && ns[r] < ne[r - 1])) return fail("corrupt N runs");
+    if (h_key_off[0] != 0) return fail("corrupt key offsets");
+    const uint64_t hmask = idx->k < 32 ? ((uint64_t)1 << 2 * idx->k) - 1 : ~(uint64_t)0;
+    for (int64_t i = 0; i < idx->n_keys; ++i) {
+        if (h_key_off[(size_t)i + 1] <= h_key_off[(size_t)i]) return fail("corrupt key offsets");
+        if (keys[(size_t)i] > hmask || (i > 0 && keys[(size_t)i] <= keys[(size_t)i - 1])) return fail("keys are not sorted");
+    }
+    for (int64_t i = 0; i < idx->n_mz; ++i) {
+        const uint64_t rid = pos[(size_t)i] >> 32, p = (uint32_t)pos[(size_t)i] >> 1;
+        if (rid >= (uint64_t)idx->n_seq || p >= (uint64_t)idx->lens[(size_t)rid]) return fail("position outside its target");
     }
     fclose(f);
+    f = nullptr;
     hipStream_t st = 0;
-    if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(idx->h_key_off.data(), idx->h_key_off.size(), st) ||
+    if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(h_key_off.data(), h_key_off.size(), st) ||
         idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq_off.upload(idx->seq_off.data(), idx->seq_off.size(), st) ||
-        idx->d_seq2.upload(words.data(), words.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
+        idx->d_seq2.upload(idx->h_seq2.data(), idx->h_seq2.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
         idx->d_nrun_e.upload(ne.data(), ne.size(), st) || build_bucket_table(idx, st) || stream_sync(st) != hipSuccess) {
         delete idx;  // (the failing HIP call has set the error text)
         return nullptr;
     }
+    idx->h_nrun_s.swap(ns); idx->h_nrun_e.swap(ne);
     return idx;
 }
 
@@ -454,19 +550,42 @@ int32_t mpn_index_seq_name(const mpn_index *idx, int32_t i, char *buf, int32_t c
     return (int32_t)nm.size();
 }
 
+// minimap2's mm_idx_cal_max_occ: the (1 - f) quantile of the occurrence counts of the keys, + 1.  The counts are
+// histogrammed on the device (bins 0..65534 exact, the last one open-ended); the exact host path is kept for the case
+// that the quantile falls into the open bin.
 int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
     if (f <= 0.f) return INT32_MAX;
     const int64_t n = idx->n_keys;
     if (n == 0) return 1;
     std::lock_guard<std::mutex> g(idx->mu);
     for (auto &kv : idx->mid_occ_cache) if (kv.first == f) return kv.second;
-    std::vector<uint32_t> a((size_t)n);
-    for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (uint32_t)(idx->h_key_off[(size_t)i + 1] - idx->h_key_off[(size_t)i]);
     int64_t kk = (int64_t)(uint32_t)((1. - (double)f) * (double)n);
     if (kk >= n) kk = n - 1;
-    std::nth_element(a.begin(), a.begin() + kk, a.end());
-    idx->mid_occ_cache.push_back({f, (int32_t)(a[(size_t)kk] + 1)});
-    return (int32_t)(a[(size_t)kk] + 1);
+    hipStream_t st = 0;
+    const int nbins = 1 << 16;
+    if (idx->occ_hist.empty()) {
+        DevBuf<unsigned long long> hist;
+        idx->occ_hist.assign((size_t)nbins, 0);
+        if (hist.alloc((size_t)nbins) || hist.zero(st)) return -1;
+        hipLaunchKernelGGL(idx_occ_hist_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, st, (const int64_t *)idx->key_off.p, n, nbins, hist.p);
+        if (hist.download((unsigned long long *)idx->occ_hist.data(), (size_t)nbins, st) || stream_sync(st) != hipSuccess) {
+            idx->occ_hist.clear();
+            set_error("mpn_index_mid_occ: histogram failed");
+            return -1;
+        }
+    }
+    int64_t cum = 0, v = -1;
+    for (int b = 0; b < nbins; ++b) { cum += (int64_t)idx->occ_hist[(size_t)b]; if (cum > kk) { v = b; break; } }
+    if (v < 0 || v == nbins - 1) {  // open bin: exact selection on the host
+        std::vector<int64_t> h_key_off((size_t)n + 1);
+        if (idx->key_off.download(h_key_off.data(), h_key_off.size(), st) || stream_sync(st) != hipSuccess) return -1;
+        std::vector<uint32_t> a((size_t)n);
+        for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (uint32_t)(h_key_off[(size_t)i + 1] - h_key_off[(size_t)i]);
+        std::nth_element(a.begin(), a.begin() + kk, a.end());
+        v = a[(size_t)kk];
+    }
+    idx->mid_occ_cache.push_back({f, (int32_t)(v + 1)});
+    return (int32_t)(v + 1);
 }
 
 int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uint64_t *pos) {
@@ -519,6 +638,11 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     return 0;
 }
 
-void mpn_map_last_stats(int64_t stats[32]) { memcpy(stats, g_stats, sizeof(g_stats)); }
+void mpn_map_last_stats(int64_t stats[32]) { memcpy(stats, g_stats, 32 * sizeof(int64_t)); }
+int32_t mpn_map_last_stats_ex(int64_t *stats, int32_t n) {
+    const int32_t m = n < MPN_NSTATS ? n : MPN_NSTATS;
+    if (stats && m > 0) memcpy(stats, g_stats, (size_t)m * sizeof(int64_t));
+    return MPN_NSTATS;
+}
 
 }  // extern "C"

@@ -19,9 +19,20 @@ struct mpn_index {
     int32_t n_seq = 0;
     std::vector<std::string> names;
     std::vector<int32_t> lens;
-    std::vector<int64_t> seq_off;     // host: offset of each target in seq4
-    std::vector<uint8_t> seq4;        // host: one code per base
-    std::vector<int64_t> h_key_off;   // host copy (mid_occ quantile)
+    std::vector<int64_t> seq_off;     // host: offset of each target in concatenated coordinates
+    // host copy of the packed targets (the CIGAR fix-up of the hit bookkeeping reads target slices): 2 bits per base +
+    // the ambiguous-base runs, i.e. 0.25 byte per target base instead of a byte
+    std::vector<uint32_t> h_seq2;
+    std::vector<int64_t> h_nrun_s, h_nrun_e;
+    // codes (0..4) of concatenated positions [g, g + len) into out
+    void fetch_codes(int64_t g, int64_t len, uint8_t *out) const {
+        for (int64_t i = 0; i < len; ++i) out[i] = (uint8_t)(h_seq2[(size_t)((g + i) >> 4)] >> (2 * ((g + i) & 15)) & 3);
+        if (h_nrun_s.empty() || len <= 0) return;
+        size_t lo = 0, hi = h_nrun_s.size();  // first run that ends after g
+        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (h_nrun_e[mid] <= g) lo = mid + 1; else hi = mid; }
+        for (; lo < h_nrun_s.size() && h_nrun_s[lo] < g + len; ++lo)
+            for (int64_t i = h_nrun_s[lo] > g ? h_nrun_s[lo] : g; i < h_nrun_e[lo] && i < g + len; ++i) out[i - g] = 4;
+    }
     int64_t n_keys = 0, n_mz = 0;
     mpn::DevBuf<uint64_t> keys, pos;
     mpn::DevBuf<int64_t> key_off;
@@ -32,6 +43,7 @@ struct mpn_index {
     int32_t n_nruns = 0;
     mutable std::mutex mu;
     mutable std::vector<std::pair<float, int32_t>> mid_occ_cache;
+    mutable std::vector<uint64_t> occ_hist;   // occurrence histogram of the keys (filled on first use)
 };
 
 namespace mpn {
@@ -58,7 +70,8 @@ struct HostChains {
     void read_chains(int i, uint64_t *u_out, u128 *b_out) const;
 };
 
-extern thread_local int64_t g_stats[32];
+constexpr int MPN_NSTATS = 64;
+extern thread_local int64_t g_stats[MPN_NSTATS];
 
 // 2-bit packing of 0..4 codes (N -> 0 + run list)
 void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne);
@@ -73,26 +86,29 @@ hipError_t stream_sync(hipStream_t st);
 struct EvTimer {
     hipStream_t st;
     std::vector<hipEvent_t> ev;
-    std::vector<int> slot;  // slot[i]: g_stats index charged with ev[i] -> ev[i+1]; -1 = gap (not charged)
-    explicit EvTimer(hipStream_t s) : st(s) { push(-1); }
-    void push(int sl) {
+    std::vector<int> slot, slot2;  // slot[i] (and slot2[i]): g_stats indices charged with ev[i] -> ev[i+1]; -1 = not charged
+    explicit EvTimer(hipStream_t s) : st(s) { push(); }
+    void push() {
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
         (void)hipEventRecord(e, st);
         ev.push_back(e);
-        slot.push_back(sl);
+        slot.push_back(-1); slot2.push_back(-1);
     }
-    void mark(int stat_index) { slot.back() = stat_index; push(-1); }  // the span that ends here goes to stat_index
-    void skip() { push(-1); }                                          // the span that ends here is not charged
+    // the span that ends here goes to stat_index (a kernel family) and, if given, to `single` (one kernel's own slot)
+    void mark(int stat_index, int single = -1) { slot.back() = stat_index; slot2.back() = single; push(); }
+    void skip() { push(); }                                            // the span that ends here is not charged
     void resolve() {  // call after the stream has been synchronised
         for (size_t i = 0; i + 1 < ev.size(); ++i) {
-            if (slot[i] < 0) continue;
+            if (slot[i] < 0 && slot2[i] < 0) continue;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) g_stats[slot[i]] += (int64_t)(ms * 1e6);
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) continue;
+            if (slot[i] >= 0) g_stats[slot[i]] += (int64_t)(ms * 1e6);
+            if (slot2[i] >= 0) g_stats[slot2[i]] += (int64_t)(ms * 1e6);
         }
         for (size_t i = 0; i + 1 < ev.size(); ++i) (void)hipEventDestroy(ev[i]);
         hipEvent_t last = ev.back();
-        ev.assign(1, last); slot.assign(1, -1);
+        ev.assign(1, last); slot.assign(1, -1); slot2.assign(1, -1);
     }
     ~EvTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };

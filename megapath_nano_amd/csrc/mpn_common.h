@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace mpn {
@@ -26,10 +27,26 @@ void set_error(const char *fmt, ...);
 struct Arena {
     struct Chunk { void *p; size_t cap; };
     std::vector<Chunk> chunks;
-    size_t cur = 0, off = 0;
-    void reset() { cur = 0; off = 0; }
+    size_t cur = 0, off = 0, used = 0;  // used: bytes handed out since the last reset (incl. alignment)
+    // Rewind.  A pass that spilled over several chunks leaves holes the next pass may not be able to use (requests come in
+    // a different size mix every sub-batch), so the chunks are then merged into ONE slab with head-room: after a few
+    // sub-batches a worker owns a single slab and bump-allocates from it, and the footprint stops growing.  (hipFree
+    // synchronises the device, which is why this happens here, between sub-batches, and only while the slab still grows.)
+    void reset() {
+        if (chunks.size() > 1) {
+            size_t total = 0;
+            for (const Chunk &c : chunks) { total += c.cap; (void)hipFree(c.p); }
+            chunks.clear();
+            const size_t want = std::max(used + used / 4, total / 2) + ((size_t)64 << 20);
+            Chunk c{nullptr, want};
+            if (hipMalloc(&c.p, c.cap) == hipSuccess) chunks.push_back(c);
+            else (void)hipGetLastError();  // take() will report the failure if the memory is really gone
+        }
+        cur = 0; off = 0; used = 0;
+    }
     void *take(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
+        used += bytes;
         for (; cur < chunks.size(); ++cur, off = 0)
             if (off + bytes <= chunks[cur].cap) { void *r = (char *)chunks[cur].p + off; off += bytes; return r; }
         Chunk c;

@@ -39,6 +39,8 @@ def _bind():
         lib.mpn_map_opt_init.restype = None
         lib.mpn_index_build.argtypes = [ct.c_int32, ct.POINTER(ct.c_char_p), ct.POINTER(ct.c_char_p), P, ct.c_int32, ct.c_int32]
         lib.mpn_index_build.restype = P
+        lib.mpn_index_build_device.argtypes = [ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, ct.c_int32, ct.c_int32]
+        lib.mpn_index_build_device.restype = P
         lib.mpn_index_destroy.argtypes = [P]
         lib.mpn_index_destroy.restype = None
         lib.mpn_index_n_minimizers.argtypes = [P]
@@ -66,16 +68,22 @@ def _bind():
         lib.mpn_sketch_batch.restype = ct.c_int64
         lib.mpn_seed_chain_batch.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, P, P, P, P, P, P, P, ct.c_int64, P, P, ct.c_int64]
         lib.mpn_seed_chain_batch.restype = ct.c_int
-        if hasattr(lib, 'mpn_map_batch'):
+        if True:
             lib.mpn_map_batch.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, ct.c_int64]
             lib.mpn_map_batch.restype = ct.c_int64
         lib.mpn_map_batch_ex.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P,
                                          ct.c_int64, ct.POINTER(AlnCols)]
         lib.mpn_map_batch_ex.restype = ct.c_int64
+        lib.mpn_map_fetch_cols.argtypes = [ct.POINTER(AlnCols)]
+        lib.mpn_map_fetch_cols.restype = ct.c_int64
+        lib.mpn_map_fetch_text.argtypes = [ct.c_char_p, ct.c_int64]
+        lib.mpn_map_fetch_text.restype = ct.c_int64
         lib.mpn_ext_dp_batch.argtypes = [ct.POINTER(MapOpt), ct.c_int32, P, P, P, P, P, P, P, P, P, P, ct.c_int32, P, P, ct.c_int64, P]
         lib.mpn_ext_dp_batch.restype = ct.c_int
         lib.mpn_map_last_stats.argtypes = [P]
         lib.mpn_map_last_stats.restype = None
+        lib.mpn_map_last_stats_ex.argtypes = [P, ct.c_int32]
+        lib.mpn_map_last_stats_ex.restype = ct.c_int32
         _bound = True
     return lib
 
@@ -111,14 +119,31 @@ class Index:
         lib = _bind()
         n = len(genomes)
         self.names = [g[0] for g in genomes]
-        self._seqs = [bytes(g[1]) if not isinstance(g[1], bytes) else g[1] for g in genomes]
-        self.lens = np.array([len(s) for s in self._seqs], dtype=np.int32)
+        seqs_b = [bytes(g[1]) if not isinstance(g[1], bytes) else g[1] for g in genomes]  # alive for the call only
+        self.lens = np.array([len(s) for s in seqs_b], dtype=np.int32)
         names = (ct.c_char_p * n)(*[x.encode() for x in self.names])
-        seqs = (ct.c_char_p * n)(*self._seqs)
+        seqs = (ct.c_char_p * n)(*seqs_b)
         self.k, self.w = k, w
         self.h = lib.mpn_index_build(n, names, seqs, self.lens.ctypes.data, k, w)
         if not self.h:
             raise _ffi.MpnError('mpn_index_build failed: ' + _ffi.last_error())
+
+    @classmethod
+    def from_device(cls, names, d_seqs_ptr, lens, k=15, w=10):
+        """Index of targets that are resident in HBM as concatenated ASCII (device pointer; target i at sum(lens[:i]))."""
+        lib = _bind()
+        self = cls.__new__(cls)
+        n = len(names)
+        self.names = list(names)
+        self.lens = np.ascontiguousarray(lens, dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum(self.lens.astype(np.int64))
+        cn = (ct.c_char_p * n)(*[x.encode() for x in self.names])
+        self.k, self.w = k, w
+        self.h = lib.mpn_index_build_device(n, cn, d_seqs_ptr, off.ctypes.data, self.lens.ctypes.data, k, w)
+        if not self.h:
+            raise _ffi.MpnError('mpn_index_build_device failed: ' + _ffi.last_error())
+        return self
 
     def sam_header(self, cmdline=None):
         cap = 64 * len(self.names) + sum(len(n) for n in self.names) + 4096 + (len(cmdline) if cmdline else 0)
@@ -139,7 +164,7 @@ class Index:
         if not h:
             raise _ffi.MpnError('mpn_index_load failed: ' + _ffi.last_error())
         self = cls.__new__(cls)
-        self.h, self._seqs = h, None
+        self.h = h
         n = lib.mpn_index_n_seq(h)
         buf = ct.create_string_buffer(1 << 16)
         self.names, lens = [], []
@@ -230,20 +255,8 @@ def seed_chain_batch(idx, opt, seqs):
 
 def map_batch(idx, opt, names, seqs):
     """-> PAF text of the whole batch (reads in input order)"""
-    lib = _bind()
-    buf, off, lens = pack_seqs(seqs)
-    n = len(seqs)
-    cnames = (ct.c_char_p * n)(*[x.encode() for x in names])
-    cap = int(lens.astype(np.int64).sum()) * (6 if opt.out_sam else 4) + 4096 * n + 4096
-    while True:
-        out = ct.create_string_buffer(cap)
-        r = lib.mpn_map_batch(idx.h, ct.byref(opt), n, cnames, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, out, cap)
-        if r == -3:
-            cap *= 4
-            continue
-        if r < 0:
-            raise _ffi.MpnError(f'mpn_map_batch rc={r}: {_ffi.last_error()}')
-        return out.raw[:r].decode()
+    packed = PackedReads(names, seqs)
+    return map_batch_ex(idx, opt, packed, want_paf=True, want_cols=False)[0]
 
 
 class PackedReads:
@@ -253,6 +266,23 @@ class PackedReads:
         self.n = len(seqs)
         self.names = list(names)
         self.buf, self.off, self.lens = pack_seqs(seqs)
+        self._finish(device)
+
+    @classmethod
+    def from_arrays(cls, names, buf, off, lens, dev=None):
+        """buf: concatenated ASCII (uint8, padded to a 4-byte multiple past the last base), off int64, lens int32 (host
+        numpy); dev: the same three as torch tensors already resident in HBM, or None."""
+        self = cls.__new__(cls)
+        self.n = len(lens)
+        self.names = list(names)
+        self.buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self.off = np.ascontiguousarray(off, dtype=np.int64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.int32)
+        self._finish(None)
+        self.dev = dev
+        return self
+
+    def _finish(self, device):
         self.cnames = (ct.c_char_p * self.n)(*[x.encode() for x in self.names])
         self.bases = int(self.lens.astype(np.int64).sum())
         self.dev = None
@@ -262,37 +292,57 @@ class PackedReads:
                         torch.from_numpy(self.lens).to(device))
             torch.cuda.synchronize(device)
 
+    def seq(self, i):
+        return self.buf[self.off[i]:self.off[i] + self.lens[i]]
 
-def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True):
+
+_rows_per_read = 2.0  # running estimate used to size the column arrays (a short guess costs a copy, not a second mapping)
+
+
+def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=True):
     """-> (paf text or None, dict of int32 column arrays or None)"""
+    global _rows_per_read
     lib = _bind()
     n = packed.n
-    d = [0, 0, 0] if packed.dev is None else [t.data_ptr() for t in packed.dev]
-    paf_cap = packed.bases * (6 if opt.out_sam else 4) + 4096 * n + 4096 if want_paf else 0
-    rows_cap = max(64, n * 4)
-    while True:
-        out = ct.create_string_buffer(paf_cap) if want_paf else None
-        cols = AlnCols()
-        arrs = {}
-        if want_cols:
-            cols.cap = rows_cap
-            for c in COL_NAMES:
-                arrs[c] = np.zeros(rows_cap, dtype=np.int32)
-                setattr(cols, c, arrs[c].ctypes.data)
-        r = lib.mpn_map_batch_ex(idx.h, ct.byref(opt), n, packed.cnames, packed.buf.ctypes.data, packed.off.ctypes.data,
-                                 packed.lens.ctypes.data, d[0], d[1], d[2], out, paf_cap, ct.byref(cols) if want_cols else None)
-        if r == -3:
-            if want_cols and cols.n_rows > rows_cap:
-                rows_cap = int(cols.n_rows) + 16
-            else:
-                paf_cap = paf_cap * 4 + 4096
-            continue
-        if r < 0:
-            raise _ffi.MpnError(f'mpn_map_batch_ex rc={r}: {_ffi.last_error()}')
-        paf = out.raw[:r].decode() if want_paf else None
-        if want_cols:
-            arrs = {k: v[:cols.n_rows] for k, v in arrs.items()}
-        return paf, (arrs if want_cols else None)
+    d = [0, 0, 0] if (packed.dev is None or not use_device) else [t.data_ptr() for t in packed.dev]
+    paf_cap = (packed.bases // 2 + 512 * n + 4096 if not opt.out_sam else packed.bases * 3 + 1024 * n + 4096) if want_paf else 0
+    rows_cap = max(64, int(n * _rows_per_read * 1.25) + 16)
+
+    def make_cols(cap):
+        cols, arrs = AlnCols(), {}
+        cols.cap = cap
+        for c in COL_NAMES:
+            arrs[c] = np.empty(cap, dtype=np.int32)
+            setattr(cols, c, arrs[c].ctypes.data)
+        return cols, arrs
+
+    out = ct.create_string_buffer(paf_cap) if want_paf else None
+    cols, arrs = make_cols(rows_cap) if want_cols else (None, None)
+    r = lib.mpn_map_batch_ex(idx.h, ct.byref(opt), n, packed.cnames, packed.buf.ctypes.data, packed.off.ctypes.data,
+                             packed.lens.ctypes.data, d[0], d[1], d[2], out, paf_cap, ct.byref(cols) if want_cols else None)
+    text = None
+    if r == -3:  # the library kept what did not fit: fetch it, do not map again
+        if want_cols and cols.n_rows > rows_cap:
+            cols, arrs = make_cols(int(cols.n_rows))
+            if lib.mpn_map_fetch_cols(ct.byref(cols)) < 0:
+                raise _ffi.MpnError('mpn_map_fetch_cols: ' + _ffi.last_error())
+        need = lib.mpn_map_fetch_text(None, 0) if want_paf else -1
+        if need > 0:
+            out = ct.create_string_buffer(need)
+            r = lib.mpn_map_fetch_text(out, need)
+            if r < 0:
+                raise _ffi.MpnError('mpn_map_fetch_text: ' + _ffi.last_error())
+        elif want_paf:
+            r = len(out.value)
+    elif r < 0:
+        raise _ffi.MpnError(f'mpn_map_batch_ex rc={r}: {_ffi.last_error()}')
+    if want_paf:
+        text = out.raw[:r].decode()
+    if want_cols:
+        nr = int(cols.n_rows)
+        _rows_per_read = max(_rows_per_read, nr / max(n, 1))
+        arrs = {k: v[:nr] for k, v in arrs.items()}
+    return text, (arrs if want_cols else None)
 
 
 def ext_dp_batch(opt, queries, targets, w, zdrop, end_bonus, flag, force_kernel=0):
@@ -326,10 +376,13 @@ STAT_NAMES = {0: 'bases', 1: 'minimizers', 2: 'anchors', 3: 'chains', 4: 'dp_job
               16: 'wall_h2d_ns', 17: 'wall_seed_chain_ns', 18: 'wall_d2h_chains_ns', 19: 'wall_host_hits_ns',
               20: 'wall_host_plan_ns', 21: 'wall_ext_stage_ns', 22: 'wall_host_stitch_ns', 23: 'wall_host_final_ns',
               24: 'wall_total_ns', 27: 'wall_ext_host_prep_ns', 28: 'wall_ext_enqueue_ns', 29: 'wall_ext_gpu_wait_ns',
-              30: 'wall_ext_finish_ns', 9: 'ev_ext_strip_ns', 31: 'strip_cells'}
+              30: 'wall_ext_finish_ns', 9: 'ev_ext_strip_ns', 31: 'strip_cells', 32: 'sub_batches',
+              33: 'k_sketch_count_ns', 34: 'k_sketch_fill_ns', 35: 'k_seed_lookup_ns', 36: 'k_seed_fill_ns',
+              37: 'k_chain_dp_ns', 38: 'k_strip16_ns', 39: 'k_strip32_ns', 40: 'k_strip64_ns', 41: 'strip16_cells',
+              42: 'strip32_cells', 43: 'strip64_cells', 44: 'sort_records_moved'}
 
 
 def last_stats():
-    s = np.zeros(32, dtype=np.int64)
-    _bind().mpn_map_last_stats(s.ctypes.data)
+    s = np.zeros(64, dtype=np.int64)
+    _bind().mpn_map_last_stats_ex(s.ctypes.data, 64)
     return {name: int(s[i]) for i, name in STAT_NAMES.items()}

@@ -54,10 +54,10 @@ class Taxonomy:
 
 
 def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_threshold=0.0, min_alignment_score=0,
-                     allreduce=None, rng=None, reassign=True, shard=(0, 1)):
+                     allreduce=None, rng=None, reassign=True, shard=(0, 1), use_device=True):
     """One step of the hot path for one batch of reads.  Returns dict(read_count, aligned_bp, n_rows, n_relations).
     With shard=(rank, world) and an all-reduce, `rng` must be seeded identically on every rank (see sharded_tiebreak)."""
-    _, c = mapper.map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True)
+    _, c = mapper.map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=use_device)
     keep = c['as_'] >= min_alignment_score                                   # aligner.py:311-312
     read_idx = c['read_idx'][keep]
     rid = c['rid'][keep]

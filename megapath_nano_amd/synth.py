@@ -99,3 +99,102 @@ def make_reads(seed, genomes, n_reads, mean_len=8000, min_len=200, max_len=None,
         reads.append(dict(name=f'read{r:07d}', seq=ont_errors(rng, frag, sub, ins, dele), genome=gi, start=s, end=s + L,
                           strand=strand))
     return reads
+
+
+# ---- the same generators on the GPU (torch): bench.py's workload is tens of Gbp of targets and ~1 Gbp of reads per batch,
+# which numpy cannot produce inside the bench's time budget.  Same distributions as above (not the same random streams).
+def make_genomes_device(seed, n_genomes, length, strain_pairs, device, repeats=True, chunk=64):
+    """-> (names, uint8 tensor [n_genomes * length] of concatenated ASCII on `device`, int32 lens)."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    n_base = n_genomes - strain_pairs
+    out = torch.empty(n_genomes * length, dtype=torch.uint8, device=device)
+    alpha = torch.tensor(list(b'ACGT'), dtype=torch.uint8, device=device)
+    view = out.view(n_genomes, length)
+    for g0 in range(0, n_base, chunk):
+        g1 = min(n_base, g0 + chunk)
+        gc = torch.rand(g1 - g0, 1, generator=gen, device=device) * 0.3 + 0.35
+        u = torch.rand(g1 - g0, length, generator=gen, device=device)
+        # A | C | G | T with P(C) = P(G) = gc / 2
+        code = (u >= (1 - gc) / 2).to(torch.uint8) + (u >= 0.5).to(torch.uint8) + (u >= 0.5 + gc / 2).to(torch.uint8)
+        view[g0:g1] = alpha[code.long()]
+        del u, code
+        if repeats and length > 3000:
+            rep_len, n_copies = min(1500, max(50, length // 20)), 10
+            rep = alpha[torch.randint(0, 4, (g1 - g0, 1, rep_len), generator=gen, device=device)]
+            starts = torch.randint(0, length - rep_len, (g1 - g0, n_copies, 1), generator=gen, device=device)
+            cols = (starts + torch.arange(rep_len, device=device)).view(g1 - g0, -1)
+            view[g0:g1].scatter_(1, cols, rep.expand(-1, n_copies, -1).reshape(g1 - g0, -1))
+    for i in range(strain_pairs):  # 99 %-identity copies of the first genomes
+        g = view[i].clone()
+        n_mut = length // 100
+        pos = torch.randint(0, length, (n_mut,), generator=gen, device=device)
+        cur = (g[pos] == alpha[1]).long() + 2 * (g[pos] == alpha[2]).long() + 3 * (g[pos] == alpha[3]).long()
+        g[pos] = alpha[(cur + torch.randint(1, 4, (n_mut,), generator=gen, device=device)) % 4]
+        view[n_base + i] = g
+    names = [f'NZ_SYN{i:05d}.1' for i in range(n_base)] + [f'NZ_STR{i:05d}.1' for i in range(strain_pairs)]
+    return names, out, np.full(n_genomes, length, dtype=np.int32)
+
+
+def make_reads_device(seed, genomes_flat, genome_len, n_reads, weights, device, mean_len=8000, min_len=200,
+                      sub=0.04, ins=0.03, dele=0.05, chunk_reads=8192):
+    """ONT-like reads sampled from device-resident genomes.
+    -> (uint8 tensor of the concatenated reads (padded by 16 bytes), int64 offsets, int32 lengths) on `device`."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    w = torch.as_tensor(np.asarray(weights, dtype=np.float64) / float(np.sum(weights)), device=device, dtype=torch.float32)
+    gamma = torch.distributions.Gamma(torch.tensor(1.6, device=device), torch.tensor(1.6 / mean_len, device=device))
+    torch.manual_seed(int(seed))  # torch.distributions draws from the default generator
+    L = gamma.sample((n_reads,)).clamp_(min=min_len, max=genome_len).long()
+    gi = torch.multinomial(w, n_reads, replacement=True, generator=gen)
+    start = (torch.rand(n_reads, generator=gen, device=device, dtype=torch.float64) * (genome_len - L + 1).double()).long()
+    rev = torch.rand(n_reads, generator=gen, device=device) < 0.5
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b'ACGT', b'TGCA'):
+        comp[a] = b
+    alpha = torch.tensor(list(b'ACGT'), dtype=torch.uint8, device=device)
+    code_of = torch.zeros(256, dtype=torch.long, device=device)
+    for k, a in enumerate(b'ACGT'):
+        code_of[a] = k
+    pieces, out_lens = [], []
+    for r0 in range(0, n_reads, chunk_reads):
+        r1 = min(n_reads, r0 + chunk_reads)
+        Lc = L[r0:r1]
+        off = torch.cumsum(Lc, 0) - Lc
+        T = int(Lc.sum())
+        rid = torch.repeat_interleave(torch.arange(r1 - r0, device=device), Lc)
+        p = torch.arange(T, device=device) - off[rid]
+        g0 = gi[r0:r1] * genome_len + start[r0:r1]
+        rv = rev[r0:r1][rid]
+        src = torch.where(rv, (g0 + Lc - 1)[rid] - p, g0[rid] + p)
+        frag = genomes_flat[src]
+        frag = torch.where(rv, comp[frag.long()], frag)
+        del src, p
+        r = torch.rand(T, generator=gen, device=device)
+        keep = r >= dele
+        subm = keep & (r < dele + sub)
+        n_sub = int(subm.sum())
+        frag[subm] = alpha[(code_of[frag[subm].long()] + torch.randint(1, 4, (n_sub,), generator=gen, device=device)) % 4]
+        n_ins = torch.where(torch.rand(T, generator=gen, device=device) < ins,
+                            torch.empty(T, device=device).geometric_(0.6, generator=gen).long(), torch.zeros((), dtype=torch.long, device=device))
+        counts = keep.long() + torch.where(keep, n_ins, torch.zeros((), dtype=torch.long, device=device))
+        out = torch.repeat_interleave(frag, counts)
+        cstart = torch.cumsum(counts, 0) - counts
+        first = torch.zeros(out.numel(), dtype=torch.bool, device=device)
+        first[cstart[counts > 0]] = True
+        n_insd = int((~first).sum())
+        out[~first] = alpha[torch.randint(0, 4, (n_insd,), generator=gen, device=device)]
+        # new length of every read: sum of its counts
+        csum = torch.cumsum(counts, 0)
+        ends = off + Lc - 1
+        tot_at_end = csum[ends]
+        new_len = tot_at_end - torch.cat([torch.zeros(1, dtype=torch.long, device=device), tot_at_end[:-1]])
+        pieces.append(out)
+        out_lens.append(new_len)
+        del rid, rv, frag, r, keep, subm, n_ins, counts, cstart, first, csum
+    lens = torch.cat(out_lens)
+    buf = torch.cat(pieces + [torch.full((16,), ord('A'), dtype=torch.uint8, device=device)])
+    offs = torch.cumsum(lens, 0) - lens
+    return buf, offs.contiguous(), lens.to(torch.int32).contiguous()
