@@ -12,7 +12,6 @@ With `paf_path_and_prefix` set the reference runs minimap2 with `-a` and keeps `
 this mirror (second text pass of the same batch with `out_sam`).  Not produced: `<prefix>.bam/.bai` (the reference pipes
 the SAM through samtools, :246-252).
 """
-import gzip
 import hashlib
 import os
 import random
@@ -21,7 +20,7 @@ import shlex
 import numpy as np
 import pandas
 
-from . import mapper
+from . import fastx, mapper
 
 align_list_col_name_no_assembly_id = ['read_id', 'read_length', 'read_from', 'read_to', 'strand', 'sequence_id',
                                       'sequence_length', 'sequence_from', 'sequence_to', 'match', 'mapq', 'edit_dist',
@@ -32,49 +31,31 @@ list_col = ('read_id', 'read_length', 'read_from', 'read_to', 'strand', 'sequenc
 _INDEX_CACHE = {}
 
 
-def _open(path):
-    with open(path, 'rb') as f:
-        magic = f.read(2)
-    return gzip.open(path, 'rb') if magic == b'\x1f\x8b' else open(path, 'rb')
+read_fastx = fastx.read_fastx
 
 
-def read_fastx(path):
-    """-> list of (name, bytes) from FASTA or FASTQ, plain or gzip (concatenated gzip members included)."""
-    out = []
-    with _open(path) as f:
-        data = f.read()
-    if not data:
-        return out
-    if data[:1] == b'>':
-        for rec in data.split(b'\n>'):
-            rec = rec.lstrip(b'>')
-            if not rec:
-                continue
-            head, _, body = rec.partition(b'\n')
-            out.append((head.split()[0].decode() if head.split() else '', body.replace(b'\n', b'').replace(b'\r', b'')))
-    elif data[:1] == b'@':
-        lines = data.split(b'\n')
-        i = 0
-        while i + 1 < len(lines):
-            if not lines[i].startswith(b'@'):
-                i += 1
-                continue
-            name = lines[i][1:].split()[0].decode() if lines[i][1:].split() else ''
-            seq = []
-            i += 1
-            while i < len(lines) and not lines[i].startswith(b'+'):
-                seq.append(lines[i].strip())
-                i += 1
-            seq = b''.join(seq)
-            i += 1  # '+'
-            got = 0
-            while i < len(lines) and got < len(seq):
-                got += len(lines[i].strip())
-                i += 1
-            out.append((name, seq))
-    else:
-        raise ValueError(f'{path}: neither FASTA nor FASTQ')
-    return out
+def load_target(path, k, w):
+    """The target of an aligner call -> mapper.Index.  The path is opened exactly once (it is a FIFO in the reference's
+    human/decoy call, aligner.py:143-144): a saved index is loaded (megapath_nano.py:1641-1645), sequences are indexed."""
+    kind, stream = fastx.open_once(path)
+    try:
+        if kind == 'index':
+            if not fastx.is_fifo(path):
+                stream.close()
+                return mapper.Index.load(path)
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix='.mpi') as tmp:  # mpn_index_load wants a seekable file
+                while True:
+                    chunk = stream.read(1 << 24)
+                    if not chunk:
+                        break
+                    tmp.write(chunk)
+                tmp.flush()
+                return mapper.Index.load(tmp.name)
+        return mapper.Index([(n, sq) for n, sq, _ in fastx.iter_fastx(stream)], k=k, w=w)
+    finally:
+        if not stream.closed:
+            stream.close()
 
 
 def parse_aligner_options(aligner_options, mapping_only):
@@ -139,16 +120,6 @@ def parse_aligner_options(aligner_options, mapping_only):
     return opt, k, w
 
 
-def _load_targets(paths):
-    key = tuple(paths)
-    if key not in _INDEX_CACHE:
-        genomes = []
-        for p in paths:
-            genomes.extend(read_fastx(p))
-        _INDEX_CACHE[key] = genomes
-    return _INDEX_CACHE[key]
-
-
 def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_filename_list=None,
           query_assembly_list=None, target_filename_list=None, target_assembly_list=None, aligner_options=None,
           paf_path_and_prefix=None, mapping_only=False, module_option='', AMR_output_folder='', align_concat_fa=False,
@@ -206,10 +177,14 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
     idx_key = (tuple(target_paths), k, w)
     idx = _INDEX_CACHE.get(idx_key)
     if idx is None:
-        if len(target_paths) == 1 and mapper.Index.is_index_file(target_paths[0]):
-            idx = mapper.Index.load(target_paths[0])    # a prebuilt index as the target (megapath_nano.py:1641-1645)
+        if len(target_paths) == 1:
+            idx = load_target(target_paths[0], k, w)    # sequences, or a prebuilt index (megapath_nano.py:1641-1645)
         else:
-            idx = mapper.Index(_load_targets(target_paths), k=k, w=w)
+            genomes = []
+            for tp in target_paths:
+                genomes.extend(read_fastx(tp))
+            idx = mapper.Index(genomes, k=k, w=w)
+            del genomes
         _INDEX_CACHE[idx_key] = idx
     seq_names = np.array(idx.names, dtype=object)
     seq_lens = idx.lens

@@ -397,8 +397,74 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
 constexpr int CHAIN_ITEM = 1024, CHAIN_BIG = 4096;
 struct ChainSeg { int32_t read, start, end; };
 
+// ---------------------------------------------------------------------------------------------------------
+// Anchor compaction.  A chain never crosses a gap of more than max_dist_x between consecutive sorted anchors (see above),
+// and a chain of fewer than min_cnt anchors is discarded by the backtrack, so a segment with fewer than min_cnt anchors
+// cannot contribute a chain: its anchors are dropped BEFORE the chaining DP.  Against a large target set most anchors
+// are such strays (random k-mer hits, one per locus), so the DP, its f/p/t/v state, the chain-end scan and the backtrack
+// shrink by an order of magnitude, with identical chains.  One wave per read; start-of-segment flags of the current and
+// the next 64-anchor tile give every anchor the (saturated) distances to its segment's start and end.
+// WRITE = false: kept[read] = anchors kept, avg_qspan[read] = mean seed length over ALL anchors (what mm_chain_dp uses).
+// WRITE = true : the kept anchors of read r go to out[c_off[r] ...) in order.
+template <bool WRITE>
+__global__ __launch_bounds__(64) void anchor_compact_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
+                                                            int n_reads, int max_dist_x, int min_cnt, int64_t *__restrict__ kept,
+                                                            float *__restrict__ avg_qspan, const int64_t *__restrict__ c_off,
+                                                            u128 *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const int K = min_cnt < 64 ? min_cnt : 64;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        const u128 *a = anchors + base;
+        u128 *o = WRITE ? out + c_off[read] : nullptr;
+        unsigned long long sum = 0;
+        int64_t run = 0, since = 0;
+        // tile registers: the record of this lane in the current and in the next tile, and their start flags
+        u128 cur{0, 0}, nxt{0, 0};
+        bool s_cur = false, s_nxt = false;
+        auto load = [&](int64_t t0, u128 &r, bool &st) {
+            const int64_t i = t0 + lane;
+            st = false;
+            if (i < n) {
+                r = a[i];
+                st = i == 0 || r.x > a[i - 1].x + (uint64_t)max_dist_x;
+            }
+        };
+        if (n > 0) load(0, cur, s_cur);
+        for (int64_t t0 = 0; t0 < n; t0 += 64) {
+            const bool has_next = t0 + 64 < n;
+            if (has_next) load(t0 + 64, nxt, s_nxt); else s_nxt = false;
+            const unsigned long long m_cur = __ballot(s_cur), m_nxt = __ballot(s_nxt);
+            const int64_t i = t0 + lane;
+            bool keep = false;
+            if (i < n) {
+                sum += cur.y >> 32 & 0xff;
+                const unsigned long long le = lane == 63 ? ~0ULL : (2ULL << lane) - 1;
+                const unsigned long long below = m_cur & le, above = m_cur & ~le;
+                const int64_t d_back = below ? lane - (63 - __builtin_clzll(below)) : since + lane;
+                int64_t e;  // index (within the read) of the next segment start, saturated
+                if (above) e = t0 + __builtin_ctzll(above);
+                else if (!has_next) e = n;
+                else if (m_nxt) e = t0 + 64 + __builtin_ctzll(m_nxt);
+                else e = n < t0 + 128 ? n : t0 + 128;
+                keep = d_back + (e - i) >= K;
+            }
+            const unsigned long long km = __ballot(keep);
+            if (WRITE && keep) o[run + __popcll(km & ((1ULL << lane) - 1))] = cur;
+            run += __popcll(km);
+            since = m_cur ? 64 - (63 - __builtin_clzll(m_cur)) : since + 64;
+            cur = nxt; s_cur = s_nxt;
+        }
+        if (!WRITE) {
+            for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+            if (lane == 0) { kept[read] = run; avg_qspan[read] = n > 0 ? (float)sum / (float)n : 0.f; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
-                                                            int n_reads, ChainParams cp, float *__restrict__ avg_qspan,
+                                                            int n_reads, ChainParams cp, float *__restrict__ avg_qspan, int have_avg,
                                                             ChainSeg *__restrict__ seg_big, ChainSeg *__restrict__ seg_small,
                                                             unsigned int *__restrict__ counters) {
     const int lane = threadIdx.x;
@@ -433,7 +499,7 @@ __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restri
         }
         for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
         if (lane == 0) {
-            avg_qspan[read] = (float)sum / (float)n;
+            if (!have_avg) avg_qspan[read] = (float)sum / (float)n;  // (given: the mean over the read's anchors before compaction)
             const bool big = (int32_t)n - open >= CHAIN_BIG;
             const unsigned int pos = atomicAdd(&counters[big ? 0 : 1], 1u);
             (big ? seg_big : seg_small)[pos] = ChainSeg{read, open, (int32_t)n};

@@ -133,10 +133,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     o.n_anchors = n_a;
     g_stats[2] += n_a;
     DevBuf<u128> tmp;
-    DevBuf<int32_t> F, P, T, V;
-    DevBuf<uint64_t> Utmp;
-    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || F.alloc(n_a) || P.alloc(n_a) || T.alloc(n_a) || V.alloc(n_a) ||
-        o.u.alloc(n_a) || Utmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
+    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
         o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(3) || o.used.zero(st))
         return -1;
     ev.mark(11);
@@ -153,30 +150,49 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     cp.max_dist_x = opt->max_gap; cp.max_dist_y = opt->max_gap; cp.bw = opt->bw; cp.max_skip = opt->max_chain_skip;
     cp.max_iter = opt->max_chain_iter; cp.min_cnt = opt->min_cnt; cp.min_sc = opt->min_chain_score;
     const int g = std::max(1, std::min(n, 256 * 32));
+    // anchors of segments too short to chain are dropped; everything below runs on the compact list (c_off, tmp)
+    DevBuf<int64_t> kept;
+    DevBuf<float> avg_qspan;
+    if (kept.alloc((size_t)n + 1) || o.c_off.alloc((size_t)n + 1) || avg_qspan.alloc(n)) return -1;
+    hipLaunchKernelGGL(anchor_compact_kernel<false>, dim3(g), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n,
+                       cp.max_dist_x, cp.min_cnt, kept.p, avg_qspan.p, (const int64_t *)nullptr, (u128 *)nullptr);
+    MPN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, kept.p, o.c_off.p, n);
+    MPN_HIP_CHECK(hipGetLastError());
+    int64_t n_c = 0;
+    MPN_HIP_CHECK(hipMemcpyAsync(&n_c, o.c_off.p + n, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    g_stats[45] += n_c;
+    DevBuf<int32_t> F, P, T, V;
+    DevBuf<uint64_t> Utmp;
+    if (F.alloc(n_c) || P.alloc(n_c) || T.alloc(n_c) || V.alloc(n_c) || o.u.alloc(n_c) || Utmp.alloc(n_c) || o.chained.alloc(n_c)) return -1;
+    u128 *ca = tmp.p;  // the sort's bounce buffer is free now: it receives the compact anchors
+    hipLaunchKernelGGL(anchor_compact_kernel<true>, dim3(g), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n,
+                       cp.max_dist_x, cp.min_cnt, (int64_t *)nullptr, (float *)nullptr, (const int64_t *)o.c_off.p, ca);
+    MPN_HIP_CHECK(hipGetLastError());
+    ev.mark(46);
     // work items of the chain DP: runs of whole independent segments of each read's anchor list, cut on the device
     DevBuf<ChainSeg> seg_big, seg_small;
-    DevBuf<float> avg_qspan;
     DevBuf<unsigned int> seg_counters;
-    if (seg_big.alloc((size_t)n_a / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_a / CHAIN_ITEM + (size_t)n + 1) || avg_qspan.alloc(n) ||
+    if (seg_big.alloc((size_t)n_c / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_c / CHAIN_ITEM + (size_t)n + 1) ||
         seg_counters.alloc(4) || seg_counters.zero(st))
         return -1;
-    hipLaunchKernelGGL(chain_segments_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, avg_qspan.p, seg_big.p,
+    hipLaunchKernelGGL(chain_segments_kernel, dim3(g), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, n, cp, avg_qspan.p, 1, seg_big.p,
                        seg_small.p, seg_counters.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(13);
-    hipLaunchKernelGGL(chain_dp_kernel, dim3(256 * 32), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, (const float *)avg_qspan.p,
+    hipLaunchKernelGGL(chain_dp_kernel, dim3(256 * 32), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, (const float *)avg_qspan.p,
                        (const ChainSeg *)seg_big.p, (const ChainSeg *)seg_small.p, seg_counters.p, cp, F.p, P.p, T.p, V.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(13, 37);
-    hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);
+    hipLaunchKernelGGL(chain_ends_kernel, dim3(g), dim3(64), 0, st, (const int64_t *)o.c_off.p, n, cp, F.p, P.p, T.p, V.p, o.u.p, o.n_ends.p);
     MPN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(chain_sort_ends_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(256), 0, st, o.u.p, Utmp.p,
-                       o.anchor_off.p, o.n_ends.p, n);
+                       (const int64_t *)o.c_off.p, o.n_ends.p, n);
     MPN_HIP_CHECK(hipGetLastError());
-    // chained anchors and surviving chains go to compact pools that reuse the sort scratch
-    o.chained.p = tmp.p; o.chained.n = tmp.n; o.chained.owned = tmp.owned; tmp.p = nullptr; tmp.n = 0;
+    // chained anchors and surviving chains go to compact pools
     o.u_compact.p = Utmp.p; o.u_compact.n = Utmp.n; o.u_compact.owned = Utmp.owned; Utmp.p = nullptr; Utmp.n = 0;
-    hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, o.anchors.p, o.anchor_off.p, n, cp, F.p, P.p, T.p, V.p,
+    hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, n, cp, F.p, P.p, T.p, V.p,
                        o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(14);

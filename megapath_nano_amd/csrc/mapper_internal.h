@@ -52,7 +52,7 @@ struct u128;
 
 struct SeedChainOut {
     int64_t n_anchors = 0;
-    DevBuf<int64_t> anchor_off, n_chained, u_pos, b_pos;
+    DevBuf<int64_t> anchor_off, c_off, n_chained, u_pos, b_pos;  // c_off: CSR of the anchors kept for chaining
     DevBuf<int32_t> rep_len, n_ends, n_chain;
     DevBuf<u128> anchors, chained;
     DevBuf<uint64_t> u, u_compact;

@@ -166,6 +166,41 @@ def test_index_save_load_round_trip(world, tmp_path):
     assert out.stdout == mapper.map_batch(gidx, opt, names[:4], seqs[:4])
 
 
+def test_dropin_with_fifo_target(world, tmp_path):
+    """B1 as the reference really calls it for the human/decoy stage (aligner.py:143-144,187-217): the target is a FIFO
+    that a writer fills with concatenated .fna.gz members in chunks; reads from a FASTQ; `--split-prefix tmp` trailing."""
+    import gzip
+    from test_fastx import feed_fifo
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    files = []
+    for i, (name, seq) in enumerate(gen):
+        fn = tmp_path / f'asm{i}.fna.gz'
+        with gzip.open(fn, 'wb') as f:
+            f.write(b'>' + name.encode() + b' synthetic assembly\n')
+            b = bytes(seq)
+            for k in range(0, len(b), 80):
+                f.write(b[k:k + 80] + b'\n')
+        files.append(str(fn))
+    pipe = str(tmp_path / 'temp_pipe_target_fasta')
+    os.mkfifo(pipe)
+    sub = reads[:24]
+    fq = tmp_path / 'reads.fq'
+    with open(fq, 'w') as f:
+        for r in sub:
+            f.write(f"@{r['name']}\n{bytes(r['seq']).decode()}\n+\n{'I' * len(r['seq'])}\n")
+    writer = feed_fifo(pipe, files, chunk=65536)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bin', 'mpn-aligner'), '-c', '-t', '4', '-I', '4G', '-x', 'map-ont', pipe, str(fq),
+                          '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300)
+    writer.join(10)
+    assert out.returncode == 0, out.stderr[-2000:]
+    oopt = mb.default_opt()  # -x map-ont defaults: -N 5 -p 0.8
+    assert out.stdout == ''.join(oracle_paf(oidx, oopt, sub))
+    assert out.stdout.count('\n') >= len(sub) // 2
+
+
 def test_edge_inputs_match_oracle(world):
     """Empty and degenerate batches through the C-ABI: no reads, reads shorter than k / shorter than one window, all-N,
     lower-case and IUPAC bases, duplicated names, a read that is a whole target, reads that map nowhere."""
