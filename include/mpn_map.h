@@ -164,7 +164,8 @@ void mpn_map_last_stats(int64_t stats[32]);
  *  [33] sketch count pass  [34] sketch fill pass  [35] seed lookup  [36] seed fill  [37] chain DP kernel alone
  *  [38] strip DP <16>  [39] strip DP <32>  [40] strip DP <64>  and their cells [41] [42] [43]
  *  [44] anchors that entered the sort x effective radix passes (bytes moved by the sort = 32 x this)
- *  [45] anchors kept for chaining (segments of at least min_cnt anchors)  [46] device ns of the compaction kernels */
+ *  [45] anchors kept for chaining (segments of at least min_cnt anchors)  [46] device ns of the compaction kernels
+ *  device ns of the anchor sort's kernels: [47] partition  [48] chunk sort in LDS  [49] radix passes over the large buckets */
 int32_t mpn_map_last_stats_ex(int64_t *stats, int32_t n);
 
 #ifdef __cplusplus

@@ -277,82 +277,317 @@ __device__ __forceinline__ uint32_t sort_digit(const u128 &r, int pass) {
 }
 
 // NY = 4: anchors, key (x, low 32 bits of y).  NY = 8: index records, key (x, y).
+struct SegSortLds {
+    uint32_t hist[256], bins[256], wcnt[4][256];
+    int skip;
+};
+
+// one segment [data, data + n) sorted by the calling workgroup (256 threads); tmp: bounce buffer of the same extent
+template <int NY>
+__device__ __forceinline__ void wg_radix_sort(SegSortLds &L, u128 *__restrict__ data, u128 *__restrict__ tmp, int64_t n,
+                                              unsigned long long *__restrict__ work) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    u128 *src = data, *dst = tmp;
+    for (int pass = 0; pass < NY + 8; ++pass) {
+        L.hist[tid] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += 256) atomicAdd(&L.hist[sort_digit<NY>(src[i], pass)], 1u);
+        __syncthreads();
+        if (tid == 0) L.skip = 0;
+        __syncthreads();
+        if (L.hist[tid] == (uint32_t)n) L.skip = 1;
+        __syncthreads();
+        if (L.skip) { __syncthreads(); continue; }
+        if (work && tid == 0) atomicAdd(work, (unsigned long long)n);  // records moved by this pass (bench.py: bytes of the sort)
+        // exclusive scan of the histogram (256 entries, thread per bin)
+        {
+            uint32_t v = L.hist[tid];
+            L.bins[tid] = v;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1) {
+                uint32_t a = tid >= d ? L.bins[tid - d] : 0;
+                __syncthreads();
+                L.bins[tid] += a;
+                __syncthreads();
+            }
+            uint32_t excl = L.bins[tid] - v;
+            __syncthreads();
+            L.bins[tid] = excl;
+            __syncthreads();
+        }
+        for (int64_t t0 = 0; t0 < n; t0 += 256) {
+            const int64_t i = t0 + tid;
+            const bool act = i < n;
+            u128 r;
+            uint32_t dg = 0;
+            if (act) { r = src[i]; dg = sort_digit<NY>(r, pass); }
+            L.wcnt[0][tid] = 0; L.wcnt[1][tid] = 0; L.wcnt[2][tid] = 0; L.wcnt[3][tid] = 0;
+            __syncthreads();
+            // lanes of this wave holding the same digit
+            unsigned long long same = __ballot(act);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                unsigned long long m = __ballot((dg >> b) & 1);
+                same &= ((dg >> b) & 1) ? m : ~m;
+            }
+            const unsigned long long lt = (1ULL << lane) - 1;
+            const uint32_t rank = __popcll(same & lt);
+            if (act && rank == 0) L.wcnt[wv][dg] = __popcll(same);
+            __syncthreads();
+            if (act) {
+                uint32_t o = L.bins[dg] + rank;
+                for (int w2 = 0; w2 < wv; ++w2) o += L.wcnt[w2][dg];
+                dst[o] = r;
+            }
+            __syncthreads();
+            L.bins[tid] += L.wcnt[0][tid] + L.wcnt[1][tid] + L.wcnt[2][tid] + L.wcnt[3][tid];
+            __syncthreads();
+        }
+        u128 *sw = src; src = dst; dst = sw;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (src != data) {
+        for (int64_t i = tid; i < n; i += 256) data[i] = src[i];
+    }
+    __syncthreads();
+}
+
+// segments = consecutive CSR rows (seg_off[n_seg + 1])
 template <int NY>
 __global__ __launch_bounds__(256) void seg_sort_kernel(u128 *__restrict__ data, u128 *__restrict__ tmp,
                                                        const int64_t *__restrict__ seg_off, int n_seg,
                                                        unsigned long long *__restrict__ work) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t bins[256];
-    __shared__ uint32_t wcnt[4][256];
-    __shared__ int s_skip;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ SegSortLds L;
     for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
         const int64_t base = seg_off[seg];
         const int64_t n = seg_off[seg + 1] - base;
         if (n < 2) continue;
-        u128 *src = data + base, *dst = tmp + base;
-        for (int pass = 0; pass < NY + 8; ++pass) {
-            hist[tid] = 0;
-            __syncthreads();
-            for (int64_t i = tid; i < n; i += 256) atomicAdd(&hist[sort_digit<NY>(src[i], pass)], 1u);
-            __syncthreads();
-            if (tid == 0) s_skip = 0;
-            __syncthreads();
-            if (hist[tid] == (uint32_t)n) s_skip = 1;
-            __syncthreads();
-            if (s_skip) { __syncthreads(); continue; }
-            if (work && tid == 0) atomicAdd(work, (unsigned long long)n);  // records moved by this pass (bench.py: bytes of the sort)
-            // exclusive scan of the histogram (256 entries, thread per bin)
-            {
-                uint32_t v = hist[tid];
-                bins[tid] = v;
-                __syncthreads();
-                for (int d = 1; d < 256; d <<= 1) {
-                    uint32_t a = tid >= d ? bins[tid - d] : 0;
-                    __syncthreads();
-                    bins[tid] += a;
-                    __syncthreads();
-                }
-                uint32_t excl = bins[tid] - v;
-                __syncthreads();
-                bins[tid] = excl;
-                __syncthreads();
-            }
-            for (int64_t t0 = 0; t0 < n; t0 += 256) {
-                const int64_t i = t0 + tid;
-                const bool act = i < n;
-                u128 r;
-                uint32_t dg = 0;
-                if (act) { r = src[i]; dg = sort_digit<NY>(r, pass); }
-                wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
-                __syncthreads();
-                // lanes of this wave holding the same digit
-                unsigned long long same = __ballot(act);
+        wg_radix_sort<NY>(L, data + base, tmp + base, n, work);
+    }
+}
+
+// segments = an explicit work list (offset, length) whose length is read from the device
+struct SortSeg { int64_t off; int64_t len; };
+template <int NY>
+__global__ __launch_bounds__(256) void seg_sort_list_kernel(u128 *__restrict__ data, u128 *__restrict__ tmp,
+                                                            const SortSeg *__restrict__ list, const unsigned int *__restrict__ n_list,
+                                                            unsigned int cap, unsigned long long *__restrict__ work) {
+    __shared__ SegSortLds L;
+    const unsigned int n_seg = *n_list < cap ? *n_list : cap;
+    for (unsigned int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const SortSeg sg = list[seg];
+        if (sg.len < 2) continue;
+        wg_radix_sort<NY>(L, data + sg.off, tmp + sg.off, sg.len, work);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Anchor sort for large target sets.  Against tens of Gbp of targets a read collects tens of thousands of stray seed
+// hits spread evenly over (strand, target): an LSD radix sort moves every one of them through HBM eight times.  Instead:
+//   1. anchor_msd_kernel: ONE partition pass per read (workgroup per read) on the top bits of the sort key -- strand,
+//      then (target, position) squeezed to what the target set needs -- with 2^14 counters in LDS.  A bucket then holds
+//      a couple of strays, or the read's true locus.
+//   2. anchor_chunk_sort_kernel: the read is streamed through LDS in chunks of whole buckets; a lane sorts a small
+//      bucket by insertion (a few LDS moves), buckets of more than 16 anchors go to a work list ...
+//   3. ... that seg_sort_list_kernel sorts by radix passes (the true loci: a few per cent of the anchors).
+// Keys are unique (a read position and a target position identify an anchor), so the result does not depend on the
+// order in which the atomics of pass 1 placed the records.
+constexpr int MSD_BITS = 14, MSD_NB = 1 << MSD_BITS, MSD_THREADS = 1024, CHUNK_CAP = 4096, CHUNK_THREADS = 1024, SMALL_BUCKET = 16;
+constexpr int BITONIC_SMALL = 1024, BITONIC_MID = 4096;  // work lists: buckets of 17..1024, 1025..4096, more (radix passes)
+struct BinParams { int pos_bits, shift; };
+
+__device__ __forceinline__ uint32_t anchor_bin(uint64_t x, const BinParams bp) {
+    const uint64_t comp = ((x >> 32 & 0x7fffffffULL) << bp.pos_bits) | (uint64_t)(uint32_t)x;
+    return (uint32_t)(x >> 63) << (MSD_BITS - 1) | (uint32_t)(comp >> bp.shift);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v, int lane) {
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    unsigned long long m = __ballot((dg >> b) & 1);
-                    same &= ((dg >> b) & 1) ? m : ~m;
-                }
-                const unsigned long long lt = (1ULL << lane) - 1;
-                const uint32_t rank = __popcll(same & lt);
-                if (act && rank == 0) wcnt[wv][dg] = __popcll(same);
-                __syncthreads();
-                if (act) {
-                    uint32_t o = bins[dg] + rank;
-                    for (int w2 = 0; w2 < wv; ++w2) o += wcnt[w2][dg];
-                    dst[o] = r;
-                }
-                __syncthreads();
-                bins[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-                __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
+
+// 16 waves per workgroup, two workgroups per CU (64 KB of counters each): the loops are bound by the latency of their
+// global loads, so what counts is loads in flight -- resident waves x the 4 independent loads each lane issues per step.
+__global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst,
+                                                                 const int64_t *__restrict__ anchor_off, int n_reads, BinParams bp,
+                                                                 unsigned long long *__restrict__ work) {
+    extern __shared__ uint32_t msd_lds[];  // MSD_NB counters + one total per wave (launch with (MSD_NB + 16) * 4 bytes)
+    uint32_t *cnt = msd_lds, *wtot = msd_lds + MSD_NB;
+    constexpr int NT = MSD_THREADS, NW = NT / 64, PER_WAVE = MSD_NB / NW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        if (n == 0) continue;
+        const u128 *in = src + base;
+        u128 *out = dst + base;
+        for (int k = tid; k < MSD_NB; k += NT) cnt[k] = 0;
+        __syncthreads();
+        for (int64_t i0 = tid; i0 < n; i0 += 4 * NT) {
+            uint64_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * NT; x[u] = i < n ? in[i].x : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + u * NT < n) atomicAdd(&cnt[anchor_bin(x[u], bp)], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of the counters: every wave owns a slice, 64 consecutive counters per step (conflict-free)
+        uint32_t s = 0;
+        for (int c = 0; c < PER_WAVE; c += 64) s += cnt[wv * PER_WAVE + c + lane];
+        for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) wtot[wv] = s;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w2 = 0; w2 < wv; ++w2) carry += wtot[w2];
+        for (int c = 0; c < PER_WAVE; c += 64) {
+            const uint32_t v = cnt[wv * PER_WAVE + c + lane];
+            const uint32_t incl = wave_incl_add(v, lane);
+            cnt[wv * PER_WAVE + c + lane] = carry + incl - v;
+            carry += __shfl(incl, 63);
+        }
+        __syncthreads();
+        for (int64_t i0 = tid; i0 < n; i0 += 4 * NT) {
+            u128 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * NT; if (i < n) r[u] = in[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * NT < n) { const uint32_t p = atomicAdd(&cnt[anchor_bin(r[u].x, bp)], 1u); out[p] = r[u]; }
+        }
+        if (work && tid == 0) atomicAdd(work, (unsigned long long)n);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ bool anchor_less(uint64_t ax, uint64_t ay, uint64_t bx, uint64_t by) {
+    return ax < bx || (ax == bx && (uint32_t)ay < (uint32_t)by);
+}
+
+struct SortLists {           // three work lists in one allocation: [0] <= BITONIC_SMALL, [1] <= BITONIC_MID, [2] larger
+    SortSeg *seg[3];
+    unsigned int *count;     // count[3]
+    unsigned int cap[3];
+};
+
+__device__ __forceinline__ void push_sort_seg(const SortLists &L, int64_t off, int64_t len) {
+    const int c = len <= BITONIC_SMALL ? 0 : len <= BITONIC_MID ? 1 : 2;
+    const unsigned int w = atomicAdd(&L.count[c], 1u);
+    if (w < L.cap[c]) L.seg[c][w] = SortSeg{off, len};
+}
+
+__global__ __launch_bounds__(CHUNK_THREADS) void anchor_chunk_sort_kernel(u128 *__restrict__ data, const int64_t *__restrict__ anchor_off,
+                                                                          int n_reads, BinParams bp, SortLists lists,
+                                                                          unsigned long long *__restrict__ work) {
+    extern __shared__ uint64_t chunk_lds[];  // kx[CHUNK_CAP], ky[CHUNK_CAP], flags[CHUNK_CAP / 64 + 1]
+    uint64_t *kx = chunk_lds, *ky = chunk_lds + CHUNK_CAP;
+    unsigned long long *flags = (unsigned long long *)(chunk_lds + 2 * CHUNK_CAP);  // bit i: a bucket starts at chunk position i
+    __shared__ int s_cut;
+    __shared__ long long s_end;
+    constexpr int NT = CHUNK_THREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t base = anchor_off[read];
+        const int64_t n = anchor_off[read + 1] - base;
+        u128 *a = data + base;
+        int64_t p = 0;
+        while (p < n) {
+            int cnt = (int)(n - p < CHUNK_CAP ? n - p : CHUNK_CAP);
+            const bool more = p + cnt < n;
+            if (tid == 0) { s_cut = 0; s_end = -1; }
+            for (int i = tid; i < cnt; i += NT) { const u128 r = a[p + i]; kx[i] = r.x; ky[i] = r.y; }
+            __syncthreads();
+            // bucket starts of the chunk (64 positions per wave step)
+            for (int i0 = wv * 64; i0 < cnt; i0 += NT) {
+                const int i = i0 + lane;
+                const bool st = i < cnt && (i == 0 || anchor_bin(kx[i], bp) != anchor_bin(kx[i - 1], bp));
+                const unsigned long long m = __ballot(st);
+                if (lane == 0) flags[i0 >> 6] = m;
+                if (more && m) { const int last = i0 + 63 - __builtin_clzll(m); if (lane == 0 && last > 0) atomicMax(&s_cut, last); }
             }
-            u128 *sw = src; src = dst; dst = sw;
-            __threadfence_block();
+            __syncthreads();
+            if (more) {
+                if (s_cut == 0) {
+                    // one bucket fills the whole chunk: it goes to a work list as it lies in HBM; find its end
+                    const uint32_t b0 = anchor_bin(kx[0], bp);
+                    for (int64_t q0 = p + cnt; q0 < n && s_end < 0; q0 += NT) {
+                        const int64_t q = q0 + tid;
+                        const bool diff = q < n && anchor_bin(a[q].x, bp) != b0;
+                        if (diff) atomicMin((unsigned long long *)&s_end, (unsigned long long)q);  // (-1 reads as the largest value)
+                        __syncthreads();
+                    }
+                    __syncthreads();
+                    const int64_t e = s_end < 0 ? n : (int64_t)s_end;
+                    if (tid == 0) push_sort_seg(lists, base + p, e - p);
+                    p = e;
+                    __syncthreads();
+                    continue;
+                }
+                cnt = s_cut;  // whole buckets only
+            }
+            // every bucket start is taken by the thread that owns its position
+            for (int i = tid; i < cnt; i += NT) {
+                if (!(flags[i >> 6] >> (i & 63) & 1)) continue;
+                // end of the bucket: next start after i (or the end of the chunk)
+                int e = cnt;
+                {
+                    int w = i >> 6;
+                    unsigned long long m = (i & 63) == 63 ? 0ULL : flags[w] >> ((i & 63) + 1) << ((i & 63) + 1);
+                    const int w_end = (cnt + 63) >> 6;
+                    while (!m && ++w < w_end) m = flags[w];
+                    if (m) { const int cand = (w << 6) + __builtin_ctzll(m); if (cand < cnt) e = cand; }
+                }
+                const int len = e - i;
+                if (len <= 1) continue;
+                if (len > SMALL_BUCKET) { push_sort_seg(lists, base + p + i, (int64_t)len); continue; }
+                for (int u = i + 1; u < e; ++u) {  // insertion sort in LDS
+                    const uint64_t vx = kx[u], vy = ky[u];
+                    int v = u - 1;
+                    while (v >= i && anchor_less(vx, vy, kx[v], ky[v])) { kx[v + 1] = kx[v]; ky[v + 1] = ky[v]; --v; }
+                    kx[v + 1] = vx; ky[v + 1] = vy;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < cnt; i += NT) { u128 r; r.x = kx[i]; r.y = ky[i]; a[p + i] = r; }
+            if (work && tid == 0) atomicAdd(work, (unsigned long long)cnt);
+            p += cnt;
             __syncthreads();
         }
-        if (src != data + base) {
-            for (int64_t i = tid; i < n; i += 256) data[base + i] = src[i];
+    }
+}
+
+// work-list segments of at most CAP anchors: one load, a bitonic network in LDS, one store
+template <int CAP>
+__global__ __launch_bounds__(256) void anchor_bitonic_list_kernel(u128 *__restrict__ data, const SortSeg *__restrict__ list,
+                                                                  const unsigned int *__restrict__ n_list, unsigned int cap,
+                                                                  unsigned long long *__restrict__ work) {
+    __shared__ uint64_t kx[CAP], ky[CAP];
+    const int tid = threadIdx.x;
+    const unsigned int n_seg = *n_list < cap ? *n_list : cap;
+    for (unsigned int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const SortSeg sg = list[seg];
+        const int len = (int)sg.len;
+        u128 *a = data + sg.off;
+        int N = 2;
+        while (N < len) N <<= 1;
+        for (int i = tid; i < N; i += 256) {
+            if (i < len) { const u128 r = a[i]; kx[i] = r.x; ky[i] = r.y; }
+            else { kx[i] = ~0ULL; ky[i] = ~0ULL; }
         }
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (N >> 1); t += 256) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const bool up = (i & k) == 0;
+                    const uint64_t ax = kx[i], ay = ky[i], bx = kx[l], by = ky[l];
+                    if (anchor_less(bx, by, ax, ay) == up) { kx[i] = bx; ky[i] = by; kx[l] = ax; ky[l] = ay; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < len; i += 256) { u128 r; r.x = kx[i]; r.y = ky[i]; a[i] = r; }
+        if (work && tid == 0) atomicAdd(work, (unsigned long long)len);
         __syncthreads();
     }
 }
@@ -402,65 +637,115 @@ struct ChainSeg { int32_t read, start, end; };
 // and a chain of fewer than min_cnt anchors is discarded by the backtrack, so a segment with fewer than min_cnt anchors
 // cannot contribute a chain: its anchors are dropped BEFORE the chaining DP.  Against a large target set most anchors
 // are such strays (random k-mer hits, one per locus), so the DP, its f/p/t/v state, the chain-end scan and the backtrack
-// shrink by an order of magnitude, with identical chains.  One wave per read; start-of-segment flags of the current and
-// the next 64-anchor tile give every anchor the (saturated) distances to its segment's start and end.
-// WRITE = false: kept[read] = anchors kept, avg_qspan[read] = mean seed length over ALL anchors (what mm_chain_dp uses).
-// WRITE = true : the kept anchors of read r go to out[c_off[r] ...) in order.
+// shrink by an order of magnitude, with identical chains.
+// The batch's anchor array is cut into pieces of COMPACT_PIECE anchors regardless of read boundaries; one wave per piece.
+// Start-of-segment flags of the current and the next 64-anchor tile (a read's first anchor always starts a segment) give
+// every anchor the saturated distances to its segment's start and end.
+// WRITE = false: piece_kept[piece]; per read (atomics): anchors kept and the sum of the seed lengths of ALL its anchors
+//                (mm_chain_dp's average uses every anchor).   WRITE = true: kept anchors -> out, in order.
+constexpr int COMPACT_PIECE = 4096;
+
 template <bool WRITE>
 __global__ __launch_bounds__(64) void anchor_compact_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
-                                                            int n_reads, int max_dist_x, int min_cnt, int64_t *__restrict__ kept,
-                                                            float *__restrict__ avg_qspan, const int64_t *__restrict__ c_off,
-                                                            u128 *__restrict__ out) {
+                                                            int n_reads, int64_t n_a, int max_dist_x, int min_cnt,
+                                                            int64_t *__restrict__ piece_kept, unsigned long long *__restrict__ read_kept,
+                                                            unsigned long long *__restrict__ read_span,
+                                                            const int64_t *__restrict__ piece_off, u128 *__restrict__ out) {
     const int lane = threadIdx.x;
-    const int K = min_cnt < 64 ? min_cnt : 64;
-    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
-        const int64_t base = anchor_off[read];
-        const int64_t n = anchor_off[read + 1] - base;
-        const u128 *a = anchors + base;
-        u128 *o = WRITE ? out + c_off[read] : nullptr;
-        unsigned long long sum = 0;
-        int64_t run = 0, since = 0;
-        // tile registers: the record of this lane in the current and in the next tile, and their start flags
+    const int K = min_cnt < 64 ? (min_cnt > 1 ? min_cnt : 1) : 64;
+    const int64_t n_pieces = (n_a + COMPACT_PIECE - 1) / COMPACT_PIECE;
+    for (int64_t piece = blockIdx.x; piece < n_pieces; piece += gridDim.x) {
+        const int64_t g0 = piece * COMPACT_PIECE, g1 = g0 + COMPACT_PIECE < n_a ? g0 + COMPACT_PIECE : n_a;
+        int r0;  // the read that holds anchor g0: last r with anchor_off[r] <= g0
+        {
+            int lo = 0, hi = n_reads;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (anchor_off[mid] <= g0) lo = mid; else hi = mid; }
+            r0 = lo;
+        }
+        // distance from the start of g0's segment to g0, looking back at most K anchors inside its read
+        int64_t since;
+        {
+            const int64_t rb = anchor_off[r0], j = g0 - 1 - lane;
+            bool st = false;
+            if (lane < K && j >= rb) st = j == rb || anchors[j].x > anchors[j - 1].x + (uint64_t)max_dist_x;
+            const unsigned long long m = __ballot(st);
+            since = m ? __builtin_ctzll(m) + 1 : K;
+        }
         u128 cur{0, 0}, nxt{0, 0};
         bool s_cur = false, s_nxt = false;
-        auto load = [&](int64_t t0, u128 &r, bool &st) {
+        int r_cur = r0, r_nxt = r0;                             // per lane: the read of its anchor, with the read's bounds cached
+        int64_t rb_cur = anchor_off[r0], re_cur = anchor_off[r0 + 1], rb_nxt, re_nxt;
+        auto load = [&](int64_t t0, u128 &rec, bool &st, int &r, int64_t &rb, int64_t &re) {
             const int64_t i = t0 + lane;
             st = false;
-            if (i < n) {
-                r = a[i];
-                st = i == 0 || r.x > a[i - 1].x + (uint64_t)max_dist_x;
+            if (i < n_a) {
+                if (i >= re) { do { ++r; re = anchor_off[r + 1]; } while (i >= re); rb = anchor_off[r]; }
+                rec = anchors[i];
+                st = i == rb || rec.x > anchors[i - 1].x + (uint64_t)max_dist_x;
             }
         };
-        if (n > 0) load(0, cur, s_cur);
-        for (int64_t t0 = 0; t0 < n; t0 += 64) {
-            const bool has_next = t0 + 64 < n;
-            if (has_next) load(t0 + 64, nxt, s_nxt); else s_nxt = false;
+        load(g0, cur, s_cur, r_cur, rb_cur, re_cur);
+        int64_t run = 0;
+        int acc_r = -1;                                         // count pass: totals of the read the wave is inside (uniform)
+        unsigned long long acc_k = 0, acc_s = 0;
+        for (int64_t t0 = g0; t0 < g1; t0 += 64) {
+            const bool has_next = t0 + 64 < n_a;
+            r_nxt = r_cur; rb_nxt = rb_cur; re_nxt = re_cur;
+            if (has_next) load(t0 + 64, nxt, s_nxt, r_nxt, rb_nxt, re_nxt); else s_nxt = false;
             const unsigned long long m_cur = __ballot(s_cur), m_nxt = __ballot(s_nxt);
             const int64_t i = t0 + lane;
+            const bool act = i < g1;
             bool keep = false;
-            if (i < n) {
-                sum += cur.y >> 32 & 0xff;
+            if (act) {
                 const unsigned long long le = lane == 63 ? ~0ULL : (2ULL << lane) - 1;
                 const unsigned long long below = m_cur & le, above = m_cur & ~le;
                 const int64_t d_back = below ? lane - (63 - __builtin_clzll(below)) : since + lane;
-                int64_t e;  // index (within the read) of the next segment start, saturated
+                int64_t e;  // next segment start, saturated
                 if (above) e = t0 + __builtin_ctzll(above);
-                else if (!has_next) e = n;
+                else if (!has_next) e = n_a;
                 else if (m_nxt) e = t0 + 64 + __builtin_ctzll(m_nxt);
-                else e = n < t0 + 128 ? n : t0 + 128;
+                else e = n_a < t0 + 128 ? n_a : t0 + 128;
                 keep = d_back + (e - i) >= K;
             }
             const unsigned long long km = __ballot(keep);
-            if (WRITE && keep) o[run + __popcll(km & ((1ULL << lane) - 1))] = cur;
+            if (WRITE) {
+                if (keep) out[piece_off[piece] + run + __popcll(km & ((1ULL << lane) - 1))] = cur;
+            } else {
+                const unsigned long long span = act ? (cur.y >> 32 & 0xff) : 0ULL;
+                const int r_first = __builtin_amdgcn_readfirstlane(r_cur);  // (lane 0 is active: t0 < g1)
+                const bool uniform = __ballot(act && r_cur != r_first) == 0;
+                if (!uniform || r_first != acc_r) {  // leaving the read the totals belong to: flush them (one atomic pair per run)
+                    if (lane == 0 && acc_r >= 0) { if (acc_k) atomicAdd(&read_kept[acc_r], acc_k); atomicAdd(&read_span[acc_r], acc_s); }
+                    acc_r = -1; acc_k = 0; acc_s = 0;
+                }
+                if (uniform) {
+                    unsigned long long ssum = span;
+                    for (int d = 32; d; d >>= 1) ssum += __shfl_xor(ssum, d);
+                    acc_r = r_first; acc_k += (unsigned long long)__popcll(km); acc_s += ssum;
+                } else if (act) {
+                    if (keep) atomicAdd(&read_kept[r_cur], 1ULL);
+                    atomicAdd(&read_span[r_cur], span);
+                }
+            }
             run += __popcll(km);
             since = m_cur ? 64 - (63 - __builtin_clzll(m_cur)) : since + 64;
-            cur = nxt; s_cur = s_nxt;
+            cur = nxt; s_cur = s_nxt; r_cur = r_nxt; rb_cur = rb_nxt; re_cur = re_nxt;
         }
-        if (!WRITE) {
-            for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
-            if (lane == 0) { kept[read] = run; avg_qspan[read] = n > 0 ? (float)sum / (float)n : 0.f; }
-        }
+        if (!WRITE && lane == 0 && acc_r >= 0) { if (acc_k) atomicAdd(&read_kept[acc_r], acc_k); atomicAdd(&read_span[acc_r], acc_s); }
+        if (!WRITE && lane == 0) piece_kept[piece] = run;
     }
+}
+
+// per read: kept anchors as int64 (input of the offset scan) and the average seed length over all its anchors
+__global__ __launch_bounds__(256) void anchor_compact_finish_kernel(const int64_t *__restrict__ anchor_off, int n_reads,
+                                                                    const unsigned long long *__restrict__ read_kept,
+                                                                    const unsigned long long *__restrict__ read_span,
+                                                                    int64_t *__restrict__ kept, float *__restrict__ avg_qspan) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t n = anchor_off[r + 1] - anchor_off[r];
+    kept[r] = (int64_t)read_kept[r];
+    avg_qspan[r] = n > 0 ? (float)read_span[r] / (float)n : 0.f;
 }
 
 __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,

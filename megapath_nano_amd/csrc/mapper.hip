@@ -4,6 +4,7 @@
 #include "../../include/mpn_map.h"
 
 #include <algorithm>
+#include <mutex>
 #include <string.h>
 #include <sys/stat.h>
 #include <string>
@@ -138,26 +139,80 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         return -1;
     ev.mark(11);
     if (n_a > 0) {
+        // anchors in (minimizer, hit) order -> tmp; partition per read on the top key bits -> o.anchors; small buckets are
+        // sorted in LDS, the large ones (true loci) by radix passes with tmp as the bounce buffer
         hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
-                           pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, o.anchors.p);
+                           pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, tmp.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(11, 36);
-        hipLaunchKernelGGL(seg_sort_kernel<4>, dim3(std::min(n, 256 * 8)), dim3(256), 0, st, o.anchors.p, tmp.p, o.anchor_off.p, n, o.used.p + 2);
+        BinParams bp;
+        {
+            int32_t max_len = 1;
+            for (int32_t l : idx->lens) max_len = std::max(max_len, l);
+            int rid_bits = 0, pos_bits = 1;
+            while (((int64_t)1 << rid_bits) < (int64_t)idx->n_seq) ++rid_bits;
+            while (((int64_t)1 << pos_bits) < (int64_t)max_len) ++pos_bits;
+            bp.pos_bits = pos_bits;
+            bp.shift = std::max(0, rid_bits + pos_bits - (MSD_BITS - 1));
+        }
+        // work lists of the buckets that are not sorted in place by the chunk kernel (more than SMALL_BUCKET anchors each)
+        SortLists lists;
+        DevBuf<SortSeg> list_mem;
+        DevBuf<unsigned int> n_list;
+        {
+            const int64_t c0 = n_a / (SMALL_BUCKET + 1) + (int64_t)n + 16, c1 = n_a / (BITONIC_SMALL + 1) + 16, c2 = n_a / (BITONIC_MID + 1) + 16;
+            if (c0 > 0x7fffffff) { set_error("sub-batch too large for the anchor sort"); return -1; }
+            if (list_mem.alloc((size_t)(c0 + c1 + c2)) || n_list.alloc(4) || n_list.zero(st)) return -1;
+            lists.seg[0] = list_mem.p; lists.seg[1] = list_mem.p + c0; lists.seg[2] = list_mem.p + c0 + c1;
+            lists.cap[0] = (unsigned int)c0; lists.cap[1] = (unsigned int)c1; lists.cap[2] = (unsigned int)c2;
+            lists.count = n_list.p;
+        }
+        const size_t msd_lds = (size_t)(MSD_NB + 16) * sizeof(uint32_t), chunk_lds = (size_t)(2 * CHUNK_CAP + CHUNK_CAP / 64 + 1) * 8;
+        static std::once_flag lds_attr;
+        std::call_once(lds_attr, [&]() {
+            (void)hipFuncSetAttribute((const void *)anchor_msd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_lds);
+            (void)hipFuncSetAttribute((const void *)anchor_chunk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chunk_lds);
+        });
+        const int gr = std::max(1, std::min(n, 256 * 4));
+        hipLaunchKernelGGL(anchor_msd_kernel, dim3(gr), dim3(MSD_THREADS), msd_lds, st, (const u128 *)tmp.p, o.anchors.p, (const int64_t *)o.anchor_off.p, n, bp,
+                           o.used.p + 2);
         MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(12, 47);
+        hipLaunchKernelGGL(anchor_chunk_sort_kernel, dim3(gr), dim3(CHUNK_THREADS), chunk_lds, st, o.anchors.p, (const int64_t *)o.anchor_off.p, n, bp, lists,
+                           o.used.p + 2);
+        MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(12, 48);
+        hipLaunchKernelGGL(anchor_bitonic_list_kernel<BITONIC_SMALL>, dim3(256 * 16), dim3(256), 0, st, o.anchors.p, (const SortSeg *)lists.seg[0],
+                           (const unsigned int *)n_list.p, lists.cap[0], o.used.p + 2);
+        hipLaunchKernelGGL(anchor_bitonic_list_kernel<BITONIC_MID>, dim3(256 * 4), dim3(256), 0, st, o.anchors.p, (const SortSeg *)lists.seg[1],
+                           (const unsigned int *)n_list.p + 1, lists.cap[1], o.used.p + 2);
+        hipLaunchKernelGGL(seg_sort_list_kernel<4>, dim3(256 * 4), dim3(256), 0, st, o.anchors.p, tmp.p, (const SortSeg *)lists.seg[2],
+                           (const unsigned int *)n_list.p + 2, lists.cap[2], o.used.p + 2);
+        MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(12, 49);
     }
-    ev.mark(12);
     ChainParams cp;
     cp.max_dist_x = opt->max_gap; cp.max_dist_y = opt->max_gap; cp.bw = opt->bw; cp.max_skip = opt->max_chain_skip;
     cp.max_iter = opt->max_chain_iter; cp.min_cnt = opt->min_cnt; cp.min_sc = opt->min_chain_score;
     const int g = std::max(1, std::min(n, 256 * 32));
     // anchors of segments too short to chain are dropped; everything below runs on the compact list (c_off, tmp)
-    DevBuf<int64_t> kept;
+    const int64_t n_pieces = (n_a + COMPACT_PIECE - 1) / COMPACT_PIECE;
+    DevBuf<int64_t> kept, piece_kept, piece_off;
+    DevBuf<unsigned long long> read_kept, read_span;
     DevBuf<float> avg_qspan;
-    if (kept.alloc((size_t)n + 1) || o.c_off.alloc((size_t)n + 1) || avg_qspan.alloc(n)) return -1;
-    hipLaunchKernelGGL(anchor_compact_kernel<false>, dim3(g), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n,
-                       cp.max_dist_x, cp.min_cnt, kept.p, avg_qspan.p, (const int64_t *)nullptr, (u128 *)nullptr);
-    MPN_HIP_CHECK(hipGetLastError());
+    if (kept.alloc((size_t)n + 1) || o.c_off.alloc((size_t)n + 1) || avg_qspan.alloc(n) || piece_kept.alloc((size_t)n_pieces + 1) ||
+        piece_off.alloc((size_t)n_pieces + 1) || read_kept.alloc(n) || read_span.alloc(n) || read_kept.zero(st) || read_span.zero(st))
+        return -1;
+    const int gp = (int)std::max<int64_t>(1, std::min<int64_t>(n_pieces, 256 * 64));
+    if (n_a > 0) {
+        hipLaunchKernelGGL(anchor_compact_kernel<false>, dim3(gp), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n, n_a,
+                           cp.max_dist_x, cp.min_cnt, piece_kept.p, read_kept.p, read_span.p, (const int64_t *)nullptr, (u128 *)nullptr);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(anchor_compact_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)o.anchor_off.p, n,
+                       (const unsigned long long *)read_kept.p, (const unsigned long long *)read_span.p, kept.p, avg_qspan.p);
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, kept.p, o.c_off.p, n);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, piece_kept.p, piece_off.p, (int)n_pieces);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_c = 0;
     MPN_HIP_CHECK(hipMemcpyAsync(&n_c, o.c_off.p + n, 8, hipMemcpyDeviceToHost, st));
@@ -167,9 +222,12 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<uint64_t> Utmp;
     if (F.alloc(n_c) || P.alloc(n_c) || T.alloc(n_c) || V.alloc(n_c) || o.u.alloc(n_c) || Utmp.alloc(n_c) || o.chained.alloc(n_c)) return -1;
     u128 *ca = tmp.p;  // the sort's bounce buffer is free now: it receives the compact anchors
-    hipLaunchKernelGGL(anchor_compact_kernel<true>, dim3(g), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n,
-                       cp.max_dist_x, cp.min_cnt, (int64_t *)nullptr, (float *)nullptr, (const int64_t *)o.c_off.p, ca);
-    MPN_HIP_CHECK(hipGetLastError());
+    if (n_a > 0) {
+        hipLaunchKernelGGL(anchor_compact_kernel<true>, dim3(gp), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n, n_a,
+                           cp.max_dist_x, cp.min_cnt, (int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                           (const int64_t *)piece_off.p, ca);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
     ev.mark(46);
     // work items of the chain DP: runs of whole independent segments of each read's anchor list, cut on the device
     DevBuf<ChainSeg> seg_big, seg_small;
