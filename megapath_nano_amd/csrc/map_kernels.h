@@ -388,12 +388,14 @@ __global__ __launch_bounds__(256) void seg_sort_list_kernel(u128 *__restrict__ d
 //   1. anchor_msd_kernel: ONE partition pass per read (workgroup per read) on the top bits of the sort key -- strand,
 //      then (target, position) squeezed to what the target set needs -- with 2^14 counters in LDS.  A bucket then holds
 //      a couple of strays, or the read's true locus.
-//   2. anchor_chunk_sort_kernel: the read is streamed through LDS in chunks of whole buckets; a lane sorts a small
-//      bucket by insertion (a few LDS moves), buckets of more than 16 anchors go to a work list ...
-//   3. ... that seg_sort_list_kernel sorts by radix passes (the true loci: a few per cent of the anchors).
+//      Buckets of more than 16 anchors (the true loci: a few per cent of the anchors) go to work lists by size.
+//   2. anchor_window_sort_kernel: the partitioned array is streamed through LDS in windows; a lane sorts a small bucket
+//      by insertion (a few LDS moves).
+//   3. anchor_bitonic_list_kernel: listed buckets of up to 4096 anchors, one load + a bitonic network in LDS + one store;
+//      seg_sort_list_kernel: the rest by radix passes through HBM.
 // Keys are unique (a read position and a target position identify an anchor), so the result does not depend on the
 // order in which the atomics of pass 1 placed the records.
-constexpr int MSD_BITS = 14, MSD_NB = 1 << MSD_BITS, MSD_THREADS = 1024, CHUNK_CAP = 4096, CHUNK_THREADS = 1024, SMALL_BUCKET = 16;
+constexpr int MSD_BITS = 14, MSD_NB = 1 << MSD_BITS, MSD_THREADS = 1024, SMALL_BUCKET = 16;
 constexpr int BITONIC_SMALL = 1024, BITONIC_MID = 4096;  // work lists: buckets of 17..1024, 1025..4096, more (radix passes)
 struct BinParams { int pos_bits, shift; };
 
@@ -408,11 +410,27 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v, int lane) {
     return v;
 }
 
+__device__ __forceinline__ bool anchor_less(uint64_t ax, uint64_t ay, uint64_t bx, uint64_t by) {
+    return ax < bx || (ax == bx && (uint32_t)ay < (uint32_t)by);
+}
+
+struct SortLists {           // three work lists in one allocation: [0] <= BITONIC_SMALL, [1] <= BITONIC_MID, [2] larger
+    SortSeg *seg[3];
+    unsigned int *count;     // count[3]
+    unsigned int cap[3];
+};
+
+__device__ __forceinline__ void push_sort_seg(const SortLists &L, int64_t off, int64_t len) {
+    const int c = len <= BITONIC_SMALL ? 0 : len <= BITONIC_MID ? 1 : 2;
+    const unsigned int w = atomicAdd(&L.count[c], 1u);
+    if (w < L.cap[c]) L.seg[c][w] = SortSeg{off, len};
+}
+
 // 16 waves per workgroup, two workgroups per CU (64 KB of counters each): the loops are bound by the latency of their
 // global loads, so what counts is loads in flight -- resident waves x the 4 independent loads each lane issues per step.
 __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst,
                                                                  const int64_t *__restrict__ anchor_off, int n_reads, BinParams bp,
-                                                                 unsigned long long *__restrict__ work) {
+                                                                 SortLists lists, unsigned long long *__restrict__ work) {
     extern __shared__ uint32_t msd_lds[];  // MSD_NB counters + one total per wave (launch with (MSD_NB + 16) * 4 bytes)
     uint32_t *cnt = msd_lds, *wtot = msd_lds + MSD_NB;
     constexpr int NT = MSD_THREADS, NW = NT / 64, PER_WAVE = MSD_NB / NW;
@@ -448,6 +466,12 @@ __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__r
             carry += __shfl(incl, 63);
         }
         __syncthreads();
+        // buckets the window kernel will not sort in LDS go to the work lists (their extents are known here)
+        for (int b = tid; b < MSD_NB; b += NT) {
+            const uint32_t st = cnt[b], en = b + 1 < MSD_NB ? cnt[b + 1] : (uint32_t)n;
+            if (en - st > SMALL_BUCKET) push_sort_seg(lists, base + st, (int64_t)(en - st));
+        }
+        __syncthreads();
         for (int64_t i0 = tid; i0 < n; i0 += 4 * NT) {
             u128 r[4];
 #pragma unroll
@@ -461,99 +485,85 @@ __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__r
     }
 }
 
-__device__ __forceinline__ bool anchor_less(uint64_t ax, uint64_t ay, uint64_t bx, uint64_t by) {
-    return ax < bx || (ax == bx && (uint32_t)ay < (uint32_t)by);
-}
+// Small buckets, sorted in LDS.  The batch's partitioned anchor array is cut into windows of SORT_WIN anchors regardless of
+// read boundaries; a workgroup owns the buckets that START in its window (a bucket start = the bin changes, or a read's
+// first anchor) and loads SMALL_BUCKET more records so that an owned small bucket is complete.  Owners are unique, so
+// the windows are independent: the grid is the number of windows, not the number of reads.  Buckets of more than
+// SMALL_BUCKET anchors are left as they are (the partition kernel has put them on the work lists).
+constexpr int SORT_WIN = 2048, SORT_LOAD = SORT_WIN + SMALL_BUCKET;
 
-struct SortLists {           // three work lists in one allocation: [0] <= BITONIC_SMALL, [1] <= BITONIC_MID, [2] larger
-    SortSeg *seg[3];
-    unsigned int *count;     // count[3]
-    unsigned int cap[3];
-};
-
-__device__ __forceinline__ void push_sort_seg(const SortLists &L, int64_t off, int64_t len) {
-    const int c = len <= BITONIC_SMALL ? 0 : len <= BITONIC_MID ? 1 : 2;
-    const unsigned int w = atomicAdd(&L.count[c], 1u);
-    if (w < L.cap[c]) L.seg[c][w] = SortSeg{off, len};
-}
-
-__global__ __launch_bounds__(CHUNK_THREADS) void anchor_chunk_sort_kernel(u128 *__restrict__ data, const int64_t *__restrict__ anchor_off,
-                                                                          int n_reads, BinParams bp, SortLists lists,
-                                                                          unsigned long long *__restrict__ work) {
-    extern __shared__ uint64_t chunk_lds[];  // kx[CHUNK_CAP], ky[CHUNK_CAP], flags[CHUNK_CAP / 64 + 1]
-    uint64_t *kx = chunk_lds, *ky = chunk_lds + CHUNK_CAP;
-    unsigned long long *flags = (unsigned long long *)(chunk_lds + 2 * CHUNK_CAP);  // bit i: a bucket starts at chunk position i
-    __shared__ int s_cut;
-    __shared__ long long s_end;
-    constexpr int NT = CHUNK_THREADS;
+__global__ __launch_bounds__(256) void anchor_window_sort_kernel(u128 *__restrict__ data, const int64_t *__restrict__ anchor_off,
+                                                                 int n_reads, int64_t n_a, BinParams bp,
+                                                                 unsigned long long *__restrict__ work) {
+    __shared__ uint64_t kx[SORT_LOAD], ky[SORT_LOAD];
+    __shared__ unsigned long long flags[SORT_LOAD / 64 + 2];  // bit i: a bucket starts at window position i (i <= cnt: the end of the data counts)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
-        const int64_t base = anchor_off[read];
-        const int64_t n = anchor_off[read + 1] - base;
-        u128 *a = data + base;
-        int64_t p = 0;
-        while (p < n) {
-            int cnt = (int)(n - p < CHUNK_CAP ? n - p : CHUNK_CAP);
-            const bool more = p + cnt < n;
-            if (tid == 0) { s_cut = 0; s_end = -1; }
-            for (int i = tid; i < cnt; i += NT) { const u128 r = a[p + i]; kx[i] = r.x; ky[i] = r.y; }
-            __syncthreads();
-            // bucket starts of the chunk (64 positions per wave step)
-            for (int i0 = wv * 64; i0 < cnt; i0 += NT) {
-                const int i = i0 + lane;
-                const bool st = i < cnt && (i == 0 || anchor_bin(kx[i], bp) != anchor_bin(kx[i - 1], bp));
-                const unsigned long long m = __ballot(st);
-                if (lane == 0) flags[i0 >> 6] = m;
-                if (more && m) { const int last = i0 + 63 - __builtin_clzll(m); if (lane == 0 && last > 0) atomicMax(&s_cut, last); }
-            }
-            __syncthreads();
-            if (more) {
-                if (s_cut == 0) {
-                    // one bucket fills the whole chunk: it goes to a work list as it lies in HBM; find its end
-                    const uint32_t b0 = anchor_bin(kx[0], bp);
-                    for (int64_t q0 = p + cnt; q0 < n && s_end < 0; q0 += NT) {
-                        const int64_t q = q0 + tid;
-                        const bool diff = q < n && anchor_bin(a[q].x, bp) != b0;
-                        if (diff) atomicMin((unsigned long long *)&s_end, (unsigned long long)q);  // (-1 reads as the largest value)
-                        __syncthreads();
-                    }
-                    __syncthreads();
-                    const int64_t e = s_end < 0 ? n : (int64_t)s_end;
-                    if (tid == 0) push_sort_seg(lists, base + p, e - p);
-                    p = e;
-                    __syncthreads();
-                    continue;
-                }
-                cnt = s_cut;  // whole buckets only
-            }
-            // every bucket start is taken by the thread that owns its position
-            for (int i = tid; i < cnt; i += NT) {
-                if (!(flags[i >> 6] >> (i & 63) & 1)) continue;
-                // end of the bucket: next start after i (or the end of the chunk)
-                int e = cnt;
-                {
-                    int w = i >> 6;
-                    unsigned long long m = (i & 63) == 63 ? 0ULL : flags[w] >> ((i & 63) + 1) << ((i & 63) + 1);
-                    const int w_end = (cnt + 63) >> 6;
-                    while (!m && ++w < w_end) m = flags[w];
-                    if (m) { const int cand = (w << 6) + __builtin_ctzll(m); if (cand < cnt) e = cand; }
-                }
-                const int len = e - i;
-                if (len <= 1) continue;
-                if (len > SMALL_BUCKET) { push_sort_seg(lists, base + p + i, (int64_t)len); continue; }
-                for (int u = i + 1; u < e; ++u) {  // insertion sort in LDS
-                    const uint64_t vx = kx[u], vy = ky[u];
-                    int v = u - 1;
-                    while (v >= i && anchor_less(vx, vy, kx[v], ky[v])) { kx[v + 1] = kx[v]; ky[v + 1] = ky[v]; --v; }
-                    kx[v + 1] = vx; ky[v + 1] = vy;
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < cnt; i += NT) { u128 r; r.x = kx[i]; r.y = ky[i]; a[p + i] = r; }
-            if (work && tid == 0) atomicAdd(work, (unsigned long long)cnt);
-            p += cnt;
-            __syncthreads();
+    const int64_t n_win = (n_a + SORT_WIN - 1) / SORT_WIN;
+    for (int64_t win = blockIdx.x; win < n_win; win += gridDim.x) {
+        const int64_t g0 = win * SORT_WIN;
+        const int cnt = (int)(n_a - g0 < SORT_LOAD ? n_a - g0 : SORT_LOAD);       // records loaded
+        const int own = (int)(n_a - g0 < SORT_WIN ? n_a - g0 : SORT_WIN);         // positions whose buckets are ours
+        for (int i = tid; i < cnt; i += 256) { const u128 r = data[g0 + i]; kx[i] = r.x; ky[i] = r.y; }
+        for (int k = tid; k < SORT_LOAD / 64 + 2; k += 256) flags[k] = 0;
+        __syncthreads();
+        // the read that holds g0, then every read boundary inside the loaded range forces a bucket start
+        int r0;
+        {
+            int lo = 0, hi = n_reads;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (anchor_off[mid] <= g0) lo = mid; else hi = mid; }
+            r0 = lo;
         }
+        for (int r = r0 + tid; r <= n_reads; r += 256) {
+            const int64_t d = anchor_off[r] - g0;
+            if (d > cnt) break;
+            if (d >= 0) atomicOr(&flags[d >> 6], 1ULL << (d & 63));
+        }
+        if (tid == 0 && g0 + cnt == n_a) atomicOr(&flags[cnt >> 6], 1ULL << (cnt & 63));
+        // bin changes
+        for (int i0 = wv * 64; i0 < cnt; i0 += 256) {
+            const int i = i0 + lane;
+            bool st = false;
+            if (i < cnt) {
+                const uint64_t prev = i > 0 ? kx[i - 1] : (g0 > 0 ? data[g0 - 1].x : ~kx[0]);
+                st = anchor_bin(kx[i], bp) != anchor_bin(prev, bp);
+            }
+            const unsigned long long m = __ballot(st);
+            if (lane == 0 && m) atomicOr(&flags[i0 >> 6], m);
+        }
+        __syncthreads();
+        // every bucket start in the owned range is taken by the thread that owns its position
+        for (int i = tid; i < own; i += 256) {
+            if (!(flags[i >> 6] >> (i & 63) & 1)) continue;
+            // end of the bucket: the next start within SMALL_BUCKET positions, else the bucket is a large one (not ours to sort)
+            int e = -1;
+            for (int q = i + 1; q <= i + SMALL_BUCKET && q <= cnt; ++q)
+                if (flags[q >> 6] >> (q & 63) & 1) { e = q; break; }
+            if (e < 0 || e - i <= 1) continue;
+            for (int u = i + 1; u < e; ++u) {  // insertion sort in LDS
+                const uint64_t vx = kx[u], vy = ky[u];
+                int v = u - 1;
+                while (v >= i && anchor_less(vx, vy, kx[v], ky[v])) { kx[v + 1] = kx[v]; ky[v + 1] = ky[v]; --v; }
+                kx[v + 1] = vx; ky[v + 1] = vy;
+            }
+        }
+        __syncthreads();
+        // write back what this window owns: from its first bucket start to the first bucket start at or after SORT_WIN
+        int lo = cnt, hi = cnt;
+        {
+            const int w_end = (cnt >> 6) + 1;
+            for (int w = 0; w < w_end; ++w) if (flags[w]) { lo = (w << 6) + __builtin_ctzll(flags[w]); break; }
+            if (own < cnt) {
+                int w = own >> 6;
+                unsigned long long m = flags[w] >> (own & 63) << (own & 63);
+                while (!m && ++w < w_end) m = flags[w];
+                if (m) hi = (w << 6) + __builtin_ctzll(m);
+                if (hi > cnt) hi = cnt;
+            }
+            if (lo > own) lo = hi;  // no bucket starts in the owned range: nothing to write
+        }
+        for (int i = lo + tid; i < hi; i += 256) { u128 r; r.x = kx[i]; r.y = ky[i]; data[g0 + i] = r; }
+        if (work && tid == 0) atomicAdd(work, (unsigned long long)(hi > lo ? hi - lo : 0));
+        __syncthreads();
     }
 }
 

@@ -167,19 +167,19 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             lists.cap[0] = (unsigned int)c0; lists.cap[1] = (unsigned int)c1; lists.cap[2] = (unsigned int)c2;
             lists.count = n_list.p;
         }
-        const size_t msd_lds = (size_t)(MSD_NB + 16) * sizeof(uint32_t), chunk_lds = (size_t)(2 * CHUNK_CAP + CHUNK_CAP / 64 + 1) * 8;
+        const size_t msd_lds = (size_t)(MSD_NB + 16) * sizeof(uint32_t);
         static std::once_flag lds_attr;
         std::call_once(lds_attr, [&]() {
             (void)hipFuncSetAttribute((const void *)anchor_msd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_lds);
-            (void)hipFuncSetAttribute((const void *)anchor_chunk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chunk_lds);
         });
         const int gr = std::max(1, std::min(n, 256 * 4));
         hipLaunchKernelGGL(anchor_msd_kernel, dim3(gr), dim3(MSD_THREADS), msd_lds, st, (const u128 *)tmp.p, o.anchors.p, (const int64_t *)o.anchor_off.p, n, bp,
-                           o.used.p + 2);
+                           lists, o.used.p + 2);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(12, 47);
-        hipLaunchKernelGGL(anchor_chunk_sort_kernel, dim3(gr), dim3(CHUNK_THREADS), chunk_lds, st, o.anchors.p, (const int64_t *)o.anchor_off.p, n, bp, lists,
-                           o.used.p + 2);
+        const int64_t n_win = (n_a + SORT_WIN - 1) / SORT_WIN;
+        hipLaunchKernelGGL(anchor_window_sort_kernel, dim3((unsigned)std::min<int64_t>(n_win, 256 * 64)), dim3(256), 0, st, o.anchors.p,
+                           (const int64_t *)o.anchor_off.p, n, n_a, bp, o.used.p + 2);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(12, 48);
         hipLaunchKernelGGL(anchor_bitonic_list_kernel<BITONIC_SMALL>, dim3(256 * 16), dim3(256), 0, st, o.anchors.p, (const SortSeg *)lists.seg[0],
