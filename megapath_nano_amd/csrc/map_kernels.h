@@ -11,6 +11,8 @@
 #include "mpn_common.h"
 #include "map_types.h"
 
+#include <type_traits>
+
 namespace mpn {
 
 __device__ __forceinline__ uint64_t hash64m(uint64_t key, uint64_t mask) {
@@ -25,25 +27,174 @@ __device__ __forceinline__ uint64_t hash64m(uint64_t key, uint64_t mask) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// (w,k)-minimizers, one lane per CHUNK of a sequence.  minimap2's sketch is a sequential window automaton
-// (ring of the last w non-symmetric k-mers; ties go to the newest; identical minima are all reported; the run
-// length l since the last ambiguous base gates the output).  Its state at position p0 depends only on the last
-// w + k - 1 window elements and on min(l, w + k), so a lane reconstructs it exactly by replaying a short
-// warm-up [p0 - D, p0) from the reset state without emitting: if the warm-up holds an ambiguous base the
-// automaton was reset there anyway; otherwise l reached w + k inside the warm-up, i.e. it is saturated in the
-// true run as well (for even k, where symmetric k-mers do not advance l, D is doubled until that holds).
-// The ring lives in LDS as [slot][thread] (conflict-free).  FILL=false counts, FILL=true writes.
+// (w,k)-minimizers.  A sequence is cut into CHUNKS of C positions; a chunk OWNS the minimizers whose position (the last
+// base of the k-mer) lies in it, and the output of a sequence is the concatenation of its chunks' outputs (minimap2
+// reports minimizers in position order).  Two kernels produce a chunk:
+//
+//  * sketch_fast_kernel -- regular chunks: no ambiguous base within reach, not at the ends of the sequence, odd k (no
+//    k-mer equals its reverse complement).  There minimap2's window automaton reports exactly the positions p whose
+//    hash is the minimum (ties included) of at least one window of w consecutive k-mers containing p: with L / R the
+//    numbers of consecutive neighbours to the left / right whose hash is not smaller, that is L + R >= w - 1.  One
+//    wave per chunk, a lane per position: bases are loaded coalesced, packed 2 bits per base in LDS, the k-mer of a
+//    position is two LDS words and a shift, the hash runs in 32-bit registers when 2k <= 32, and the window test is
+//    2(w-1) LDS reads of 4 bytes.  No divergence, ~100 lane-instructions per base (the automaton below: ~5000).
+//  * sketch_chunk_kernel -- every other chunk (listed by the fast kernel): exact replay of minimap2's sequential
+//    automaton by one lane per chunk.  The ring of the last w window elements lives in LDS as [slot][lane].  The state
+//    at p0 depends only on the last w + k - 1 window elements and on min(l, w + k), so the lane reconstructs it by
+//    replaying a short warm-up [p0 - D, p0) from the reset state: if the warm-up holds an ambiguous base the automaton
+//    was reset there anyway; otherwise l saturated inside it (for even k, where symmetric k-mers do not advance l, D
+//    is doubled until that holds).  It then runs w window steps past the chunk, because a minimizer is reported when
+//    it is replaced or leaves the window, and keeps the reports whose position the chunk owns.
+// FILL = false counts (chunk_cnt), FILL = true writes at mz_off[seq] + chunk_rel[chunk].
+constexpr int SKETCH_FAST_MAX_W = 32;
+
+template <bool HASH64>
+__device__ __forceinline__ uint64_t sketch_hash(uint64_t key, uint64_t mask) {
+    if (HASH64) return hash64m(key, mask);
+    // the same mixing on 32-bit registers: every step of hash64m is reduced modulo 2^(2k) <= 2^32 before a right shift
+    uint32_t h = (uint32_t)key;
+    const uint32_t m = (uint32_t)mask;
+    h = (~h + (h << 21)) & m;
+    h = h ^ h >> 24;
+    h = ((h + (h << 3)) + (h << 8)) & m;
+    h = h ^ h >> 14;
+    h = ((h + (h << 2)) + (h << 4)) & m;
+    h = h ^ h >> 28;
+    h = (h + (h << 31)) & m;
+    return h;
+}
+
+// Is the chunk [p0, p1) of a sequence of length len regular, as far as its place in the sequence goes?  [A0, A1) is the range
+// of bases that must also be free of ambiguous codes: an ambiguous base resets the automaton's run length l, and while
+// l < w + k (the w + k - 1 steps after it) nothing is reported, not even a minimum whose turn ends there; a minimizer at p
+// is reported at step p + w at the latest.  So the chunk's reports are the regular ones iff no such base lies in
+// [p0 - 2w - k, p1 + w], the sequence starts before that range and ends after it (the end of a sequence reports the
+// last minimum unconditionally).
+__device__ __forceinline__ bool sketch_chunk_in_range(int p0, int p1, int len, int w, int k, int *A0, int *A1) {
+    *A0 = p0 - 2 * w - k;
+    *A1 = p1 + w + 1;
+    return (k & 1) && w <= SKETCH_FAST_MAX_W && *A0 >= 0 && *A1 <= len;
+}
+
+template <bool FILL, bool HASH64>
+__global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
+                                                          const int32_t *__restrict__ seq_len, int n,
+                                                          const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
+                                                          const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
+                                                          int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base,
+                                                          int64_t *__restrict__ slow_list, unsigned long long *__restrict__ n_slow) {
+    // per wave: packed bases (2 bits each, first base in the top bits of a word), hashes of the k-mer end positions, strands
+    constexpr int MAX_EXT = 256 + 3 * SKETCH_FAST_MAX_W + 28 + 1 + 16;
+    typedef typename std::conditional<HASH64, uint64_t, uint32_t>::type hash_t;
+    __shared__ uint32_t s_words[4][MAX_EXT / 16 + 2];
+    __shared__ hash_t s_hash[4][256 + 2 * (SKETCH_FAST_MAX_W - 1) + 2];
+    __shared__ unsigned long long s_z[4][(256 + 2 * (SKETCH_FAST_MAX_W - 1)) / 64 + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *words = s_words[wv];
+    hash_t *hs = s_hash[wv];
+    unsigned long long *zs = s_z[wv];
+    const uint64_t mask = (1ULL << 2 * k) - 1;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wv; c < n_chunks; c += (int64_t)gridDim.x * 4) {
+        int lo = 0, hi = n;  // last sequence with chunk_off[seq] <= c
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
+        const int i = lo;
+        const uint8_t *sq = seqs + seq_off[i];
+        const int len = seq_len[i];
+        const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
+        int a0, a1;  // bases loaded: [a0, a1)
+        bool regular = sketch_chunk_in_range(p0, p1, len, w, k, &a0, &a1);
+        const int ext = a1 - a0;
+        const int qbase = w + 2;  // loaded index of the first base of the first k-mer needed: (p0 - (w-1) - (k-1)) - a0
+        if (regular) {
+            // bases -> 2-bit words: 16 consecutive lanes OR their codes together
+            for (int t0 = 0; t0 < ext; t0 += 64) {
+                const int t = t0 + lane;
+                const int code = t < ext ? nt4_code(sq[a0 + t]) : 0;
+                if (__ballot(code > 3)) regular = false;
+                uint32_t v = (uint32_t)(code & 3) << (2 * (15 - (lane & 15)));
+                v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
+                if ((lane & 15) == 0) words[(t0 >> 4) + (lane >> 4)] = v;
+            }
+        }
+        if (!regular) {
+            if (!FILL && lane == 0) slow_list[atomicAdd(n_slow, 1ULL)] = c;
+            continue;
+        }
+        // hash and strand of the k-mers ending at p0 - (w-1) + q, q in [0, n_q)
+        const int n_q = (p1 - p0) + 2 * (w - 1);
+        for (int q0 = 0; q0 < n_q; q0 += 64) {
+            const int q = q0 + lane;
+            uint64_t h = 0;
+            bool z = false;
+            if (q < n_q) {
+                // bases qbase + q .. qbase + q + k - 1 of the loaded range; the k-mer's first base is the most significant
+                const int wi = (qbase + q) >> 4, sh = 2 * ((qbase + q) & 15);
+                const uint64_t hi64 = (uint64_t)words[wi] << 32 | words[wi + 1];
+                // 64 bits hold bases 16 wi .. 16 wi + 31; k <= 28 and (q & 15) + k <= 43 may exceed them: take a third word
+                uint64_t f;
+                if (sh + 2 * k <= 64) f = hi64 << sh >> (64 - 2 * k);
+                else f = ((hi64 << sh) | ((uint64_t)words[wi + 2] >> (32 - sh))) >> (64 - 2 * k);  // (sh >= 10 here)
+                // reverse complement: complement, then reverse the 2-bit groups
+                uint64_t r = ~f & mask;
+                r = __builtin_bitreverse64(r);
+                r = ((r & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((r & 0x5555555555555555ULL) << 1);
+                r >>= 64 - 2 * k;
+                z = !(f < r);
+                h = sketch_hash<HASH64>(z ? r : f, mask);
+            }
+            if (q < n_q) hs[q] = (hash_t)h;
+            const unsigned long long zm = __ballot(z);
+            if (lane == 0) zs[q0 >> 6] = zm;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // window test of the owned positions p = p0 + t: q index of p is t + (w - 1)
+        int run = 0;
+        u128 *out = FILL ? mz + mz_off[i] + chunk_rel[c] : nullptr;
+        for (int t0 = 0; t0 < p1 - p0; t0 += 64) {
+            const int t = t0 + lane;
+            bool emit = false;
+            hash_t hp = 0;
+            int q = 0;
+            if (t < p1 - p0) {
+                q = t + (w - 1);
+                hp = hs[q];
+                int L = 0, R = 0;
+                bool go = true;
+                for (int d = 1; d < w; ++d) { go = go && hs[q - d] >= hp; L += go; }
+                go = true;
+                for (int d = 1; d < w; ++d) { go = go && hs[q + d] >= hp; R += go; }
+                emit = L + R >= w - 1;
+            }
+            const unsigned long long em = __ballot(emit);
+            if (FILL && emit) {
+                const uint32_t pos = (uint32_t)(p0 + t);
+                const uint32_t zbit = (uint32_t)(zs[q >> 6] >> (q & 63) & 1);
+                u128 rec;
+                rec.x = (uint64_t)hp << 8 | (uint64_t)k;
+                rec.y = (uint64_t)(rid_base + (uint32_t)i) << 32 | pos << 1 | zbit;
+                out[run + __popcll(em & ((1ULL << lane) - 1))] = rec;
+            }
+            run += __popcll(em);
+        }
+        if (!FILL && lane == 0) chunk_cnt[c] = run;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
-                                                          const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
+                                                          const int64_t *__restrict__ chunk_off, const int64_t *__restrict__ slow_list,
+                                                          const unsigned long long *__restrict__ n_slow, int C, int w, int k,
                                                           const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
                                                           int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base) {
     extern __shared__ __attribute__((aligned(16))) uint64_t ring[];  // bx[w][64] then by[w][64]
     const int tid = threadIdx.x;
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + tid;
     uint64_t *bx = ring, *by = ring + (size_t)w * blockDim.x;
-    if (c >= n_chunks) return;
+    const int64_t n_list = (int64_t)*n_slow;
+    for (int64_t li = (int64_t)blockIdx.x * blockDim.x + tid; li < n_list; li += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = slow_list[li];
     int lo = 0, hi = n;  // last read with chunk_off[read] <= c
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
     const int i = lo;
@@ -55,31 +206,34 @@ __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restr
     const uint32_t rid = rid_base + (uint32_t)i;
     int64_t cnt = 0;
     u128 *out = FILL ? mz + mz_off[i] + chunk_rel[c] : nullptr;
-#define MPN_PUSH(X, Y) do { if (emit) { if (FILL) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } } while (0)
+    // a report belongs to this chunk iff the reported position does
+#define MPN_PUSH(X, Y) do { const int pp_ = (int)((uint32_t)(Y) >> 1); if (pp_ >= p0 && pp_ < p1) { if (FILL) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } } while (0)
     int D = w + k + 8;
     for (;;) {
         const int ps = max(0, p0 - D);
         uint64_t kmer0 = 0, kmer1 = 0, minx = ~0ULL, miny = ~0ULL;
-        int l = 0, buf_pos = 0, min_pos = 0;
+        int l = 0, buf_pos = 0, min_pos = 0, extra = 0;
         bool saw_n = false, redo = false;
+        int p;
         for (int j = 0; j < w; ++j) bx[j * blockDim.x + tid] = ~0ULL, by[j * blockDim.x + tid] = ~0ULL;
-        for (int p = ps; p < p1; ++p) {
+        for (p = ps; p < len; ++p) {
             if (p == p0 && ps > 0 && !saw_n && l < lsat) { redo = true; break; }  // warm-up too short (even k only)
-            const bool emit = p >= p0;
+            if (p >= p1 && ++extra > w) break;  // w window steps past the chunk: everything it owns has been reported
+            const bool warm = p < p0;
             const int cc = nt4_code(s[p]);
             uint64_t ix = ~0ULL, iy = ~0ULL;
             if (cc < 4) {
                 const int kmer_span = l + 1 < k ? l + 1 : k;
                 kmer0 = (kmer0 << 2 | (uint64_t)cc) & mask;
                 kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)cc) << shift1;
-                if (kmer0 == kmer1) continue;
+                if (kmer0 == kmer1) { if (p >= p1) --extra; continue; }  // (the window does not move)
                 const int z = kmer0 < kmer1 ? 0 : 1;
                 if (l < lsat) ++l;
                 if (l >= k) {
                     ix = hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
                     iy = (uint64_t)rid << 32 | (uint32_t)p << 1 | (uint32_t)z;
                 }
-            } else { l = 0; if (!emit) saw_n = true; }
+            } else { l = 0; if (warm) saw_n = true; }
             bx[buf_pos * blockDim.x + tid] = ix, by[buf_pos * blockDim.x + tid] = iy;
             if (l == w + k - 1 && minx != ~0ULL) {
                 for (int j = buf_pos + 1; j < w; ++j) {
@@ -119,11 +273,12 @@ __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restr
             if (++buf_pos == w) buf_pos = 0;
         }
         if (redo) { D *= 2; cnt = 0; continue; }
-        if (p1 == len && minx != ~0ULL) { const bool emit = true; MPN_PUSH(minx, miny); }
+        if (p == len && minx != ~0ULL) MPN_PUSH(minx, miny);  // the end of the sequence reports the last minimum
         break;
     }
 #undef MPN_PUSH
     if (!FILL) chunk_cnt[c] = (int32_t)cnt;
+    }
 }
 
 // per sequence (one lane): offsets of its chunks' minimizers relative to the sequence start, and the total

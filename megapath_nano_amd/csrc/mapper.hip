@@ -52,20 +52,36 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     std::vector<int64_t> chunk_off((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) chunk_off[i + 1] = chunk_off[i] + (h_len[i] + C - 1) / C;
     const int64_t n_chunks = chunk_off[n];
-    DevBuf<int64_t> cnt, d_chunk_off;
+    DevBuf<int64_t> cnt, d_chunk_off, slow_list;
     DevBuf<int32_t> chunk_cnt, chunk_rel;
+    DevBuf<unsigned long long> n_slow;
     if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1) || d_chunk_off.upload(chunk_off.data(), (size_t)n + 1, st) ||
-        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks))
+        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1) ||
+        n_slow.zero(st))
         return -1;
+    // regular chunks by the position-parallel kernel (a wave per chunk); it lists the others for the automaton kernel
     const size_t lds = (size_t)2 * w * 64 * sizeof(uint64_t);
-    const unsigned grid = (unsigned)((n_chunks + 63) / 64);
-    if (n_chunks > 0) {
-        hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(grid), dim3(64), lds, st, d_seqs, d_off, d_len, n,
-                           (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, (const int64_t *)nullptr, (const int32_t *)nullptr,
-                           chunk_cnt.p, (u128 *)nullptr, rid_base);
-        MPN_HIP_CHECK(hipGetLastError());
-        if (ev) ev->mark(10, 33);
-    }
+    const unsigned fast_grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 3) / 4, 256 * 64));
+    const unsigned slow_grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 63) / 64, 256 * 16));
+    const bool hash64 = 2 * k > 32;
+    auto pass = [&](bool fill, u128 *out) {
+        if (n_chunks <= 0) return;
+        const int64_t *moff = fill ? (const int64_t *)mz_off.p : nullptr;
+        const int32_t *crel = fill ? (const int32_t *)chunk_rel.p : nullptr;
+        int32_t *ccnt = fill ? nullptr : chunk_cnt.p;
+#define MPN_FAST(F, H) hipLaunchKernelGGL((sketch_fast_kernel<F, H>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, \
+                       (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p)
+        if (fill) { if (hash64) MPN_FAST(true, true); else MPN_FAST(true, false); }
+        else { if (hash64) MPN_FAST(false, true); else MPN_FAST(false, false); }
+#undef MPN_FAST
+        if (fill) hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                     (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base);
+        else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base);
+    };
+    pass(false, nullptr);
+    MPN_HIP_CHECK(hipGetLastError());
+    if (ev) ev->mark(10, 33);
     hipLaunchKernelGGL(sketch_chunk_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)d_chunk_off.p, n,
                        (const int32_t *)chunk_cnt.p, chunk_rel.p, cnt.p);
     MPN_HIP_CHECK(hipGetLastError());
@@ -76,10 +92,8 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     MPN_HIP_CHECK(stream_sync(st));
     if (mz.alloc((size_t)total)) return -1;
     if (ev) ev->mark(10);
-    if (n_chunks > 0 && total > 0) {
-        hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(grid), dim3(64), lds, st, d_seqs, d_off, d_len, n,
-                           (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, (const int64_t *)mz_off.p, (const int32_t *)chunk_rel.p,
-                           (int32_t *)nullptr, mz.p, rid_base);
+    if (total > 0) {
+        pass(true, mz.p);
         MPN_HIP_CHECK(hipGetLastError());
         if (ev) ev->mark(10, 34);
     }

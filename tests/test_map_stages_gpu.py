@@ -35,6 +35,38 @@ def test_sketch_matches_oracle(world):
         assert np.array_equal(got[i], mb.sketch(seqs[i], 5, 19, i))
 
 
+def test_sketch_adversarial_matches_oracle(libmpn, oracle_built):
+    """The position-parallel sketch kernel and the automaton kernel must tile a sequence seamlessly: ties (low-complexity
+    sequence), ambiguous bases on and around chunk boundaries (256 positions), lengths around the chunk and window sizes,
+    even k (symmetric k-mers), hashes wider than 32 bits, windows wider than the fast kernel takes."""
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b'ACGT', dtype=np.uint8)
+    rnd = lambda n: alpha[rng.integers(0, 4, size=n)]  # noqa: E731
+    seqs = [np.full(1500, ord('A'), dtype=np.uint8), np.frombuffer(b'AT' * 700, dtype=np.uint8).copy(),
+            np.frombuffer(b'ACG' * 500, dtype=np.uint8).copy(), np.tile(rnd(37), 60)]
+    for L in (0, 1, 14, 15, 16, 24, 25, 26, 255, 256, 257, 280, 281, 282, 511, 512, 513, 537, 538, 800, 5000):
+        seqs.append(rnd(L))
+    for pos in (0, 10, 230, 255, 256, 257, 270, 290, 500, 512, 767, 768, 1023, 1024, 1999):
+        s = rnd(2000)
+        s[pos] = ord('N')
+        seqs.append(s)
+    s = rnd(4000)
+    s[1000:1300] = ord('N')
+    s[2047:2049] = ord('n')
+    seqs.append(s)
+    low = rnd(3000)
+    low[500:1500] = np.frombuffer(b'CA' * 500, dtype=np.uint8)
+    seqs.append(low)
+    seqs.append(np.frombuffer(bytes(rnd(1200)).lower(), dtype=np.uint8).copy())
+    for k, w in ((15, 10), (15, 1), (15, 2), (15, 32), (15, 33), (15, 50), (14, 10), (16, 10), (17, 10), (19, 5), (28, 19), (11, 3), (4, 4)):
+        got = mapper.sketch_batch(seqs, k=k, w=w)
+        for i, sq in enumerate(seqs):
+            want = mb.sketch(sq, w, k, i)
+            assert np.array_equal(got[i], want), (k, w, i, len(sq), len(got[i]), len(want))
+
+
 def test_index_matches_oracle(world):
     import ctypes as ct
     from oracle import mm2_bindings as mb
