@@ -12,6 +12,8 @@
 #include "../../include/mpn_map.h"
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -709,14 +711,71 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn) {
-    if (n_threads <= 1 || n < 2) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
-    std::atomic<int> next(0);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() { for (;;) { int i = next.fetch_add(1); if (i >= n) break; fn(i, t); } });
-    for (auto &x : th) x.join();
-}
+// Host thread pool shared by the pipeline workers.  A worker's host phases (hits from chains, DP-window planning, CIGAR
+// stitching, MAPQ/text) are short bursts between GPU waits; with a private share of the cores a worker would crawl
+// through its burst while the threads of the workers that wait on the GPU sleep.  Every burst is a job in one queue and
+// every idle pool thread helps the oldest open job; the posting thread works on its own job too, so a job always
+// advances.  fn(i, slot): slot < max_par identifies the helping thread (per-thread accumulators of the caller).
+class HostPool {
+    struct Job {
+        const std::function<void(int, int)> *fn;
+        int n, max_par;
+        std::atomic<int> next{0};
+        int slots = 1, active = 0;  // guarded by mu (slot 0 is the posting thread)
+    };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job *> jobs;
+    std::vector<std::thread> threads;
+    bool stop = false;
+
+    static void run(Job &j, int slot) {
+        for (;;) { const int i = j.next.fetch_add(1); if (i >= j.n) break; (*j.fn)(i, slot); }
+    }
+    Job *pick(int *slot) {  // mu held
+        for (Job *j : jobs)
+            if (j->slots < j->max_par && j->next.load(std::memory_order_relaxed) < j->n) { *slot = j->slots++; ++j->active; return j; }
+        return nullptr;
+    }
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            int slot = 0;
+            Job *j = nullptr;
+            cv_work.wait(lk, [&]() { return stop || (j = pick(&slot)) != nullptr; });
+            if (stop) return;
+            lk.unlock();
+            run(*j, slot);
+            lk.lock();
+            if (--j->active == 0) cv_done.notify_all();
+        }
+    }
+
+public:
+    void ensure(int n_threads) {
+        std::lock_guard<std::mutex> g(mu);
+        while ((int)threads.size() < n_threads - 1) threads.emplace_back([this]() { worker(); });
+    }
+    void parallel_for(int n, int max_par, const std::function<void(int, int)> &fn) {
+        if (max_par <= 1 || n < 2) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
+        Job j;
+        j.fn = &fn; j.n = n; j.max_par = max_par;
+        { std::lock_guard<std::mutex> g(mu); jobs.push_back(&j); }
+        cv_work.notify_all();
+        run(j, 0);
+        std::unique_lock<std::mutex> lk(mu);
+        for (auto it = jobs.begin(); it != jobs.end(); ++it) if (*it == &j) { jobs.erase(it); break; }
+        cv_done.wait(lk, [&]() { return j.active == 0; });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+static HostPool g_pool;
+
+static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn) { g_pool.parallel_for(n, n_threads, fn); }
 
 struct ReadState {
     std::vector<Reg> regs;
@@ -874,9 +933,8 @@ static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 
 
 static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn) {
     if (n_threads <= 1 || n < 8192) { fn(0, n, 0); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) th.emplace_back([&, t]() { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
-    for (auto &x : th) x.join();
+    // chunk t of n_threads equal ranges; the chunk index is what the callers use for their per-thread accumulators
+    g_pool.parallel_for(n_threads, n_threads, [&](int t, int) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
 }
 
 // the second pass of a gap fill whose CIGAR failed the z-drop test: exact maximum, band (or anti-diagonal) layout
@@ -1443,6 +1501,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
     if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
     if (n_threads < 1) n_threads = 1;
+    g_pool.ensure(n_threads);
     // sub-batches of ~24 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
     // device arena, so that the host phases of one sub-batch overlap the GPU phases of the others and the
     // latency-bound kernels (chain DP, long extensions) of one overlap the throughput-bound ones of another
@@ -1512,7 +1571,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
             const double t_in = since();
             struct Out { bool on; int wid, sb; double t_in; decltype(since) &f; ~Out() { if (on) fprintf(stderr, "[worker %d] sub-batch %d: %.1f -> %.1f ms\n", wid, sb, t_in, f()); } } out_{dbg_workers, wid, sb, t_in, since};
             if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1],
-                          std::max(1, n_threads / n_workers), S.st, rs, rep_len, lines, paf != nullptr)) {
+                          n_threads, S.st, rs, rep_len, lines, paf != nullptr)) {
                 std::lock_guard<std::mutex> g(mu);
                 err = get_error();
                 failed = 1;

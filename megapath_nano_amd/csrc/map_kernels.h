@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
         const int len = seq_len[i];
         const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
         int a0, a1;  // bases loaded: [a0, a1)
-        bool regular = sketch_chunk_in_range(p0, p1, len, w, k, &a0, &a1);
+        const bool in_range = sketch_chunk_in_range(p0, p1, len, w, k, &a0, &a1);
+        bool regular = in_range;
         const int ext = a1 - a0;
         const int qbase = w + 2;  // loaded index of the first base of the first k-mer needed: (p0 - (w-1) - (k-1)) - a0
         if (regular) {
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
             }
         }
         if (!regular) {
-            if (!FILL && lane == 0) slow_list[atomicAdd(n_slow, 1ULL)] = c;
+            // chunks that are irregular by their place in the sequence are on the host-built part of the list already;
+            // one that holds an ambiguous base is appended here (rare, so the atomic on one counter does not matter)
+            if (!FILL && in_range && lane == 0) slow_list[atomicAdd(n_slow, 1ULL)] = c;
             continue;
         }
         // hash and strand of the k-mers ending at p0 - (w-1) + q, q in [0, n_q)

@@ -56,9 +56,26 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     DevBuf<int32_t> chunk_cnt, chunk_rel;
     DevBuf<unsigned long long> n_slow;
     if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1) || d_chunk_off.upload(chunk_off.data(), (size_t)n + 1, st) ||
-        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1) ||
-        n_slow.zero(st))
+        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1))
         return -1;
+    {
+        // the chunks that are irregular by their place in the sequence (its first chunk(s), its last one(s); all of them for
+        // even k or a very wide window: the same rule as sketch_chunk_in_range) start the automaton kernel's list
+        std::vector<int64_t> slow;
+        const bool none_fast = !(k & 1) || w > SKETCH_FAST_MAX_W;
+        for (int i = 0; i < n; ++i) {
+            const int64_t nc = chunk_off[i + 1] - chunk_off[i];
+            for (int64_t c = 0; c < nc; ++c) {
+                const int64_t p0 = c * C, p1 = std::min<int64_t>(h_len[i], p0 + C);
+                if (none_fast || p0 - 2 * w - k < 0 || p1 + w + 1 > h_len[i]) slow.push_back(chunk_off[i] + c);
+                else if (p1 + C + w + 1 <= h_len[i]) c = std::max<int64_t>(c, (h_len[i] - w - 1) / C - 2);  // skip the regular middle
+            }
+        }
+        const unsigned long long ns = slow.size();
+        if (ns) MPN_HIP_CHECK(hipMemcpyAsync(slow_list.p, slow.data(), ns * 8, hipMemcpyHostToDevice, st));
+        MPN_HIP_CHECK(hipMemcpyAsync(n_slow.p, &ns, 8, hipMemcpyHostToDevice, st));
+        MPN_HIP_CHECK(stream_sync(st));  // (the host vectors leave scope)
+    }
     // regular chunks by the position-parallel kernel (a wave per chunk); it lists the others for the automaton kernel
     const size_t lds = (size_t)2 * w * 64 * sizeof(uint64_t);
     const unsigned fast_grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 3) / 4, 256 * 64));
@@ -79,6 +96,7 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
         else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
                                 (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base);
     };
+    if (ev) ev->skip();  // (host work above: the span of the count pass starts at its launch)
     pass(false, nullptr);
     MPN_HIP_CHECK(hipGetLastError());
     if (ev) ev->mark(10, 33);
