@@ -1555,6 +1555,8 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     int64_t tot_stats[MPN_NSTATS] = {0};
     std::string err;
     const bool dbg_workers = getenv("MPN_DEBUG_WORKERS") != nullptr;
+    g_phase_log.on = getenv("MPN_DEBUG_PHASES") != nullptr;
+    if (g_phase_log.on) { g_phase_log.recs.clear(); g_phase_log.origin = std::chrono::steady_clock::now(); }
     const auto t_call = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     auto worker = [&](int wid) {
@@ -1563,6 +1565,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         if (!S.st && hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
         tl_slot = &S;
         tl_arena = &S.arena;
+        tl_worker_id = wid;
         memset(g_stats, 0, sizeof(g_stats));
         for (;;) {
             const int sb = next.fetch_add(1);
@@ -1599,6 +1602,10 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
             fprintf(stderr, "[slot %d] arena %.2f GB, pools %.2f GB (P %.2f, CIG %.2f, compact %.2f), pinned host %.2f GB\n", wdx, arena / 1e9,
                     pools / 1e9, S.pool_P.cap / 1e9, S.pool_CIG.cap / 1e9, S.pool_compact.cap / 1e9, pinned / 1e9);
         }
+    }
+    if (g_phase_log.on) {
+        for (const auto &r : g_phase_log.recs) fprintf(stderr, "[phase] %d %d %lld %lld\n", r.worker, r.slot, (long long)r.t0, (long long)r.t1);
+        fprintf(stderr, "[phase-end]\n");
     }
     if (failed) { set_error("%s", err.empty() ? "worker failed" : err.c_str()); return -1; }
     {

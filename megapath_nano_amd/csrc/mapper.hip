@@ -26,6 +26,8 @@ hipError_t stream_sync(hipStream_t st) {
 
 
 thread_local int64_t g_stats[MPN_NSTATS] = {0};
+PhaseLog g_phase_log;
+thread_local int tl_worker_id = -1;
 
 void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne) {
     words.assign((size_t)(n + 15) / 16 + 1, 0u);

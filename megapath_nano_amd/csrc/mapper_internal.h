@@ -132,11 +132,29 @@ struct PoolBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+// phase log of the pipeline workers (MPN_DEBUG_PHASES=1): every stop_into() of a worker thread appends
+// (worker, slot of the phase that ended, start ns, end ns); dumped to stderr at the end of the call
+struct PhaseLog {
+    struct Rec { int worker, slot; int64_t t0, t1; };
+    std::mutex mu;
+    std::vector<Rec> recs;
+    bool on = false;
+    std::chrono::steady_clock::time_point origin;
+    void add(int worker, int slot, std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        std::lock_guard<std::mutex> g(mu);
+        recs.push_back({worker, slot, std::chrono::duration_cast<std::chrono::nanoseconds>(a - origin).count(),
+                        std::chrono::duration_cast<std::chrono::nanoseconds>(b - origin).count()});
+    }
+};
+extern PhaseLog g_phase_log;
+extern thread_local int tl_worker_id;
+
 struct WallTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void stop_into(int64_t &acc) {
         auto t1 = std::chrono::steady_clock::now();
         acc += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+        if (g_phase_log.on) g_phase_log.add(tl_worker_id, (int)(&acc - g_stats), t0, t1);
         t0 = t1;
     }
 };

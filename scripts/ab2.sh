@@ -1,0 +1,5 @@
+run() { python -c "
+import json,sys;d=json.loads(open('gpurun_out/sw.log').read().strip().splitlines()[-1]);print(sys.argv[1], round(d['value'],2), round(d['ms_per_step'],1), flush=True)" "$1"; }
+B="timeout -k 10 300 python bench.py --no-cpu-baseline --steps 5 --warmup 2 --pcie-steps 0"
+$B > gpurun_out/sw.log 2>/dev/null; run A1
+$B > gpurun_out/sw.log 2>/dev/null; run A2
