@@ -47,9 +47,10 @@ typedef struct {
     int32_t with_cigar;           /* -c; 0 = mapping_only (aligner.py:188) */
     uint32_t seed;
     int32_t host_threads;         /* threads for the host-side hit bookkeeping; 0 = all cores */
-    int32_t out_sam;              /* -a: the text buffer of mpn_map_batch(_ex) receives SAM records instead of PAF lines
-                                   * (aligner.py:188-192; header lines: mpn_sam_header).  Unmapped reads get a flag-4
-                                   * record; qualities are not carried ('*'). */
+    int32_t out_sam;              /* -a: 1 = the text buffer of mpn_map_batch(_ex) receives SAM records instead of PAF lines
+                                   * (aligner.py:188-192; header lines: mpn_sam_header), 2 = PAF lines AND kept SAM records
+                                   * (mpn_map_batch_q).  Unmapped reads get a flag-4 record; QUAL is '*' unless the
+                                   * qualities are handed over (mpn_map_batch_q, mpn_hits_finish). */
 } mpn_map_opt;
 
 /* minimap2 2.17 defaults for `-x map-ont -c` (-N 5 -p 0.8) */
@@ -134,6 +135,39 @@ typedef struct {
 int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
                          const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs,
                          const int64_t *d_off, const int32_t *d_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols);
+
+/* The general product call: mpn_map_batch_ex plus the reads' base qualities (quals: concatenated like seqs, same offsets, or
+ * NULL) for the QUAL column of SAM records.  opt->out_sam: 0 = PAF into paf, 1 = SAM into paf, 2 = PAF into paf AND the SAM
+ * records of the same hits kept by the library for mpn_map_fetch_sam (the reference's species-placement call keeps both:
+ * bin/lib/aligner.py:183-184,219-227,260-261 -- one mapping pass serves them). */
+int64_t mpn_map_batch_q(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                        const char *quals, const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs, const int64_t *d_off,
+                        const int32_t *d_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols);
+int64_t mpn_map_fetch_sam(char *buf, int64_t cap);  /* like mpn_map_fetch_text, for the SAM text of out_sam == 2 */
+
+/* ---- split index: minimap2 -I <bases> parts and the --split-prefix merge (bin/lib/aligner.py:199; bin/megapath_nano.py:
+ * 4019-4022 passes -I <RAM/64>G, :1124,:1270 pass --split-prefix on every call) ----------------------------------------
+ * A target set that exceeds one index is mapped part by part: the caller builds the index of part p, adds the hits of the
+ * batch against it (mpn_map_batch_part), destroys it, and after the last part mpn_hits_finish merges per read exactly as
+ * minimap2 merges its per-part dumps -- hits pooled with target ids shifted to the concatenated target list,
+ * sub-optimal bookkeeping cleared, ranking / parent-secondary grouping / -p -N selection / SAM-primary / MAPQ
+ * recomputed over the pool, repetitive-seed length = the largest over the parts -- and emits text and columns like
+ * mpn_map_batch_q (column rid and the names in the text refer to the concatenated target list: mpn_hits_seq_*).
+ * minimap2 takes the merge path whenever --split-prefix is given, also for a single part. */
+typedef struct mpn_hits mpn_hits;
+mpn_hits *mpn_hits_create(int32_t n_reads);
+void mpn_hits_destroy(mpn_hits *h);
+int mpn_map_batch_part(const mpn_index *part, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                       const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs, const int64_t *d_off,
+                       const int32_t *d_len, mpn_hits *acc);
+int64_t mpn_hits_finish(mpn_hits *acc, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                        const char *quals, const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap,
+                        mpn_aln_cols *cols);
+int32_t mpn_hits_n_parts(const mpn_hits *h);
+int32_t mpn_hits_n_seq(const mpn_hits *h);
+int32_t mpn_hits_seq_len(const mpn_hits *h, int32_t i);
+int32_t mpn_hits_seq_name(const mpn_hits *h, int32_t i, char *buf, int32_t cap);
+int64_t mpn_hits_sam_header(const mpn_hits *h, const char *cmdline, char *buf, int64_t cap);
 
 /* After mpn_map_batch(_ex) returned -3 the results of that call are kept by the library (process-wide, until the next
  * mapping call): fetch them with larger buffers instead of mapping the batch again.

@@ -1,247 +1,422 @@
-"""Host-side mirror of /root/reference/bin/lib/aligner.py `Align()` (:93-342) on top of libmpn.so.
+"""Host-side mirror of the reference's `Align()` (/root/reference/bin/lib/aligner.py:93-342) on top of libmpn.so.
 
-Same keyword-only signature, same returned DataFrame (columns and dtypes of aligner.py:291-294 plus the taxonomy join
-of :317-332 and `alignment_score_tiebreaker` from Python's `random` seeded with the md5 of the query basenames,
-:160-168,:334-335), same `os.sys.exit(...)` messages on bad arguments (:120,:126,:132,:140,:153,:157,:164), same side
-file `<paf_path_and_prefix>.paf`.  What differs: no child process.  The `minimap2` argv the reference would build
-(:187-199,:219-224) is parsed into mpn_map_opt, the target FASTA files are read here and indexed on the GPU (cached per
-target set), reads are mapped in batches through mpn_map_batch_ex (PAF text + integer columns), and no
-awk/SAM2PAF/samtools step exists: the PAF comes out in minimap2's native `-c` tag order directly.
+Contract kept: the keyword-only signature, the returned DataFrame (the 14 alignment columns of :291-294, the taxonomy
+columns of the join at :317-332, `alignment_score_tiebreaker` drawn from Python's `random` seeded with the md5 of the
+query basenames, :160-168,:334-335), the `os.sys.exit(...)` messages on bad arguments (:120,:126,:132,:140,:153,:157,
+:164) and the side files `<paf_path_and_prefix>.sam/.paf/.bam/.bam.bai` (:183-184,:245-261).
 
-With `paf_path_and_prefix` set the reference runs minimap2 with `-a` and keeps `<prefix>.sam` (:183-184,:219-227): so does
-this mirror (second text pass of the same batch with `out_sam`).  Not produced: `<prefix>.bam/.bai` (the reference pipes
-the SAM through samtools, :246-252).
+What differs: no child processes.  The minimap2 command line the reference would build (:187-199,:219-224) is parsed
+into mpn_map_opt; the target is read ONCE (it may be a FIFO, :143-144) and cut into index parts the way minimap2's `-I`
+does; every part is indexed on the GPU and every batch of reads is mapped against it; with `--split-prefix` (which the
+reference always passes, megapath_nano.py:1124,:1270) the per-part hits are merged like minimap2 merges its dumps.
+PAF and SAM come from the same mapping pass; awk / SAM2PAF / samtools are replaced by integer columns, and the BAM is
+written by megapath_nano_amd.bam.
 """
 import hashlib
 import os
 import random
-import shlex
 
 import numpy as np
 import pandas
 
 from . import fastx, mapper
+from .pipeline import random_block
 
 align_list_col_name_no_assembly_id = ['read_id', 'read_length', 'read_from', 'read_to', 'strand', 'sequence_id',
                                       'sequence_length', 'sequence_from', 'sequence_to', 'match', 'mapq', 'edit_dist',
                                       'alignment_score']
 list_col = ('read_id', 'read_length', 'read_from', 'read_to', 'strand', 'sequence_id', 'sequence_length', 'sequence_from',
             'sequence_to', 'match', 'alignment_block_length', 'mapq', 'edit_dist', 'alignment_score')
+_TEXT_COLS = ('read_id', 'strand', 'sequence_id')
 
+# minimap2 reads the target in mini-batches of at least this many bases (mm_idx_reader); the environment override exists so
+# that tests can cut small target sets into parts
+IDX_MINI_BATCH = int(os.environ.get('MPN_IDX_MINI_BATCH', 50_000_000))
+IDX_BATCH_DEFAULT = 4_000_000_000  # minimap2 -I default
+
+read_fastx = fastx.read_fastx
 _INDEX_CACHE = {}
 
 
-read_fastx = fastx.read_fastx
+# ---- minimap2 command line -------------------------------------------------------------------------------------------
+def parse_num(text):
+    """minimap2's mm_parse_num: a number with an optional K/M/G suffix."""
+    text = text.strip()
+    mult = {'k': 1e3, 'm': 1e6, 'g': 1e9}.get(text[-1:].lower())
+    return int(float(text[:-1]) * mult + .499) if mult else int(float(text) + .499)
+
+
+class AlignerOptions:
+    """The subset of minimap2's command line the reference uses (megapath_nano.py:1124,:1270,:1383,:221-241)."""
+
+    _INT = {'-N': 'best_n', '-k': None, '-w': None, '-A': 'a', '-B': 'b', '-s': 'min_dp_max'}
+
+    def __init__(self, args, mapping_only):
+        self.k, self.w = 15, 10
+        self.batch_bases = IDX_BATCH_DEFAULT
+        self.split = False
+        fields = {}
+        args = list(args or [])
+        i = 0
+        while i < len(args):
+            a = args[i]
+            if a in ('-c', '-a'):
+                i += 1
+                continue
+            if a == '--split-prefix':
+                self.split = True
+                i += 2
+                continue
+            flag = a[:2]
+            if not a.startswith('-') or a.startswith('--') or flag not in ('-x', '-N', '-p', '-k', '-w', '-A', '-B', '-O', '-E', '-s',
+                                                                           '-z', '-f', '-t', '-I'):
+                raise ValueError(f'aligner option {a} is not understood')
+            if len(a) > 2:
+                value = a[2:]
+                i += 1
+            else:
+                if i + 1 >= len(args):
+                    raise ValueError(f'aligner option {a} needs a value')
+                value = args[i + 1]
+                i += 2
+            if flag == '-x':
+                if value != 'map-ont':
+                    raise ValueError(f'preset {value} is not implemented (map-ont only)')
+            elif flag == '-k':
+                self.k = int(value)
+            elif flag == '-w':
+                self.w = int(value)
+            elif flag in self._INT:
+                fields[self._INT[flag]] = int(value)
+            elif flag == '-p':
+                fields['pri_ratio'] = float(value)
+            elif flag == '-f':
+                fields['mid_occ_frac'] = float(value)
+            elif flag in ('-O', '-E', '-z'):
+                first, _, second = value.partition(',')
+                lo, hi = {'-O': ('q', 'q2'), '-E': ('e', 'e2'), '-z': ('zdrop', 'zdrop_inv')}[flag]
+                fields[lo] = int(first)
+                if second:
+                    fields[hi] = int(second)
+                elif flag == '-z':
+                    fields[hi] = int(first)
+            elif flag == '-I':
+                self.batch_bases = parse_num(value)
+            # -t: the library owns its threads
+        self.opt = mapper.default_opt(with_cigar=0 if mapping_only else 1, **fields)
+
+
+def parse_aligner_options(aligner_options, mapping_only):
+    """-> (MapOpt, k, w)"""
+    o = AlignerOptions(aligner_options, mapping_only)
+    return o.opt, o.k, o.w
+
+
+# ---- targets: one pass over the files, cut into index parts like minimap2 -I ----------------------------------------------
+def iter_target_records(paths):
+    for path in paths:
+        kind, stream = fastx.open_once(path)
+        try:
+            if kind == 'index':
+                raise ValueError(f'{path}: a saved index cannot be mixed with sequence targets')
+            for name, seq, _ in fastx.iter_fastx(stream):
+                yield name, seq
+        finally:
+            stream.close()
+
+
+def iter_target_parts(records, batch_bases):
+    """minimap2's index reader (index.c: mm_idx_gen): the target is taken in mini-batches of at least IDX_MINI_BATCH bases
+    (whole sequences); a part is closed after the first mini-batch that brings it OVER batch_bases.  Yields lists of
+    (name, sequence)."""
+    part, part_bases, mini = [], 0, 0
+    for name, seq in records:
+        part.append((name, seq))
+        mini += len(seq)
+        if mini >= IDX_MINI_BATCH:
+            part_bases += mini
+            mini = 0
+            if part_bases > batch_bases:
+                yield part
+                part, part_bases = [], 0
+    if part:
+        yield part
 
 
 def load_target(path, k, w):
-    """The target of an aligner call -> mapper.Index.  The path is opened exactly once (it is a FIFO in the reference's
-    human/decoy call, aligner.py:143-144): a saved index is loaded (megapath_nano.py:1641-1645), sequences are indexed."""
+    """One target path -> mapper.Index: a saved index is loaded (megapath_nano.py:1641-1645), sequences are indexed.
+    The path is opened exactly once (it is a FIFO in the reference's human/decoy call, aligner.py:143-144)."""
     kind, stream = fastx.open_once(path)
     try:
-        if kind == 'index':
-            if not fastx.is_fifo(path):
-                stream.close()
-                return mapper.Index.load(path)
-            import tempfile
-            with tempfile.NamedTemporaryFile(suffix='.mpi') as tmp:  # mpn_index_load wants a seekable file
-                while True:
-                    chunk = stream.read(1 << 24)
-                    if not chunk:
-                        break
-                    tmp.write(chunk)
-                tmp.flush()
-                return mapper.Index.load(tmp.name)
-        return mapper.Index([(n, sq) for n, sq, _ in fastx.iter_fastx(stream)], k=k, w=w)
+        if kind != 'index':
+            return mapper.Index([(n, sq) for n, sq, _ in fastx.iter_fastx(stream)], k=k, w=w)
+        if not fastx.is_fifo(path):
+            stream.close()
+            return mapper.Index.load(path)
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix='.mpi') as tmp:  # mpn_index_load wants a seekable file
+            for chunk in iter(lambda: stream.read(1 << 24), b''):
+                tmp.write(chunk)
+            tmp.flush()
+            return mapper.Index.load(tmp.name)
     finally:
         if not stream.closed:
             stream.close()
 
 
-def parse_aligner_options(aligner_options, mapping_only):
-    """minimap2 CLI subset used by the reference (megapath_nano.py:1124,:1270,:1383,:221-241) -> (MapOpt, k, w)."""
-    k, w = 15, 10
-    kw = {}
-    args = list(aligner_options or [])
-    i = 0
+def _is_saved_index(paths):
+    if len(paths) != 1 or fastx.is_fifo(paths[0]):
+        return False
+    try:
+        with open(paths[0], 'rb') as f:
+            return f.read(8) == fastx.INDEX_MAGIC
+    except OSError:
+        return False
 
-    def val():
-        nonlocal i
-        a = args[i]
-        if len(a) > 2 and not a.startswith('--'):
-            return a[2:]
-        i += 1
-        return args[i]
 
-    while i < len(args):
-        a = args[i]
-        if a.startswith('-x'):
-            preset = val()
-            if preset not in ('map-ont',):
-                raise ValueError(f'preset {preset} is not implemented (map-ont only)')
-        elif a.startswith('-N'):
-            kw['best_n'] = int(val())
-        elif a.startswith('-p'):
-            kw['pri_ratio'] = float(val())
-        elif a.startswith('-k'):
-            k = int(val())
-        elif a.startswith('-w'):
-            w = int(val())
-        elif a.startswith('-A'):
-            kw['a'] = int(val())
-        elif a.startswith('-B'):
-            kw['b'] = int(val())
-        elif a.startswith('-O'):
-            v = val().split(',')
-            kw['q'] = int(v[0])
-            kw['q2'] = int(v[1]) if len(v) > 1 else kw.get('q2', 24)
-        elif a.startswith('-E'):
-            v = val().split(',')
-            kw['e'] = int(v[0])
-            kw['e2'] = int(v[1]) if len(v) > 1 else kw.get('e2', 1)
-        elif a.startswith('-s'):
-            kw['min_dp_max'] = int(val())
-        elif a.startswith('-z'):
-            v = val().split(',')
-            kw['zdrop'] = int(v[0])
-            kw['zdrop_inv'] = int(v[1]) if len(v) > 1 else int(v[0])
-        elif a.startswith('-f'):
-            kw['mid_occ_frac'] = float(val())
-        elif a.startswith('-t') or a.startswith('-I'):
-            val()  # threads / index batch size: owned by the library
-        elif a == '--split-prefix':
-            i += 1
-        elif a in ('-c', '-a'):
-            pass
+# ---- reads ---------------------------------------------------------------------------------------------------------------
+def iter_read_batches(query_paths, batch_bases=200_000_000, device=None):
+    """PackedReads of at most batch_bases each, qualities included, in file order."""
+    names, seqs, quals, acc = [], [], [], 0
+
+    def flush():
+        return mapper.PackedReads(names, seqs, device=device, quals=quals)
+    for path in query_paths:
+        kind, stream = fastx.open_once(path)
+        try:
+            if kind == 'index':
+                raise ValueError(f'{path}: a saved index is not a read file')
+            for name, seq, qual in fastx.iter_fastx(stream):
+                if names and acc + len(seq) > batch_bases:
+                    yield flush()
+                    names, seqs, quals, acc = [], [], [], 0
+                names.append(name)
+                seqs.append(seq)
+                quals.append(qual)
+                acc += len(seq)
+        finally:
+            stream.close()
+    if names:
+        yield flush()
+
+
+# ---- the engine shared by Align() and bin/mpn-aligner ----------------------------------------------------------------------
+class MappedBatch:
+    """What one batch of reads produced: text(s), integer columns, and the target table the column `rid` indexes."""
+
+    def __init__(self, packed, paf, sam, cols, target_names, target_lens):
+        self.packed, self.paf, self.sam, self.cols = packed, paf, sam, cols
+        self.target_names, self.target_lens = target_names, target_lens
+
+
+def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False, want_cols=True, read_batch_bases=200_000_000,
+              save_index=None, cache_key=None):
+    """Map the reads of query_paths against the targets.  -> (list of MappedBatch, SAM header text or None).
+
+    Without `--split-prefix` and with more than one index part minimap2 reports every part on its own; the batches are
+    then returned part by part, in that order."""
+    opt = options.opt
+    out_opt = mapper.MapOpt.from_buffer_copy(bytes(opt))
+    out_opt.out_sam = (2 if want_paf else 1) if want_sam else 0
+    text_wanted = want_paf or want_sam
+    batches = list(iter_read_batches(query_paths, read_batch_bases))
+    results, header = [], None
+
+    def single(idx):
+        nonlocal header
+        if want_sam:
+            header = idx.sam_header()
+        names, lens = np.array(idx.names, dtype=object), idx.lens
+        for b in batches:
+            text, sam, cols = mapper.map_batch_full(idx, out_opt, b, want_paf=text_wanted, want_cols=want_cols)
+            if want_sam and not want_paf:
+                text, sam = None, text
+            results.append(MappedBatch(b, text, sam, cols, names, lens))
+
+    if _is_saved_index(target_paths):
+        idx = _INDEX_CACHE.get(cache_key) if cache_key else None
+        if idx is None:
+            idx = mapper.Index.load(target_paths[0])
+            if cache_key:
+                _INDEX_CACHE[cache_key] = idx
+        if options.split:
+            hits = [mapper.Hits(b) for b in batches]
+            for h in hits:
+                h.add_part(idx, opt)
+            _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
+            header = hits[0].sam_header() if (want_sam and hits) else (idx.sam_header() if want_sam else None)
+            for h in hits:
+                h.close()
         else:
-            raise ValueError(f'aligner option {a} is not understood')
-        i += 1
-    opt = mapper.default_opt(with_cigar=0 if mapping_only else 1, **kw)
-    return opt, k, w
+            single(idx)
+        return results, header
+
+    hits = [mapper.Hits(b) for b in batches] if options.split else None
+    headers = []
+
+    def use(idx):
+        if hits is not None:
+            for h in hits:
+                h.add_part(idx, opt)
+        else:
+            single(idx)
+            headers.append(header)
+
+    cached = _INDEX_CACHE.get(cache_key) if cache_key else None
+    if cached is not None:
+        use(cached)
+    else:
+        prev, n_parts = None, 0
+        for part in iter_target_parts(iter_target_records(target_paths), options.batch_bases):
+            if prev is not None:   # a part's index leaves HBM before the next one is built
+                prev.close()
+            idx = mapper.Index(part, k=options.k, w=options.w)
+            del part
+            n_parts += 1
+            if save_index and n_parts == 1:
+                idx.save(save_index)  # minimap2 -d FILE
+            use(idx)
+            prev = idx
+        if prev is not None:
+            if cache_key and n_parts == 1:
+                _INDEX_CACHE[cache_key] = prev
+            else:
+                prev.close()
+    if hits is not None:
+        if want_sam:
+            header = hits[0].sam_header() if hits else ''
+        _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
+        for h in hits:
+            h.close()
+    elif headers:
+        header = headers[0]
+    return results, header
+
+
+def _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results):
+    for h in hits:
+        text, sam, cols = h.finish(out_opt, want_paf=want_paf or want_sam, want_cols=want_cols)
+        if want_sam and not want_paf:
+            text, sam = None, text
+        names, lens = h.targets()
+        results.append(MappedBatch(h.packed, text, sam, cols, np.array(names, dtype=object), lens))
+
+
+# ---- Align() ---------------------------------------------------------------------------------------------------------------
+def _count_given(*tables_and_columns):
+    return sum(1 for table, column in tables_and_columns if table is not None and table[column].shape[0] > 0)
+
+
+def _paths_of_assemblies(assembly_metadata, assembly_list, folder, missing_message, need_all=False):
+    table = assembly_metadata.get_assembly_path(assembly_list=assembly_list)
+    if table is None or (need_all and table.shape[0] != assembly_list['assembly_id'].shape[0]):
+        os.sys.exit(missing_message)
+    table['path'] = [os.path.join(folder, p) for p in table['path']]
+    return table
+
+
+def _resolve_targets(assembly_metadata, global_options, target_filename_list, target_assembly_list, align_concat_fa, module_option):
+    """-> list of target paths (exit messages of aligner.py:120,126,132,140)."""
+    if align_concat_fa:
+        if module_option == 'amplicon_filter_module':
+            return [str(target_filename_list['path'][0])]
+        nano_dir = global_options.get('nano_dir', os.getcwd())
+        return [f'{nano_dir}/genomes/refseq/refseq.fna.gz']
+    if _count_given((target_filename_list, 'path'), (target_assembly_list, 'assembly_id')) != 1:
+        os.sys.exit('Exactly one of target_filename_list and target_assembly_list must be specified')
+    by_assembly = target_assembly_list is not None and len(target_assembly_list['assembly_id']) > 0
+    if by_assembly:
+        target_filename_list = _paths_of_assemblies(assembly_metadata, target_assembly_list, global_options['assembly_folder'],
+                                                    'Target assembly_id not found')
+        lengths = assembly_metadata.get_assembly_length(assembly_list=target_assembly_list)
+        if lengths is None:
+            os.sys.exit('Target assembly_length not found')
+        n_lengths = lengths.shape[0]
+    else:
+        n_lengths = target_filename_list.shape[0]
+    if n_lengths != target_filename_list.shape[0]:
+        os.sys.exit('Number of target_assembly_length does not match number of target_filename_list')
+    return [str(p) for p in target_filename_list['path']]
+
+
+def _resolve_queries(assembly_metadata, global_options, query_filename_list, query_assembly_list):
+    """-> list of query paths (exit messages of aligner.py:153,157,164)."""
+    if _count_given((query_filename_list, 'path'), (query_assembly_list, 'assembly_id')) != 1:
+        os.sys.exit('Exactly one of query_filename_list and query_assembly_list must be specified')
+    if query_assembly_list is not None and query_assembly_list['assembly_id'].shape[0] > 0:
+        query_filename_list = _paths_of_assemblies(assembly_metadata, query_assembly_list, global_options['assembly_folder'],
+                                                   'Query assembly_id not found', need_all=True)
+    paths = [str(p) for p in query_filename_list['path']]
+    for p in paths:
+        if not os.path.isfile(p):
+            os.sys.exit('Query file ' + p + ' not exists')
+    return paths
+
+
+def _frame_of(batch):
+    c = batch.cols
+    i64 = lambda a: a.astype(np.int64)  # noqa: E731
+    names = np.array(batch.packed.names, dtype=object)
+    return pandas.DataFrame({
+        'read_id': names[c['read_idx']], 'read_length': i64(batch.packed.lens[c['read_idx']]), 'read_from': i64(c['qs']),
+        'read_to': i64(c['qe']), 'strand': np.where(c['rev'] != 0, '-', '+'), 'sequence_id': batch.target_names[c['rid']],
+        'sequence_length': i64(batch.target_lens[c['rid']]), 'sequence_from': i64(c['rs']), 'sequence_to': i64(c['re']),
+        'match': i64(c['mlen']), 'alignment_block_length': i64(c['blen']), 'mapq': i64(c['mapq']), 'edit_dist': i64(c['nm']),
+        'alignment_score': i64(c['as_'])})
+
+
+def _join_taxonomy(align_list, sequence_tax):
+    """Inner join on sequence_id with a many-to-one check (aligner.py:317-332), row order of align_list kept."""
+    keys = pandas.Index(sequence_tax['sequence_id'])
+    if keys.has_duplicates:
+        raise pandas.errors.MergeError('Merge keys are not unique in right dataset; not a many-to-one merge')
+    where = keys.get_indexer(align_list['sequence_id'])
+    hit = where >= 0
+    if not hit.all():
+        print('Some sequence id cannot be matched', file=os.sys.stderr)
+    joined = align_list[hit].copy()
+    for col in ('assembly_id', 'tax_id', 'species_tax_id', 'genus_tax_id'):
+        joined[col] = sequence_tax[col].to_numpy()[where[hit]]
+    return joined
 
 
 def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_filename_list=None,
           query_assembly_list=None, target_filename_list=None, target_assembly_list=None, aligner_options=None,
           paf_path_and_prefix=None, mapping_only=False, module_option='', AMR_output_folder='', align_concat_fa=False,
           batch_bases=200_000_000):
-    nano_dir = global_options.get('nano_dir', os.getcwd())
-    if not align_concat_fa:
-        num_target_specification = 0
-        if target_filename_list is not None and target_filename_list['path'].shape[0] > 0:
-            num_target_specification += 1
-        if target_assembly_list is not None and target_assembly_list['assembly_id'].shape[0] > 0:
-            num_target_specification += 1
-        if num_target_specification != 1:
-            os.sys.exit('Exactly one of target_filename_list and target_assembly_list must be specified')
-        if target_assembly_list is not None and len(target_assembly_list['assembly_id']) > 0:
-            target_filename_list = assembly_metadata.get_assembly_path(assembly_list=target_assembly_list)
-            if target_filename_list is None:
-                os.sys.exit('Target assembly_id not found')
-            target_filename_list['path'] = target_filename_list['path'].map(
-                lambda x: os.path.join(global_options['assembly_folder'], x))
-            target_assembly_length = assembly_metadata.get_assembly_length(assembly_list=target_assembly_list)
-            if target_assembly_length is None:
-                os.sys.exit('Target assembly_length not found')
-        else:
-            target_assembly_length = target_filename_list.assign(assembly_length=lambda x: 1)
-        if target_assembly_length.shape[0] != target_filename_list.shape[0]:
-            os.sys.exit('Number of target_assembly_length does not match number of target_filename_list')
-        target_paths = list(target_filename_list['path'])
-    elif module_option != 'amplicon_filter_module':
-        target_paths = [f'{nano_dir}/genomes/refseq/refseq.fna.gz']
-    else:
-        target_paths = [f'{target_filename_list["path"][0]}']
+    target_paths = _resolve_targets(assembly_metadata, global_options, target_filename_list, target_assembly_list,
+                                    align_concat_fa, module_option)
+    query_paths = _resolve_queries(assembly_metadata, global_options, query_filename_list, query_assembly_list)
+    # the tiebreaker stream: Python's generator seeded with the md5 of the query basenames (aligner.py:160-168)
+    random.seed(hashlib.md5(''.join(os.path.split(q)[1] for q in query_paths).encode()).hexdigest())
 
-    num_query_specification = 0
-    if query_filename_list is not None and query_filename_list['path'].shape[0] > 0:
-        num_query_specification += 1
-    if query_assembly_list is not None and query_assembly_list['assembly_id'].shape[0] > 0:
-        num_query_specification += 1
-    if num_query_specification != 1:
-        os.sys.exit('Exactly one of query_filename_list and query_assembly_list must be specified')
-    if query_assembly_list is not None and query_assembly_list['assembly_id'].shape[0] > 0:
-        query_filename_list = assembly_metadata.get_assembly_path(assembly_list=query_assembly_list)
-        if query_filename_list is None or query_filename_list.shape[0] != query_assembly_list['assembly_id'].shape[0]:
-            os.sys.exit('Query assembly_id not found')
-        query_filename_list['path'] = query_filename_list['path'].map(
-            lambda x: os.path.join(global_options['assembly_folder'], x))
-
-    random_hash_string = ''
-    for query in query_filename_list['path']:
-        if not os.path.isfile(query):
-            os.sys.exit('Query file ' + query + ' not exists')
-        random_hash_string = random_hash_string + os.path.split(query)[1]
-    random.seed(hashlib.md5(random_hash_string.encode()).hexdigest())                            # :167-168
-
-    opt, k, w = parse_aligner_options(aligner_options, mapping_only)
-    idx_key = (tuple(target_paths), k, w)
-    idx = _INDEX_CACHE.get(idx_key)
-    if idx is None:
-        if len(target_paths) == 1:
-            idx = load_target(target_paths[0], k, w)    # sequences, or a prebuilt index (megapath_nano.py:1641-1645)
-        else:
-            genomes = []
-            for tp in target_paths:
-                genomes.extend(read_fastx(tp))
-            idx = mapper.Index(genomes, k=k, w=w)
-            del genomes
-        _INDEX_CACHE[idx_key] = idx
-    seq_names = np.array(idx.names, dtype=object)
-    seq_lens = idx.lens
-
+    options = AlignerOptions(aligner_options, mapping_only)
     output_paf = not (paf_path_and_prefix is None or paf_path_and_prefix == '')
-    paf_file = open(f'{paf_path_and_prefix}.paf', 'w') if output_paf else None
-    sam_file = open(f'{paf_path_and_prefix}.sam', 'w') if output_paf and not mapping_only else None
-    if sam_file is not None:
-        sam_file.write(idx.sam_header())
-        sam_opt = mapper.MapOpt.from_buffer_copy(bytes(opt))
-        sam_opt.out_sam = 1
-    frames = []
-    try:
-        for query in query_filename_list['path']:
-            reads = read_fastx(query)
-            lo = 0
-            while lo < len(reads):
-                hi, acc = lo, 0
-                while hi < len(reads) and (hi == lo or acc + len(reads[hi][1]) <= batch_bases):
-                    acc += len(reads[hi][1])
-                    hi += 1
-                packed = mapper.PackedReads([r[0] for r in reads[lo:hi]], [r[1] for r in reads[lo:hi]])
-                paf, c = mapper.map_batch_ex(idx, opt, packed, want_paf=output_paf, want_cols=True)
-                if paf_file is not None:
-                    paf_file.write(paf)
-                if sam_file is not None:
-                    sam_file.write(mapper.map_batch_ex(idx, sam_opt, packed, want_paf=True, want_cols=False)[0])
-                names = np.array(packed.names, dtype=object)
-                frames.append(pandas.DataFrame({
-                    'read_id': names[c['read_idx']], 'read_length': packed.lens[c['read_idx']].astype(np.int64),
-                    'read_from': c['qs'].astype(np.int64), 'read_to': c['qe'].astype(np.int64),
-                    'strand': np.where(c['rev'] != 0, '-', '+'), 'sequence_id': seq_names[c['rid']],
-                    'sequence_length': seq_lens[c['rid']].astype(np.int64), 'sequence_from': c['rs'].astype(np.int64),
-                    'sequence_to': c['re'].astype(np.int64), 'match': c['mlen'].astype(np.int64),
-                    'alignment_block_length': c['blen'].astype(np.int64), 'mapq': c['mapq'].astype(np.int64),
-                    'edit_dist': c['nm'].astype(np.int64), 'alignment_score': c['as_'].astype(np.int64)}))
-                lo = hi
-    finally:
-        if paf_file is not None:
-            paf_file.close()
-        if sam_file is not None:
-            sam_file.close()
+    want_sam = output_paf and not mapping_only
+    regular = all(os.path.isfile(p) for p in target_paths)
+    cache_key = (tuple(target_paths), options.k, options.w, options.batch_bases) if regular else None
+    batches, header = map_files(target_paths, query_paths, options, want_paf=output_paf, want_sam=want_sam, want_cols=True,
+                                read_batch_bases=batch_bases, cache_key=cache_key)
+    if output_paf:
+        with open(f'{paf_path_and_prefix}.paf', 'w') as f:
+            for b in batches:
+                f.write(b.paf)
+    if want_sam:
+        with open(f'{paf_path_and_prefix}.sam', 'w') as f:
+            f.write(header or '')
+            for b in batches:
+                f.write(b.sam)
+        from . import bam  # samtools view -F1796 -b | samtools sort; samtools index (aligner.py:246-252)
+        bam.sam_to_sorted_bam(f'{paf_path_and_prefix}.sam', f'{paf_path_and_prefix}.bam', exclude_flags=1796)
+
+    frames = [_frame_of(b) for b in batches if len(b.cols['read_idx'])]
     if frames:
-        prefilter_align_list = pandas.concat(frames, ignore_index=True)[list(list_col)]
+        table = pandas.concat(frames, ignore_index=True)[list(list_col)]
     else:
-        prefilter_align_list = pandas.DataFrame({c: pandas.Series(dtype=(str if c in ('read_id', 'strand', 'sequence_id')
-                                                                         else np.int64)) for c in list_col})
-    min_alignment_score = global_options['min_alignment_score']
-    align_list = prefilter_align_list.query('sequence_length > 0 and alignment_score >= @min_alignment_score')  # :312
+        table = pandas.DataFrame({c: pandas.Series(dtype=(str if c in _TEXT_COLS else np.int64)) for c in list_col})
+    keep = (table['sequence_length'].to_numpy() > 0) & (table['alignment_score'].to_numpy() >= global_options['min_alignment_score'])
+    align_list = table[keep]                                                                          # aligner.py:311-312
     if target_assembly_list is not None and len(target_assembly_list['assembly_id']) > 0:
-        sequence_assembly_tax_id = assembly_metadata.get_sequence_tax_id(assembly_list=target_assembly_list).set_index(
-            ['sequence_id'])[['assembly_id', 'tax_id', 'species_tax_id', 'genus_tax_id']]
-        num_align = align_list.shape[0]
-        align_list = align_list.merge(right=sequence_assembly_tax_id, how='inner', left_on='sequence_id', right_index=True,
-                                      suffixes=['', '_y'], validate='m:1')
-        if align_list.shape[0] != num_align:
-            print('Some sequence id cannot be matched', file=os.sys.stderr)
-    align_list = align_list.assign(alignment_score_tiebreaker=lambda x: 0)
-    align_list['alignment_score_tiebreaker'] = align_list['alignment_score_tiebreaker'].apply(lambda x: random.random())
-    return align_list
+        align_list = _join_taxonomy(align_list, assembly_metadata.get_sequence_tax_id(assembly_list=target_assembly_list))
+    # one random.random() per surviving row, in row order (aligner.py:334-335)
+    return align_list.assign(alignment_score_tiebreaker=random_block(random, align_list.shape[0]))

@@ -792,16 +792,23 @@ static double event_identity(const Reg &r) {
     return (double)r.mlen / (r.blen + r.n_ambi - n_gap + n_gapo);
 }
 
-static void write_paf(const mpn_index *mi, const mpn_map_opt *o, const char *name, int32_t qlen, const std::vector<Reg> &regs,
+// names and lengths of the targets the hits refer to: one index, or all parts of a split index in order
+struct Targets {
+    const std::vector<std::string> *names;
+    const std::vector<int32_t> *lens;
+};
+
+static void write_paf(const Targets mi_, const mpn_map_opt *o, const char *name, int32_t qlen, const std::vector<Reg> &regs,
                       int32_t rep_len, std::string &out) {
+    const Targets *mi = &mi_;
     char buf[1024];
     for (const Reg &r : regs) {
         const int type = r.id == r.parent ? (r.inv ? 'I' : 'P') : (r.inv ? 'i' : 'S');
         out += name;
         snprintf(buf, sizeof(buf), "\t%d\t%d\t%d\t%c\t", qlen, r.qs, r.qe, "+-"[r.rev]);
         out += buf;
-        out += mi->names[r.rid];
-        snprintf(buf, sizeof(buf), "\t%d\t%d\t%d\t%d\t%d\t%d", mi->lens[r.rid], r.rs, r.re, r.mlen, r.blen, r.mapq);
+        out += (*mi->names)[r.rid];
+        snprintf(buf, sizeof(buf), "\t%d\t%d\t%d\t%d\t%d\t%d", (*mi->lens)[r.rid], r.rs, r.re, r.mlen, r.blen, r.mapq);
         out += buf;
         if (r.has_p) {
             snprintf(buf, sizeof(buf), "\tNM:i:%d\tms:i:%d\tAS:i:%d\tnn:i:%d", r.blen - r.mlen + r.n_ambi, r.dp_max, r.dp_score, r.n_ambi);
@@ -839,14 +846,24 @@ static void sam_seq(std::string &out, const char *seq, int st, int en, bool rev)
     else for (int i = en - 1; i >= st; --i) out += sam_comp(seq[i]);
 }
 
-static void write_sam(const mpn_index *mi, const char *name, int32_t qlen, const char *seq, const std::vector<Reg> &regs,
+// QUAL column of a record whose SEQ is seq[st, en) on strand rev: the qualities in the same orientation, or '*' without them
+static void sam_qual(std::string &out, const char *qual, int st, int en, bool rev) {
+    out += '\t';
+    if (!qual) { out += '*'; return; }
+    if (!rev) out.append(qual + st, (size_t)(en - st));
+    else for (int i = en - 1; i >= st; --i) out += qual[i];
+}
+
+static void write_sam(const Targets mi_, const char *name, int32_t qlen, const char *seq, const char *qual, const std::vector<Reg> &regs,
                       int32_t rep_len, std::string &out) {
+    const Targets *mi = &mi_;
     char buf[1024];
     if (regs.empty()) {
         out += name;
         out += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
         sam_seq(out, seq, 0, qlen, false);
-        snprintf(buf, sizeof(buf), "\t*\trl:i:%d\n", rep_len);
+        sam_qual(out, qual, 0, qlen, false);
+        snprintf(buf, sizeof(buf), "\trl:i:%d\n", rep_len);
         out += buf;
         return;
     }
@@ -859,7 +876,7 @@ static void write_sam(const mpn_index *mi, const char *name, int32_t qlen, const
         out += name;
         snprintf(buf, sizeof(buf), "\t%d\t", flag);
         out += buf;
-        out += mi->names[r.rid];
+        out += (*mi->names)[r.rid];
         snprintf(buf, sizeof(buf), "\t%d\t%d\t", r.rs + 1, r.mapq);
         out += buf;
         if (!r.has_p) out += '*';
@@ -871,9 +888,9 @@ static void write_sam(const mpn_index *mi, const char *name, int32_t qlen, const
             if (clip1) { snprintf(buf, sizeof(buf), "%d%c", clip1, clip_char); out += buf; }
         }
         out += "\t*\t0\t0\t";
-        if ((flag & 0x900) == 0) { sam_seq(out, seq, 0, qlen, r.rev); out += "\t*"; }
+        if ((flag & 0x900) == 0) { sam_seq(out, seq, 0, qlen, r.rev); sam_qual(out, qual, 0, qlen, r.rev); }
         else if (flag & 0x100) out += "*\t*";
-        else { sam_seq(out, seq, r.qs, r.qe, r.rev); out += "\t*"; }
+        else { sam_seq(out, seq, r.qs, r.qe, r.rev); sam_qual(out, qual, r.qs, r.qe, r.rev); }
         if (r.has_p) {
             snprintf(buf, sizeof(buf), "\tNM:i:%d\tms:i:%d\tAS:i:%d\tnn:i:%d", r.blen - r.mlen + r.n_ambi, r.dp_max, r.dp_score, r.n_ambi);
             out += buf;
@@ -897,7 +914,7 @@ static void write_sam(const mpn_index *mi, const char *name, int32_t qlen, const
                 if (q.qe - q.qs < q.re - q.rs) { l_M = q.qe - q.qs; l_D = (q.re - q.rs) - l_M; }
                 else { l_M = q.re - q.rs; l_I = (q.qe - q.qs) - l_M; }
                 const int c5 = q.rev ? qlen - q.qe : q.qs, c3 = q.rev ? q.qs : qlen - q.qe;
-                out += mi->names[q.rid];
+                out += (*mi->names)[q.rid];
                 snprintf(buf, sizeof(buf), ",%d,%c,", q.rs + 1, "+-"[q.rev]);
                 out += buf;
                 if (c5) { snprintf(buf, sizeof(buf), "%dS", c5); out += buf; }
@@ -926,8 +943,6 @@ struct Slot {
 };
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
-
-static struct Kept { std::vector<int32_t> cols; int64_t n_rows = -1; std::string text; bool has_text = false; } g_kept;  // see mpn_map_batch_ex
 
 static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 3 workgroup kernel, 4 strip (else band), 5 band
 
@@ -1329,11 +1344,11 @@ static const struct Nt4Tables {  // ASCII -> 0..4 code, and the complement of a 
 } g_nt4;
 
 // One contiguous range [lo, hi) of the batch through the whole path, on the calling worker's stream and arena.
-// Fills rs[lo..hi), rep_len[lo..hi) and lines[lo..hi) (PAF text, only if want_paf).
+// Fills rs[lo..hi) (the final hits of every read) and rep_len[lo..hi).
 static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *const *names, const char *seqs,
                      const int64_t *seq_off_all, const int32_t *seq_len_all, const uint8_t *d_seqs_p, const int64_t *d_off_all,
                      const int32_t *d_len_all, int lo, int hi, int n_threads, hipStream_t st, std::vector<ReadState> &rs_all,
-                     std::vector<int32_t> &rep_len_all, std::vector<std::string> &lines_all, bool want_paf) {
+                     std::vector<int32_t> &rep_len_all) {
     const int n = hi - lo;
     if (n <= 0) return 0;
     const int64_t *seq_off = seq_off_all + lo;
@@ -1447,7 +1462,6 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
         const int qlen = seq_len[i];
-        const char *nm = names && names[lo + i] ? names[lo + i] : "*";
         if (!S.regs.empty()) {
             if (opt->with_cigar) {
                 filter_regs(opt, qlen, S.regs);
@@ -1457,10 +1471,6 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
                 set_sam_pri(S.regs);
             }
             set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
-        }
-        if (want_paf) {
-            if (opt->out_sam) write_sam(idx, nm, qlen, seqs + seq_off[i], S.regs, h.rep_len[i], lines_all[lo + i]);
-            else if (!S.regs.empty()) write_paf(idx, opt, nm, qlen, S.regs, h.rep_len[i], lines_all[lo + i]);
         }
         n_aln += (int64_t)S.regs.size();
         // the per-read scratch is no longer needed
@@ -1473,22 +1483,27 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     return 0;
 }
 
-extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
-                                    const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
-                                    const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
-    // the worker slots (streams, arenas, pools) are process-wide: concurrent callers take turns
-    static std::mutex call_mu;
-    std::lock_guard<std::mutex> call_guard(call_mu);
+// Hits of a batch accumulated over the parts of a split index (minimap2 -I / --split-prefix): per read the hits of every
+// part with target ids shifted to the concatenated target table, and the largest repetitive-seed span.
+struct mpn_hits {
+    int32_t n_reads = 0, n_parts = 0, k = 15;
+    std::vector<std::vector<Reg>> regs;
+    std::vector<int32_t> rep_len;
+    std::vector<std::string> names;
+    std::vector<int32_t> lens;
+};
+
+// the mapping itself: every read's final hits against ONE index -> rs, rep_len (no text)
+static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                          const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off, const int32_t *r_len,
+                          std::vector<ReadState> &rs, std::vector<int32_t> &rep_len, int *n_threads_out) {
     hipStream_t st0 = 0;
-    memset(g_stats, 0, sizeof(g_stats));
-    if (cols) cols->n_rows = 0;
-    if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; return 0; }
     struct Borrowed {  // device views of the reads: owned uploads or the caller's resident buffers
         DevBuf<uint8_t> seqs; DevBuf<int64_t> off; DevBuf<int32_t> len;
         const uint8_t *p = nullptr; const int64_t *po = nullptr; const int32_t *pl = nullptr;
     } dv;
     int64_t bases = 0;
-    WallTimer whole, wt;
+    WallTimer wt;
     if (r_seqs && r_off && r_len) {
         dv.p = (const uint8_t *)r_seqs; dv.po = r_off; dv.pl = r_len;
         for (int i = 0; i < n; ++i) bases += seq_len[i];
@@ -1501,6 +1516,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
     if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
     if (n_threads < 1) n_threads = 1;
+    *n_threads_out = n_threads;
     g_pool.ensure(n_threads);
     // sub-batches of ~24 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
     // device arena, so that the host phases of one sub-batch overlap the GPU phases of the others and the
@@ -1547,9 +1563,8 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
     }
     int dev = 0;
     MPN_HIP_CHECK(hipGetDevice(&dev));
-    std::vector<ReadState> rs(n);
-    std::vector<int32_t> rep_len(n, 0);
-    std::vector<std::string> lines(paf ? n : 0);
+    rs.assign((size_t)n, ReadState());
+    rep_len.assign((size_t)n, 0);
     std::atomic<int> next(0), failed(0);
     std::mutex mu;
     int64_t tot_stats[MPN_NSTATS] = {0};
@@ -1573,8 +1588,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
             S.arena.reset();
             const double t_in = since();
             struct Out { bool on; int wid, sb; double t_in; decltype(since) &f; ~Out() { if (on) fprintf(stderr, "[worker %d] sub-batch %d: %.1f -> %.1f ms\n", wid, sb, t_in, f()); } } out_{dbg_workers, wid, sb, t_in, since};
-            if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1],
-                          n_threads, S.st, rs, rep_len, lines, paf != nullptr)) {
+            if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1], n_threads, S.st, rs, rep_len)) {
                 std::lock_guard<std::mutex> g(mu);
                 err = get_error();
                 failed = 1;
@@ -1614,11 +1628,29 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         g_stats[16] = h2d;
         g_stats[0] = bases;
     }
-    int64_t n_aln = g_stats[6];
-    // Results that do not fit the caller's buffers are kept (columns / text of this call) so that the caller can fetch them
-    // with larger buffers (mpn_map_fetch_cols / mpn_map_fetch_text) instead of mapping the batch again.
+    return 0;
+}
+
+// Text and columns of a batch whose hits are final.  opt->out_sam: 0 = PAF into text, 1 = SAM into text, 2 = PAF into text and
+// SAM kept for mpn_map_fetch_sam.  Results that do not fit the caller's buffers are kept (mpn_map_fetch_cols / _text)
+// so that the caller fetches them with larger buffers instead of mapping the batch again.  Returns bytes of text or -3.
+static struct Kept { std::vector<int32_t> cols; int64_t n_rows = -1; std::string text, sam; bool has_text = false, has_sam = false; } g_kept;
+
+static int64_t emit_batch(const Targets tg, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs, const char *quals,
+                          const int64_t *seq_off, const int32_t *seq_len, std::vector<std::vector<Reg>*> &regs, const std::vector<int32_t> &rep_len,
+                          int n_threads, char *text, int64_t text_cap, mpn_aln_cols *cols) {
+    const bool want_paf = text && opt->out_sam != 1, want_sam = opt->out_sam == 2 || (text && opt->out_sam == 1);
+    std::vector<std::string> paf_lines(want_paf ? n : 0), sam_lines(want_sam ? n : 0);
+    int64_t n_aln = 0;
+    for (int i = 0; i < n; ++i) n_aln += (int64_t)regs[i]->size();
+    if (want_paf || want_sam)
+        parallel_for(n, n_threads, [&](int i, int) {
+            const char *nm = names && names[i] ? names[i] : "*";
+            if (want_paf && !regs[i]->empty()) write_paf(tg, opt, nm, seq_len[i], *regs[i], rep_len[i], paf_lines[i]);
+            if (want_sam) write_sam(tg, nm, seq_len[i], seqs + seq_off[i], quals ? quals + seq_off[i] : nullptr, *regs[i], rep_len[i], sam_lines[i]);
+        });
     bool short_cols = false, short_text = false;
-    g_kept.cols.clear(); g_kept.text.clear(); g_kept.n_rows = -1; g_kept.has_text = false;
+    g_kept.cols.clear(); g_kept.text.clear(); g_kept.sam.clear(); g_kept.n_rows = -1; g_kept.has_text = g_kept.has_sam = false;
     if (cols) {
         cols->n_rows = n_aln;
         short_cols = n_aln > cols->cap;
@@ -1631,7 +1663,7 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
         }
         int64_t k = 0;
         for (int i = 0; i < n; ++i)
-            for (const Reg &r : rs[i].regs) {
+            for (const Reg &r : *regs[i]) {
                 dst[0][k] = i; dst[1][k] = r.qs; dst[2][k] = r.qe; dst[3][k] = (int32_t)r.rev; dst[4][k] = r.rid;
                 dst[5][k] = r.rs; dst[6][k] = r.re; dst[7][k] = r.mlen; dst[8][k] = r.blen; dst[9][k] = (int32_t)r.mapq;
                 dst[10][k] = r.has_p ? r.blen - r.mlen + r.n_ambi : -1;
@@ -1641,26 +1673,140 @@ extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt
             }
     }
     int64_t w = 0;
-    if (paf) {
+    if (text) {
+        std::vector<std::string> &lines = opt->out_sam == 1 ? sam_lines : paf_lines;
         int64_t tot = 0;
         for (auto &l : lines) tot += (int64_t)l.size();
-        short_text = tot + 1 > paf_cap;
+        short_text = tot + 1 > text_cap;
         if (short_text) {
             g_kept.text.reserve((size_t)tot);
             for (auto &l : lines) g_kept.text += l;
             g_kept.has_text = true;
         } else {
-            for (auto &l : lines) { memcpy(paf + w, l.data(), l.size()); w += (int64_t)l.size(); }
-            paf[w] = 0;
+            for (auto &l : lines) { memcpy(text + w, l.data(), l.size()); w += (int64_t)l.size(); }
+            text[w] = 0;
         }
     }
-    // the per-read state (regs with their CIGARs, PAF lines) is a few hundred thousand small allocations: free them in parallel
+    if (opt->out_sam == 2) {
+        size_t tot = 0;
+        for (auto &l : sam_lines) tot += l.size();
+        g_kept.sam.reserve(tot);
+        for (auto &l : sam_lines) g_kept.sam += l;
+        g_kept.has_sam = true;
+    }
     parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t i = lo; i < hi; ++i) { rs[i] = ReadState(); if (paf) std::string().swap(lines[i]); }
+        for (int64_t i = lo; i < hi; ++i) { if (want_paf) std::string().swap(paf_lines[i]); if (want_sam) std::string().swap(sam_lines[i]); }
     });
-    whole.stop_into(g_stats[24]);
-    if (dbg_workers) fprintf(stderr, "[call] done at %.1f ms\n", since());
+    g_stats[6] = n_aln;
     return (short_cols || short_text) ? -3 : w;
+}
+
+static std::mutex g_call_mu;  // the worker slots (streams, arenas, pools) are process-wide: concurrent callers take turns
+
+extern "C" int64_t mpn_map_batch_q(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                                   const char *seqs, const char *quals, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
+                                   const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
+    std::lock_guard<std::mutex> call_guard(g_call_mu);
+    memset(g_stats, 0, sizeof(g_stats));
+    if (cols) cols->n_rows = 0;
+    if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; g_kept = Kept(); if (opt->out_sam == 2) g_kept.has_sam = true; return 0; }
+    WallTimer whole;
+    std::vector<ReadState> rs;
+    std::vector<int32_t> rep_len;
+    int n_threads = 1;
+    if (map_batch_core(idx, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
+    std::vector<std::vector<Reg>*> regs((size_t)n);
+    for (int i = 0; i < n; ++i) regs[(size_t)i] = &rs[(size_t)i].regs;
+    const int64_t w = emit_batch(Targets{&idx->names, &idx->lens}, opt, n, names, seqs, quals, seq_off, seq_len, regs, rep_len, n_threads, paf, paf_cap, cols);
+    // the per-read state (regs with their CIGARs) is a few hundred thousand small allocations: free them in parallel
+    parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) rs[(size_t)i] = ReadState(); });
+    whole.stop_into(g_stats[24]);
+    return w;
+}
+
+extern "C" int64_t mpn_map_batch_ex(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                                    const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs,
+                                    const int64_t *r_off, const int32_t *r_len, char *paf, int64_t paf_cap, mpn_aln_cols *cols) {
+    return mpn_map_batch_q(idx, opt, n, names, seqs, nullptr, seq_off, seq_len, r_seqs, r_off, r_len, paf, paf_cap, cols);
+}
+
+// ---- split index (minimap2 -I parts + --split-prefix merge) ---------------------------------------------------------
+extern "C" mpn_hits *mpn_hits_create(int32_t n_reads) {
+    if (n_reads < 0) { set_error("mpn_hits_create: negative read count"); return nullptr; }
+    mpn_hits *h = new mpn_hits();
+    h->n_reads = n_reads;
+    h->regs.resize((size_t)n_reads);
+    h->rep_len.assign((size_t)n_reads, 0);
+    return h;
+}
+extern "C" void mpn_hits_destroy(mpn_hits *h) { delete h; }
+extern "C" int32_t mpn_hits_n_seq(const mpn_hits *h) { return (int32_t)h->lens.size(); }
+extern "C" int32_t mpn_hits_n_parts(const mpn_hits *h) { return h->n_parts; }
+extern "C" int32_t mpn_hits_seq_len(const mpn_hits *h, int32_t i) { return i >= 0 && (size_t)i < h->lens.size() ? h->lens[(size_t)i] : -1; }
+extern "C" int32_t mpn_hits_seq_name(const mpn_hits *h, int32_t i, char *buf, int32_t cap) {
+    if (i < 0 || (size_t)i >= h->names.size() || !buf || cap <= 0) return -1;
+    const std::string &nm = h->names[(size_t)i];
+    const int32_t l = (int32_t)std::min<size_t>(nm.size(), (size_t)cap - 1);
+    memcpy(buf, nm.data(), (size_t)l);
+    buf[l] = 0;
+    return (int32_t)nm.size();
+}
+
+extern "C" int mpn_map_batch_part(const mpn_index *part, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                                  const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off,
+                                  const int32_t *r_len, mpn_hits *acc) {
+    if (!acc || n != acc->n_reads) { set_error("mpn_map_batch_part: the accumulator was created for another batch"); return -1; }
+    std::lock_guard<std::mutex> call_guard(g_call_mu);
+    memset(g_stats, 0, sizeof(g_stats));
+    const int32_t rid0 = (int32_t)acc->lens.size();
+    if (n > 0) {
+        std::vector<ReadState> rs;
+        std::vector<int32_t> rep_len;
+        int n_threads = 1;
+        if (map_batch_core(part, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
+        parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i) {
+                for (Reg &r : rs[(size_t)i].regs) { r.rid += rid0; acc->regs[(size_t)i].push_back(std::move(r)); }
+                acc->rep_len[(size_t)i] = std::max(acc->rep_len[(size_t)i], rep_len[(size_t)i]);
+                rs[(size_t)i] = ReadState();
+            }
+        });
+    }
+    acc->names.insert(acc->names.end(), part->names.begin(), part->names.end());
+    acc->lens.insert(acc->lens.end(), part->lens.begin(), part->lens.end());
+    acc->k = part->k;
+    ++acc->n_parts;
+    return 0;
+}
+
+// minimap2's merge of the per-part hits of a read (mm_split_merge): the sub-optimal bookkeeping is reset, the hits are
+// ranked, grouped and trimmed again over all parts, and MAPQ is recomputed
+static void merge_regs(const mpn_map_opt *opt, int k, std::vector<Reg> &regs, int32_t rep_len) {
+    if (regs.empty()) return;
+    for (Reg &r : regs) { r.subsc = 0; r.n_sub = 0; if (r.has_p) r.dp_max2 = 0; }
+    hit_sort(regs);
+    set_parent(opt->mask_level, regs, opt->a * 2 + opt->b);
+    select_sub(opt->pri_ratio, k * 2, opt->best_n, regs);
+    set_sam_pri(regs);
+    set_mapq(regs, opt->min_chain_score, opt->a, rep_len);
+}
+
+extern "C" int64_t mpn_hits_finish(mpn_hits *acc, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+                                   const char *quals, const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap,
+                                   mpn_aln_cols *cols) {
+    if (!acc || n != acc->n_reads) { set_error("mpn_hits_finish: the accumulator was created for another batch"); return -1; }
+    std::lock_guard<std::mutex> call_guard(g_call_mu);
+    if (cols) cols->n_rows = 0;
+    if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; g_kept = Kept(); if (opt->out_sam == 2) g_kept.has_sam = true; return 0; }
+    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
+    if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
+    if (n_threads < 1) n_threads = 1;
+    g_pool.ensure(n_threads);
+    if (!acc->n_parts) { set_error("mpn_hits_finish: no part was mapped"); return -1; }
+    parallel_for(n, n_threads, [&](int i, int) { merge_regs(opt, acc->k, acc->regs[(size_t)i], acc->rep_len[(size_t)i]); });
+    std::vector<std::vector<Reg>*> regs((size_t)n);
+    for (int i = 0; i < n; ++i) regs[(size_t)i] = &acc->regs[(size_t)i];
+    return emit_batch(Targets{&acc->names, &acc->lens}, opt, n, names, seqs, quals, seq_off, seq_len, regs, acc->rep_len, n_threads, paf, paf_cap, cols);
 }
 
 extern "C" int64_t mpn_map_fetch_cols(mpn_aln_cols *cols) {
@@ -1677,27 +1823,38 @@ extern "C" int64_t mpn_map_fetch_cols(mpn_aln_cols *cols) {
     return r;
 }
 
-extern "C" int64_t mpn_map_fetch_text(char *buf, int64_t cap) {
-    if (!g_kept.has_text) { set_error("mpn_map_fetch_text: no text kept from the last call"); return -1; }
-    const int64_t need = (int64_t)g_kept.text.size();
+static int64_t fetch_kept(std::string &txt, bool &has, const char *what, char *buf, int64_t cap) {
+    if (!has) { set_error("%s: no text kept from the last call", what); return -1; }
+    const int64_t need = (int64_t)txt.size();
     if (!buf) return need + 1;  // size query
     if (cap < need + 1) return -3;
-    memcpy(buf, g_kept.text.data(), (size_t)need);
+    memcpy(buf, txt.data(), (size_t)need);
     buf[need] = 0;
-    std::string().swap(g_kept.text);
-    g_kept.has_text = false;
+    std::string().swap(txt);
+    has = false;
     return need;
 }
+extern "C" int64_t mpn_map_fetch_text(char *buf, int64_t cap) { return fetch_kept(g_kept.text, g_kept.has_text, "mpn_map_fetch_text", buf, cap); }
+extern "C" int64_t mpn_map_fetch_sam(char *buf, int64_t cap) { return fetch_kept(g_kept.sam, g_kept.has_sam, "mpn_map_fetch_sam", buf, cap); }
+
+static int64_t sam_header_of(const std::vector<std::string> &names, const std::vector<int32_t> &lens, const char *cmdline, char *buf, int64_t cap);
 
 extern "C" int64_t mpn_sam_header(const mpn_index *idx, const char *cmdline, char *buf, int64_t cap) {
+    return sam_header_of(idx->names, idx->lens, cmdline, buf, cap);
+}
+extern "C" int64_t mpn_hits_sam_header(const mpn_hits *h, const char *cmdline, char *buf, int64_t cap) {
+    return sam_header_of(h->names, h->lens, cmdline, buf, cap);
+}
+
+static int64_t sam_header_of(const std::vector<std::string> &names, const std::vector<int32_t> &lens, const char *cmdline, char *buf, int64_t cap) {
     std::string h;
     char line[64];
-    for (int i = 0; i < idx->n_seq; ++i) {
-        h += "@SQ\tSN:"; h += idx->names[(size_t)i];
-        snprintf(line, sizeof(line), "\tLN:%d\n", idx->lens[(size_t)i]);
+    for (size_t i = 0; i < names.size(); ++i) {
+        h += "@SQ\tSN:"; h += names[i];
+        snprintf(line, sizeof(line), "\tLN:%d\n", lens[i]);
         h += line;
     }
-    h += "@PG\tID:mpn-aligner\tPN:mpn-aligner\tVN:r01";
+    h += "@PG\tID:mpn-aligner\tPN:mpn-aligner\tVN:r02";
     if (cmdline && cmdline[0]) { h += "\tCL:"; h += cmdline; }
     h += '\n';
     if ((int64_t)h.size() + 1 > cap) return -3;

@@ -74,6 +74,29 @@ def _bind():
         lib.mpn_map_batch_ex.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P,
                                          ct.c_int64, ct.POINTER(AlnCols)]
         lib.mpn_map_batch_ex.restype = ct.c_int64
+        lib.mpn_map_batch_q.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P, P,
+                                        ct.c_int64, ct.POINTER(AlnCols)]
+        lib.mpn_map_batch_q.restype = ct.c_int64
+        lib.mpn_hits_create.argtypes = [ct.c_int32]
+        lib.mpn_hits_create.restype = P
+        lib.mpn_hits_destroy.argtypes = [P]
+        lib.mpn_hits_destroy.restype = None
+        for fn in ('mpn_hits_n_seq', 'mpn_hits_n_parts'):
+            getattr(lib, fn).argtypes = [P]
+            getattr(lib, fn).restype = ct.c_int32
+        lib.mpn_hits_seq_len.argtypes = [P, ct.c_int32]
+        lib.mpn_hits_seq_len.restype = ct.c_int32
+        lib.mpn_hits_seq_name.argtypes = [P, ct.c_int32, ct.c_char_p, ct.c_int32]
+        lib.mpn_hits_seq_name.restype = ct.c_int32
+        lib.mpn_hits_sam_header.argtypes = [P, ct.c_char_p, ct.c_char_p, ct.c_int64]
+        lib.mpn_hits_sam_header.restype = ct.c_int64
+        lib.mpn_map_batch_part.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P]
+        lib.mpn_map_batch_part.restype = ct.c_int
+        lib.mpn_hits_finish.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, ct.c_int64,
+                                        ct.POINTER(AlnCols)]
+        lib.mpn_hits_finish.restype = ct.c_int64
+        lib.mpn_map_fetch_sam.argtypes = [ct.c_char_p, ct.c_int64]
+        lib.mpn_map_fetch_sam.restype = ct.c_int64
         lib.mpn_map_fetch_cols.argtypes = [ct.POINTER(AlnCols)]
         lib.mpn_map_fetch_cols.restype = ct.c_int64
         lib.mpn_map_fetch_text.argtypes = [ct.c_char_p, ct.c_int64]
@@ -262,10 +285,15 @@ def map_batch(idx, opt, names, seqs):
 class PackedReads:
     """Reads packed for mpn_map_batch_ex; optionally also resident in HBM (torch uint8/int64/int32 tensors)."""
 
-    def __init__(self, names, seqs, device=None):
+    def __init__(self, names, seqs, device=None, quals=None):
+        """quals: per read a quality string of the read's length, or None (then the SAM QUAL column is '*')"""
         self.n = len(seqs)
         self.names = list(names)
         self.buf, self.off, self.lens = pack_seqs(seqs)
+        self.qbuf = None
+        if quals is not None and any(q is not None for q in quals):
+            # reads without qualities in a batch that has some: the '*' cannot be mixed per read, they get '!' (Phred 0)
+            self.qbuf = pack_seqs([q if q is not None else b'!' * int(l) for q, l in zip(quals, self.lens)])[0]
         self._finish(device)
 
     @classmethod
@@ -278,6 +306,7 @@ class PackedReads:
         self.buf = np.ascontiguousarray(buf, dtype=np.uint8)
         self.off = np.ascontiguousarray(off, dtype=np.int64)
         self.lens = np.ascontiguousarray(lens, dtype=np.int32)
+        self.qbuf = None
         self._finish(None)
         self.dev = dev
         return self
@@ -299,13 +328,14 @@ class PackedReads:
 _rows_per_read = 2.0  # running estimate used to size the column arrays (a short guess costs a copy, not a second mapping)
 
 
-def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=True):
-    """-> (paf text or None, dict of int32 column arrays or None)"""
+def _emit(call, opt, packed, want_paf, want_cols):
+    """Shared buffer handling of mpn_map_batch_q / mpn_hits_finish: call(text_buf, text_cap, cols_ref) -> rc.
+    -> (text or None, SAM text or None (opt.out_sam == 2), column dict or None)"""
     global _rows_per_read
     lib = _bind()
     n = packed.n
-    d = [0, 0, 0] if (packed.dev is None or not use_device) else [t.data_ptr() for t in packed.dev]
-    paf_cap = (packed.bases // 2 + 512 * n + 4096 if not opt.out_sam else packed.bases * 3 + 1024 * n + 4096) if want_paf else 0
+    per_base = 3 if opt.out_sam == 1 else 0.5
+    paf_cap = int(packed.bases * per_base) + 512 * n + 4096 if want_paf else 0
     rows_cap = max(64, int(n * _rows_per_read * 1.25) + 16)
 
     def make_cols(cap):
@@ -318,9 +348,7 @@ def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=Tr
 
     out = ct.create_string_buffer(paf_cap) if want_paf else None
     cols, arrs = make_cols(rows_cap) if want_cols else (None, None)
-    r = lib.mpn_map_batch_ex(idx.h, ct.byref(opt), n, packed.cnames, packed.buf.ctypes.data, packed.off.ctypes.data,
-                             packed.lens.ctypes.data, d[0], d[1], d[2], out, paf_cap, ct.byref(cols) if want_cols else None)
-    text = None
+    r = call(out, paf_cap, ct.byref(cols) if want_cols else None)
     if r == -3:  # the library kept what did not fit: fetch it, do not map again
         if want_cols and cols.n_rows > rows_cap:
             cols, arrs = make_cols(int(cols.n_rows))
@@ -335,14 +363,103 @@ def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=Tr
         elif want_paf:
             r = len(out.value)
     elif r < 0:
-        raise _ffi.MpnError(f'mpn_map_batch_ex rc={r}: {_ffi.last_error()}')
-    if want_paf:
-        text = out.raw[:r].decode()
+        raise _ffi.MpnError(f'mapping call rc={r}: {_ffi.last_error()}')
+    text = out.raw[:r].decode() if want_paf else None
+    sam = None
+    if opt.out_sam == 2:
+        need = lib.mpn_map_fetch_sam(None, 0)
+        if need < 0:
+            raise _ffi.MpnError('mpn_map_fetch_sam: ' + _ffi.last_error())
+        sbuf = ct.create_string_buffer(need)
+        k = lib.mpn_map_fetch_sam(sbuf, need)
+        sam = sbuf.raw[:k].decode()
     if want_cols:
         nr = int(cols.n_rows)
         _rows_per_read = max(_rows_per_read, nr / max(n, 1))
         arrs = {k: v[:nr] for k, v in arrs.items()}
-    return text, (arrs if want_cols else None)
+    return text, sam, (arrs if want_cols else None)
+
+
+def _dev_ptrs(packed, use_device):
+    return [0, 0, 0] if (packed.dev is None or not use_device) else [t.data_ptr() for t in packed.dev]
+
+
+def map_batch_full(idx, opt, packed, want_paf=False, want_cols=True, use_device=True):
+    """-> (text (PAF; SAM if opt.out_sam == 1) or None, SAM text if opt.out_sam == 2 else None, column dict or None)"""
+    lib = _bind()
+    d = _dev_ptrs(packed, use_device)
+    q = packed.qbuf.ctypes.data if getattr(packed, 'qbuf', None) is not None else None
+
+    def call(out, cap, cols):
+        return lib.mpn_map_batch_q(idx.h, ct.byref(opt), packed.n, packed.cnames, packed.buf.ctypes.data, q, packed.off.ctypes.data,
+                                   packed.lens.ctypes.data, d[0], d[1], d[2], out, cap, cols)
+    return _emit(call, opt, packed, want_paf, want_cols)
+
+
+def map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=True):
+    """-> (paf text or None, dict of int32 column arrays or None)"""
+    text, _, cols = map_batch_full(idx, opt, packed, want_paf, want_cols, use_device)
+    return text, cols
+
+
+class Hits:
+    """Hits of one batch of reads accumulated over the parts of a split index (minimap2 -I), merged by finish()
+    the way minimap2 --split-prefix merges its per-part dumps."""
+
+    def __init__(self, packed):
+        self.packed = packed
+        self.h = _bind().mpn_hits_create(packed.n)
+        if not self.h:
+            raise _ffi.MpnError('mpn_hits_create: ' + _ffi.last_error())
+
+    def add_part(self, idx, opt, use_device=True):
+        p = self.packed
+        d = _dev_ptrs(p, use_device)
+        _ffi.check(_bind().mpn_map_batch_part(idx.h, ct.byref(opt), p.n, p.cnames, p.buf.ctypes.data, p.off.ctypes.data, p.lens.ctypes.data,
+                                              d[0], d[1], d[2], self.h), 'mpn_map_batch_part')
+
+    def finish(self, opt, want_paf=False, want_cols=True):
+        """-> (text, SAM text or None, columns); column `rid` indexes targets()"""
+        lib = _bind()
+        p = self.packed
+        q = p.qbuf.ctypes.data if getattr(p, 'qbuf', None) is not None else None
+
+        def call(out, cap, cols):
+            return lib.mpn_hits_finish(self.h, ct.byref(opt), p.n, p.cnames, p.buf.ctypes.data, q, p.off.ctypes.data, p.lens.ctypes.data,
+                                       out, cap, cols)
+        return _emit(call, opt, p, want_paf, want_cols)
+
+    def targets(self):
+        lib = _bind()
+        n = lib.mpn_hits_n_seq(self.h)
+        buf = ct.create_string_buffer(1 << 16)
+        names, lens = [], np.zeros(n, dtype=np.int32)
+        for i in range(n):
+            lib.mpn_hits_seq_name(self.h, i, buf, len(buf))
+            names.append(buf.value.decode())
+            lens[i] = lib.mpn_hits_seq_len(self.h, i)
+        return names, lens
+
+    def sam_header(self, cmdline=None):
+        lib = _bind()
+        names, _ = self.targets()
+        cap = 64 * len(names) + sum(len(x) for x in names) + 4096 + (len(cmdline) if cmdline else 0)
+        buf = ct.create_string_buffer(cap)
+        r = lib.mpn_hits_sam_header(self.h, cmdline.encode() if cmdline else None, buf, cap)
+        if r < 0:
+            raise _ffi.MpnError(f'mpn_hits_sam_header rc={r}')
+        return buf.raw[:r].decode()
+
+    def close(self):
+        if self.h:
+            _bind().mpn_hits_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ext_dp_batch(opt, queries, targets, w, zdrop, end_bonus, flag, force_kernel=0):

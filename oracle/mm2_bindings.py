@@ -67,6 +67,14 @@ def lib():
         L.mmo_write_sam.argtypes = [ct.c_void_p, ct.POINTER(Opt), ct.c_char_p, ct.c_int32, ct.c_char_p, ct.POINTER(Reg), ct.c_int32,
                                     ct.c_int32, ct.c_char_p, ct.c_int64]
         L.mmo_write_sam.restype = ct.c_int64
+        L.mmo_write_sam_q.argtypes = [ct.c_void_p, ct.POINTER(Opt), ct.c_char_p, ct.c_int32, ct.c_char_p, ct.c_char_p, ct.POINTER(Reg),
+                                      ct.c_int32, ct.c_int32, ct.c_char_p, ct.c_int64]
+        L.mmo_write_sam_q.restype = ct.c_int64
+        L.mmo_idx_concat_names.argtypes = [ct.c_int32, ct.POINTER(ct.c_void_p)]
+        L.mmo_idx_concat_names.restype = ct.c_void_p
+        L.mmo_map_read_split.argtypes = [ct.c_int32, ct.POINTER(ct.c_void_p), ct.POINTER(Opt), ct.c_char_p, ct.c_char_p, ct.c_int32,
+                                         ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]
+        L.mmo_map_read_split.restype = ct.POINTER(Reg)
         L.mmo_extd2.argtypes = [ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int8, ct.c_int8, ct.c_int8, ct.c_int8,
                                 ct.c_int8, ct.c_int8, ct.c_int8, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(Ez)]
         _lib = L
@@ -140,20 +148,54 @@ def chain(opt, a):
     return uu, _take128(b, n_b)
 
 
-def map_read_sam(idx, opt, name, seq):
-    """-> SAM records of one read (minimap2 -a), unmapped reads included"""
+def map_read_sam(idx, opt, name, seq, qual=None):
+    """-> SAM records of one read (minimap2 -a), unmapped reads included; qual: the read's quality string or None"""
     L = lib()
     seq = bytes(seq)
     n = ct.c_int32()
     rep = ct.c_int32()
     regs = L.mmo_map_read(idx.h, ct.byref(opt), name.encode(), seq, len(seq), ct.byref(n), ct.byref(rep))
-    cap = (4096 + len(seq)) * max(n.value, 1) + sum(regs[i].n_cigar for i in range(n.value)) * 12 + 4096
+    cap = (4096 + 2 * len(seq)) * max(n.value, 1) + sum(regs[i].n_cigar for i in range(n.value)) * 12 + 4096
     buf = ct.create_string_buffer(cap)
-    nb = L.mmo_write_sam(idx.h, ct.byref(opt), name.encode(), len(seq), seq, regs, n.value, rep.value, buf, cap)
+    nb = L.mmo_write_sam_q(idx.h, ct.byref(opt), name.encode(), len(seq), seq, bytes(qual) if qual is not None else None, regs, n.value,
+                           rep.value, buf, cap)
     assert nb >= 0
     if n.value > 0:
         L.mmo_free_regs(regs, n.value)
     return buf.raw[:nb].decode()
+
+
+class SplitIndex:
+    """Index parts (minimap2 -I) + the concatenated name table the writers need."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.arr = (ct.c_void_p * len(self.parts))(*[p.h for p in self.parts])
+        self.names_h = lib().mmo_idx_concat_names(len(self.parts), self.arr)
+
+    def map_read(self, opt, name, seq, sam=False, qual=None):
+        """-> PAF lines (or SAM records) of one read mapped against every part and merged (--split-prefix)"""
+        L = lib()
+        seq = bytes(seq)
+        n = ct.c_int32()
+        rep = ct.c_int32()
+        regs = L.mmo_map_read_split(len(self.parts), self.arr, ct.byref(opt), name.encode(), seq, len(seq), ct.byref(n), ct.byref(rep))
+        cap = (4096 + 2 * len(seq)) * max(n.value, 1) + sum(regs[i].n_cigar for i in range(n.value)) * 12 + 4096
+        buf = ct.create_string_buffer(cap)
+        if sam:
+            nb = L.mmo_write_sam_q(self.names_h, ct.byref(opt), name.encode(), len(seq), seq, bytes(qual) if qual is not None else None,
+                                   regs, n.value, rep.value, buf, cap)
+        else:
+            nb = L.mmo_write_paf(self.names_h, ct.byref(opt), name.encode(), len(seq), regs, n.value, rep.value, buf, cap) if n.value else 0
+        assert nb >= 0
+        if n.value > 0:
+            L.mmo_free_regs(regs, n.value)
+        return buf.raw[:nb].decode()
+
+    def close(self):
+        if self.names_h:
+            lib().mmo_idx_destroy(self.names_h)
+            self.names_h = None
 
 
 def map_read(idx, opt, name, seq):

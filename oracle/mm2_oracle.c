@@ -1388,6 +1388,58 @@ mmo_reg *mmo_map_read(const mmo_idx *mi, const mmo_opt *o, const char *name, con
     return regs;
 }
 
+/* ---- split index: minimap2 -I parts + --split-prefix (map.c: mm_split_merge / merge_hits), restated ------------------
+ * Every part is mapped on its own (its own mid-occ cut-off); the hits of a read from all parts are then pooled with the
+ * target ids shifted to the concatenated target list, the sub-optimal bookkeeping (subsc, n_sub, dp_max2) is cleared,
+ * and ranking, parent/secondary grouping, the -p/-N selection, the SAM-primary flag and MAPQ are computed again over
+ * the pool.  The repetitive-seed length of the read is the largest over the parts.  PARITY UNPINNED (see header). */
+mmo_idx *mmo_idx_concat_names(int32_t n_parts, const mmo_idx **parts)
+{
+    mmo_idx *mi = (mmo_idx *)calloc(1, sizeof(mmo_idx));
+    int32_t p, s, n = 0;
+    for (p = 0; p < n_parts; ++p) n += parts[p]->n_seq;
+    mi->k = parts[0]->k, mi->w = parts[0]->w, mi->n_seq = n;
+    mi->name = (char **)calloc(n > 0 ? n : 1, sizeof(char *));
+    mi->len = (int32_t *)calloc(n > 0 ? n : 1, 4);
+    mi->off = (int64_t *)calloc((size_t)n + 1, 8);
+    for (p = 0, n = 0; p < n_parts; ++p)
+        for (s = 0; s < parts[p]->n_seq; ++s, ++n) mi->name[n] = strdup(parts[p]->name[s]), mi->len[n] = parts[p]->len[s];
+    return mi;  /* names and lengths only: for the writers */
+}
+
+mmo_reg *mmo_map_read_split(int32_t n_parts, const mmo_idx **parts, const mmo_opt *o, const char *name, const char *seq,
+                            int32_t qlen, int32_t *n_regs_, int32_t *rep_len_)
+{
+    mmo_reg *all = 0;
+    int32_t p, i, n_all = 0, rep_len = 0, rid0 = 0;
+    for (p = 0; p < n_parts; ++p) {
+        int32_t n = 0, rep = 0;
+        mmo_opt op = *o;
+        mmo_reg *r;
+        op.mid_occ = 0; /* every part has its own cut-off (-f quantile of ITS keys) */
+        r = mmo_map_read(parts[p], &op, name, seq, qlen, &n, &rep);
+        if (n > 0) {
+            all = (mmo_reg *)realloc(all, (size_t)(n_all + n) * sizeof(mmo_reg));
+            for (i = 0; i < n; ++i) { all[n_all + i] = r[i]; all[n_all + i].rid += rid0; }
+            n_all += n;
+            free(r); /* (the cigars moved) */
+        }
+        if (rep > rep_len) rep_len = rep;
+        rid0 += parts[p]->n_seq;
+    }
+    for (i = 0; i < n_all; ++i) { all[i].subsc = 0; all[i].n_sub = 0; if (all[i].has_p) all[i].dp_max2 = 0; }
+    if (n_all > 0) {
+        hit_sort(&n_all, all);
+        set_parent(o->mask_level, n_all, all, o->a * 2 + o->b);
+        select_sub(o->pri_ratio, parts[0]->k * 2, o->best_n, &n_all, all);
+        set_sam_pri(n_all, all);
+        set_mapq(n_all, all, o->min_chain_score, o->a, rep_len);
+    }
+    *n_regs_ = n_all;
+    if (rep_len_) *rep_len_ = rep_len;
+    return all;
+}
+
 void mmo_free_regs(mmo_reg *r, int32_t n)
 {
     int32_t i;
@@ -1458,24 +1510,43 @@ static int64_t sam_seq(char *buf, const char *seq, int32_t st, int32_t en, int r
     return n;
 }
 
+/* QUAL of a record whose SEQ is seq[st, en) on strand rev (mm_write_sam3 prints the qualities in the orientation of SEQ;
+ * '*' when the read has none) */
+static int64_t sam_qual(char *buf, const char *qual, int32_t st, int32_t en, int rev)
+{
+    int32_t i, n = 0;
+    buf[n++] = '\t';
+    if (!qual) { buf[n++] = '*'; return n; }
+    if (!rev) for (i = st; i < en; ++i) buf[n++] = qual[i];
+    else for (i = en - 1; i >= st; --i) buf[n++] = qual[i];
+    return n;
+}
+
 int64_t mmo_write_sam(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const char *seq, const mmo_reg *regs,
                       int32_t n_regs, int32_t rep_len, char *buf, int64_t cap)
+{
+    return mmo_write_sam_q(mi, o, name, qlen, seq, 0, regs, n_regs, rep_len, buf, cap);
+}
+
+int64_t mmo_write_sam_q(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const char *seq, const char *qual,
+                        const mmo_reg *regs, int32_t n_regs, int32_t rep_len, char *buf, int64_t cap)
 {
     int64_t n = 0;
     int32_t i, j, k;
     (void)o;
     if (n_regs == 0) {
-        if ((int64_t)strlen(name) + qlen + 64 > cap) return -1;
+        if ((int64_t)strlen(name) + 2 * (int64_t)qlen + 64 > cap) return -1;
         n += sprintf(buf + n, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t", name);
         n += sam_seq(buf + n, seq, 0, qlen, 0);
-        n += sprintf(buf + n, "\t*\trl:i:%d\n", rep_len);
+        n += sam_qual(buf + n, qual, 0, qlen, 0);
+        n += sprintf(buf + n, "\trl:i:%d\n", rep_len);
         buf[n] = 0;
         return n;
     }
     for (i = 0; i < n_regs; ++i) {
         const mmo_reg *r = &regs[i];
         int flag = 0, type = r->id == r->parent ? (r->inv ? 'I' : 'P') : (r->inv ? 'i' : 'S');
-        int64_t need = 1024 + (int64_t)strlen(name) + (int64_t)strlen(mi->name[r->rid]) + (int64_t)r->n_cigar * 12 + qlen + (int64_t)n_regs * 128;
+        int64_t need = 1024 + (int64_t)strlen(name) + (int64_t)strlen(mi->name[r->rid]) + (int64_t)r->n_cigar * 12 + 2 * (int64_t)qlen + (int64_t)n_regs * 128;
         if (n + need > cap) return -1;
         if (r->rev) flag |= 0x10;
         if (r->parent != r->id) flag |= 0x100;
@@ -1490,9 +1561,9 @@ int64_t mmo_write_sam(const mmo_idx *mi, const mmo_opt *o, const char *name, int
             if (clip1) n += sprintf(buf + n, "%d%c", clip1, clip_char);
         }
         n += sprintf(buf + n, "\t*\t0\t0\t");
-        if ((flag & 0x900) == 0) { n += sam_seq(buf + n, seq, 0, qlen, r->rev); n += sprintf(buf + n, "\t*"); }
+        if ((flag & 0x900) == 0) { n += sam_seq(buf + n, seq, 0, qlen, r->rev); n += sam_qual(buf + n, qual, 0, qlen, r->rev); }
         else if (flag & 0x100) n += sprintf(buf + n, "*\t*");
-        else { n += sam_seq(buf + n, seq, r->qs, r->qe, r->rev); n += sprintf(buf + n, "\t*"); }
+        else { n += sam_seq(buf + n, seq, r->qs, r->qe, r->rev); n += sam_qual(buf + n, qual, r->qs, r->qe, r->rev); }
         if (r->has_p)
             n += sprintf(buf + n, "\tNM:i:%d\tms:i:%d\tAS:i:%d\tnn:i:%d", r->blen - r->mlen + r->n_ambi, r->dp_max, r->dp_score, r->n_ambi);
         n += sprintf(buf + n, "\ttp:A:%c\tcm:i:%d\ts1:i:%d", type, r->cnt, r->score);

@@ -81,6 +81,12 @@ int64_t mmo_chain(const mmo_opt *o, int64_t n_a, const mm128 *a, int32_t *n_u, u
 mmo_reg *mmo_map_read(const mmo_idx *mi, const mmo_opt *o, const char *name, const char *seq, int32_t qlen,
                       int32_t *n_regs, int32_t *rep_len);
 void mmo_free_regs(mmo_reg *r, int32_t n);
+/* split index (minimap2 -I / --split-prefix): hits of one read over all parts, merged; names/lengths of all parts for the writers */
+mmo_idx *mmo_idx_concat_names(int32_t n_parts, const mmo_idx **parts);
+mmo_reg *mmo_map_read_split(int32_t n_parts, const mmo_idx **parts, const mmo_opt *o, const char *name, const char *seq,
+                            int32_t qlen, int32_t *n_regs, int32_t *rep_len);
+int64_t mmo_write_sam_q(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const char *seq, const char *qual,
+                        const mmo_reg *regs, int32_t n_regs, int32_t rep_len, char *buf, int64_t cap);
 /* PAF line(s) for one read into buf (NUL terminated); returns bytes written (excluding NUL) or -1 if cap too small */
 int64_t mmo_write_paf(const mmo_idx *mi, const mmo_opt *o, const char *name, int32_t qlen, const mmo_reg *regs,
                       int32_t n_regs, int32_t rep_len, char *buf, int64_t cap);

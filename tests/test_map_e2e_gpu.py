@@ -163,7 +163,14 @@ def test_index_save_load_round_trip(world, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, 'bin', 'mpn-aligner'), '-c', '-t', '4', '-I', '1G', '-N', '50', '-p', '1',
                           '-x', 'map-ont', str(path), str(fq), '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout == mapper.map_batch(gidx, opt, names[:4], seqs[:4])
+    # --split-prefix: minimap2 takes its merge path even for one part (oracle: mmo_map_read_split)
+    from oracle import mm2_bindings as mb
+    oidx = mb.Index(gen)
+    sp = mb.SplitIndex([oidx])
+    oopt = mb.default_opt(best_n=50, pri_ratio=1.0)
+    assert out.stdout == ''.join(sp.map_read(oopt, n_, s_) for n_, s_ in zip(names[:4], seqs[:4]))
+    sp.close()
+    oidx.close()
 
 
 def test_dropin_with_fifo_target(world, tmp_path):
@@ -197,8 +204,73 @@ def test_dropin_with_fifo_target(world, tmp_path):
     writer.join(10)
     assert out.returncode == 0, out.stderr[-2000:]
     oopt = mb.default_opt()  # -x map-ont defaults: -N 5 -p 0.8
-    assert out.stdout == ''.join(oracle_paf(oidx, oopt, sub))
+    sp = mb.SplitIndex([oidx])  # --split-prefix: the merge path
+    assert out.stdout == ''.join(sp.map_read(oopt, r['name'], r['seq']) for r in sub)
+    sp.close()
     assert out.stdout.count('\n') >= len(sub) // 2
+
+
+def test_split_index_parts_merge_matches_oracle(world, tmp_path):
+    """minimap2 -I parts + --split-prefix (aligner.py:199): three index parts, hits merged per read.  The C-ABI accumulator
+    (mpn_hits_*) against the oracle's restatement of mm_split_merge; then the same through the executable, which cuts the
+    target into the same parts itself; then invariants against the one-part run."""
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    parts = [gen[:2], gen[2:4], gen[4:]]
+    gparts, oparts = [mapper.Index(p) for p in parts], [mb.Index(p) for p in parts]
+    sp = mb.SplitIndex(oparts)
+    names, seqs = [r['name'] for r in reads], [r['seq'] for r in reads]
+    quals = [bytes(33 + (7 * i + k) % 40 for k in range(len(s))) for i, s in enumerate(seqs)]
+    packed = mapper.PackedReads(names, seqs, quals=quals)
+    for best_n, pri in ((5, 0.8), (50, 1.0)):
+        gopt = mapper.default_opt(best_n=best_n, pri_ratio=pri, out_sam=2)
+        oopt = mb.default_opt(best_n=best_n, pri_ratio=pri)
+        h = mapper.Hits(packed)
+        for gp in gparts:
+            h.add_part(gp, gopt)
+        paf, sam, cols = h.finish(gopt, want_paf=True, want_cols=True)
+        tnames, tlens = h.targets()
+        assert tnames == [g[0] for g in gen] and list(tlens) == [len(g[1]) for g in gen]
+        want = [sp.map_read(oopt, n_, s_) for n_, s_ in zip(names, seqs)]
+        assert split_by_read(paf, names) == want
+        assert sam == ''.join(sp.map_read(oopt, n_, s_, sam=True, qual=q_) for n_, s_, q_ in zip(names, seqs, quals))
+        lines = paf.splitlines()
+        assert len(lines) == len(cols['rid']) and [tnames[i] for i in cols['rid']] == [l.split('\t')[5] for l in lines]
+        if best_n == 50:
+            # against the one-part index: the best hit of a read (first line) keeps target, strand, coordinates and CIGAR
+            one = split_by_read(mapper.map_batch(gidx, mapper.default_opt(best_n=50, pri_ratio=1.0), names, seqs), names)
+            same = 0
+            for a, b in zip(one, want):
+                if a and b:
+                    fa, fb = a.splitlines()[0].split('\t'), b.splitlines()[0].split('\t')
+                    if fa[14] != fb[14]:
+                        continue  # (equal-score hits on the strain pair may swap)
+                    assert fa[:11] == fb[:11] and fa[-1] == fb[-1], (fa[0],)
+                    same += 1
+            assert same >= len(reads) // 2
+        h.close()
+    # the executable: MPN_IDX_MINI_BATCH makes every genome a mini-batch, -I 200K closes a part after two of them
+    fa = tmp_path / 'targets.fa'
+    with open(fa, 'w') as f:
+        for name, seq in gen:
+            f.write(f'>{name}\n{bytes(seq).decode()}\n')
+    fq = tmp_path / 'reads.fq'
+    with open(fq, 'w') as f:
+        for n_, s_, q_ in zip(names, seqs, quals):
+            f.write(f'@{n_}\n{bytes(s_).decode()}\n+\n{q_.decode()}\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPN_IDX_MINI_BATCH='100000')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bin', 'mpn-aligner'), '-c', '-a', '-t', '4', '-I', '200K', '-x', 'map-ont', str(fa),
+                          str(fq), '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    body = ''.join(l for l in out.stdout.splitlines(keepends=True) if not l.startswith('@'))
+    oopt = mb.default_opt()
+    assert body == ''.join(sp.map_read(oopt, n_, s_, sam=True, qual=q_) for n_, s_, q_ in zip(names, seqs, quals))
+    assert out.stdout.count('@SQ\t') == len(gen)
+    sp.close()
+    for x in gparts + oparts:
+        x.close()
 
 
 def test_edge_inputs_match_oracle(world):
