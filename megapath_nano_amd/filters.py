@@ -1,41 +1,77 @@
-"""Host-side mirror of the human/decoy classification that consumes Align() output in the reference's step 2
-(/root/reference/bin/megapath_nano.py step_human_and_decoy_filter, :1135-1200; thresholds :5071-5074).
+"""Human / decoy classification of reads from the alignments of the reference's step 2
+(/root/reference/bin/megapath_nano.py:1135-1200 `step_human_and_decoy_filter`; thresholds :5071-5074), on integer codes.
 
-Pure pandas post-processing over the align_list DataFrame (a few thousand rows per batch); kept on the host exactly as
-in the reference.  The alignment itself (the expensive part of step 2) is megapath_nano_amd.aligner.Align."""
+Rules (from the reference): a read's best alignment within a set of assemblies is the one with the largest
+(alignment_score, alignment_score_tiebreaker).  A read is HUMAN if its best alignment to a human assembly has
+alignment_score >= human_min_alignment_score or alignment_score * 100 / read_length >= human_min_alignment_score_percent.
+Human reads are removed with all their alignments; the same test with the decoy thresholds on the best alignment to a
+decoy assembly makes a DECOY read.  What is left is MICROBE: its best alignment over all remaining rows is reported,
+and every input read that is neither human nor decoy (aligned or not) is a microbe read.
+
+The DataFrame in / DataFrame out interface of the reference is kept; inside, reads are coded as integers, the "best row
+per read" is one lexsort, and set membership is a boolean gather -- no joins.  (The per-read best hit is also what
+reassign_apply_kernel computes on the GPU for the species-placement stage; here the table is a few rows per read and
+stays on the host.)
+"""
+import numpy as np
 import pandas
 
 
-def _best_per_read(df):
-    # megapath_nano.py:1142 / :1176 / :1195: sort (read_id, alignment_score, tiebreaker), keep the last row per read
-    return df.sort_values(['read_id', 'alignment_score', 'alignment_score_tiebreaker']).drop_duplicates(subset=['read_id'], keep='last')
+def _last_of_groups(codes, order):
+    """order: row permutation sorted by (code, score, tiebreak); -> rows that close each run of equal codes"""
+    sorted_codes = codes[order]
+    last = np.ones(len(order), dtype=bool)
+    last[:-1] = sorted_codes[1:] != sorted_codes[:-1]
+    return order[last]
+
+
+def _best_rows(read_code, score, tiebreak, mask):
+    """Per read (ascending code), the row with the largest (score, tiebreak) among the rows selected by mask."""
+    rows = np.flatnonzero(mask)
+    if rows.size == 0:
+        return rows
+    order = rows[np.lexsort((tiebreak[rows], score[rows], read_code[rows]))]
+    return _last_of_groups(read_code, order)
+
+
+def _passes(score, read_length, min_score, min_percent):
+    return (score >= min_score) | (score * 100 / read_length >= min_percent)
 
 
 def human_and_decoy_classify(align_list, human_assembly_list, decoy_assembly_list, read_id_list,
                              human_min_alignment_score=1000, human_min_alignment_score_percent=100,
-                             decoy_min_alignment_score=1000, decoy_min_alignment_score_percent=100):
+                             decoy_min_alignment_score=1000, decoy_min_alignment_score_percent=100, key='assembly_id'):
     """-> dict(human_best_align_list, human_read_id_list, decoy_best_align_list, decoy_read_id_list,
-               microbe_best_align_list, microbe_read_id_list), the O.* members the reference fills at :1144-1200."""
-    human_best = _best_per_read(align_list.merge(right=human_assembly_list.set_index('assembly_id'), how='inner',
-                                                 left_on='assembly_id', right_index=True, suffixes=['', '_y'], validate='m:1'))
-    human_best = human_best.query('alignment_score >= @human_min_alignment_score or '
-                                  'alignment_score * 100 / read_length >= @human_min_alignment_score_percent')    # :1144
-    human_ids = human_best[['read_id', 'read_length']].sort_values(['read_id', 'read_length']).drop_duplicates()   # :1152
-    remaining = align_list.merge(right=human_ids.set_index('read_id').rename(columns={'read_length': 'filtered'}),
-                                 how='left', left_on='read_id', right_index=True, suffixes=['', '_y'],
-                                 validate='m:1').fillna(0).query('filtered == 0').drop(['filtered'], axis=1)       # :1155-1162
-    decoy_best = _best_per_read(remaining.merge(right=decoy_assembly_list.set_index('assembly_id'), how='inner',
-                                                left_on='assembly_id', right_index=True, suffixes=['', '_y'], validate='m:1'))
-    decoy_best = decoy_best.query('alignment_score >= @decoy_min_alignment_score or '
-                                  'alignment_score * 100 / read_length >= @decoy_min_alignment_score_percent')     # :1178
-    decoy_ids = decoy_best[['read_id', 'read_length']].sort_values(['read_id', 'read_length']).drop_duplicates()    # :1183
-    microbe_best = remaining.merge(right=decoy_ids.set_index('read_id').rename(columns={'read_length': 'filtered'}),
-                                   how='left', left_on='read_id', right_index=True, suffixes=['', '_y'], validate='m:1')
-    microbe_best = _best_per_read(microbe_best.fillna(0).query('filtered == 0').drop(['filtered'], axis=1))        # :1193
+               microbe_best_align_list, microbe_read_id_list): the O.* tables the reference fills at :1144-1200."""
+    for name, lst in (('human', human_assembly_list), ('decoy', decoy_assembly_list)):
+        if pandas.Index(lst['assembly_id']).has_duplicates:
+            raise pandas.errors.MergeError(f'{name} assembly list is not unique: not a many-to-one merge')
+    ids, read_code = np.unique(align_list['read_id'].to_numpy(dtype=object).astype(str), return_inverse=True)
+    score = align_list['alignment_score'].to_numpy()
+    tiebreak = align_list['alignment_score_tiebreaker'].to_numpy()
+    read_length = align_list['read_length'].to_numpy()
+    target = align_list[key].to_numpy(dtype=object)
+    is_human = np.isin(target, human_assembly_list['assembly_id'].to_numpy(dtype=object))
+    is_decoy = np.isin(target, decoy_assembly_list['assembly_id'].to_numpy(dtype=object))
+
+    def classify(candidates, min_score, min_percent):
+        best = _best_rows(read_code, score, tiebreak, candidates)
+        best = best[_passes(score[best], read_length[best], min_score, min_percent)]
+        caught = np.zeros(len(ids), dtype=bool)
+        caught[read_code[best]] = True
+        return best, caught
+
+    human_rows, human_read = classify(is_human, human_min_alignment_score, human_min_alignment_score_percent)
+    remaining = ~human_read[read_code]
+    decoy_rows, decoy_read = classify(is_decoy & remaining, decoy_min_alignment_score, decoy_min_alignment_score_percent)
+    microbe_rows = _best_rows(read_code, score, tiebreak, remaining & ~decoy_read[read_code])
+
+    def id_table(rows):
+        return align_list.iloc[rows][['read_id', 'read_length']].drop_duplicates()
+
     reads = read_id_list.drop_duplicates()
-    gone = pandas.concat([human_ids, decoy_ids], axis=0).sort_values(['read_id', 'read_length']).drop_duplicates()
-    microbe_ids = reads.merge(right=gone.set_index('read_id').rename(columns={'read_length': 'filtered'}), how='left',
-                              left_on='read_id', right_index=True, suffixes=['', '_y'],
-                              validate='1:1').fillna(0).query('filtered == 0').drop(['filtered'], axis=1)[['read_id', 'read_length']]
-    return dict(human_best_align_list=human_best, human_read_id_list=human_ids, decoy_best_align_list=decoy_best,
-                decoy_read_id_list=decoy_ids, microbe_best_align_list=microbe_best, microbe_read_id_list=microbe_ids)
+    gone = set(ids[human_read | decoy_read])
+    keep = ~reads['read_id'].astype(str).isin(gone).to_numpy()
+    return dict(human_best_align_list=align_list.iloc[human_rows], human_read_id_list=id_table(human_rows),
+                decoy_best_align_list=align_list.iloc[decoy_rows], decoy_read_id_list=id_table(decoy_rows),
+                microbe_best_align_list=align_list.iloc[microbe_rows], microbe_read_id_list=reads[keep][['read_id', 'read_length']])

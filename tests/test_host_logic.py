@@ -159,6 +159,42 @@ def test_human_decoy_classification_rules():
     assert mb.loc['m1', 'assembly_id'] == 'MIC2' and mb.loc['m2', 'assembly_id'] == 'MIC1'
 
 
+def test_human_decoy_classification_randomised_against_plain_loops():
+    """The integer-coded classification against a dictionary-and-loops restatement of the same rules, on random tables with
+    score ties, reads hitting several sets, reads without alignments."""
+    import pandas as pd
+    from megapath_nano_amd.filters import human_and_decoy_classify
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n_reads = int(rng.integers(1, 60))
+        lens = {f'r{i:03d}': int(rng.integers(200, 6000)) for i in range(n_reads)}
+        rows = []
+        for rid, L in lens.items():
+            for _ in range(int(rng.integers(0, 5))):
+                rows.append((rid, L, str(rng.choice(['H1', 'H2', 'D1', 'M1', 'M2', 'M3'])), int(rng.choice([50, 500, 999, 1000, 1001, L, L - 1, 3000])),
+                             float(rng.random())))
+        al = pd.DataFrame(rows, columns=['read_id', 'read_length', 'assembly_id', 'alignment_score', 'alignment_score_tiebreaker'])
+        reads = pd.DataFrame({'read_id': list(lens), 'read_length': list(lens.values())})
+        out = human_and_decoy_classify(al, pd.DataFrame({'assembly_id': ['H1', 'H2']}), pd.DataFrame({'assembly_id': ['D1']}), reads)
+        # plain restatement
+        def best(rows_):
+            b = {}
+            for r in rows_:
+                if r[0] not in b or (r[3], r[4]) > (b[r[0]][3], b[r[0]][4]):
+                    b[r[0]] = r
+            return b
+        ok = lambda r: r[3] >= 1000 or r[3] * 100 / r[1] >= 100  # noqa: E731
+        human = {k for k, r in best([r for r in rows if r[2] in ('H1', 'H2')]).items() if ok(r)}
+        rest = [r for r in rows if r[0] not in human]
+        decoy = {k for k, r in best([r for r in rest if r[2] == 'D1']).items() if ok(r)}
+        micro = best([r for r in rest if r[0] not in decoy])
+        assert set(out['human_read_id_list']['read_id']) == human and set(out['decoy_read_id_list']['read_id']) == decoy
+        assert set(out['microbe_read_id_list']['read_id']) == set(lens) - human - decoy
+        got = {t.read_id: (t.assembly_id, t.alignment_score, t.alignment_score_tiebreaker) for t in out['microbe_best_align_list'].itertuples()}
+        assert got == {k: (r[2], r[3], r[4]) for k, r in micro.items()}
+        assert list(out['microbe_best_align_list']['read_id']) == sorted(micro)
+
+
 def test_index_file_magic_detection(tmp_path):
     """`Align()` / bin/mpn-aligner treat a target as a saved index only if it carries the magic (no GPU needed to tell)."""
     from megapath_nano_amd.mapper import Index

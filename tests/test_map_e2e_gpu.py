@@ -273,6 +273,52 @@ def test_split_index_parts_merge_matches_oracle(world, tmp_path):
         x.close()
 
 
+def test_independent_checker_on_gpu_output(world):
+    """Every number of the PAF / SAM lines recomputed from the CIGAR and the sequences by tests/paf_check.py (written from
+    the format and tag definitions, not from the oracle): breaks the twin relation between csrc/align.hip's host half and
+    oracle/mm2_oracle.c for NM, ms, AS, nn, de, mlen, blen, clipping, flags, SA, one-primary-per-read, MAPQ range."""
+    import paf_check
+    from map_cases import hard_reads
+    from megapath_nano_amd import mapper
+    gen, reads, gidx, _ = world
+    allr = reads + hard_reads(gen)
+    names, seqs = [r['name'] for r in allr], [r['seq'] for r in allr]
+    quals = [bytes(33 + (3 * i + k) % 41 for k in range(len(s))) for i, s in enumerate(seqs)]
+    rd = {n_: bytes(s_).decode() for n_, s_ in zip(names, seqs)}
+    gd = {n_: bytes(s_).decode() for n_, s_ in gen}
+    qd = {n_: q_.decode() for n_, q_ in zip(names, quals)}
+    packed = mapper.PackedReads(names, seqs, quals=quals)
+    for best_n, pri in ((5, 0.8), (50, 1.0)):
+        opt = mapper.default_opt(best_n=best_n, pri_ratio=pri, out_sam=2)
+        paf, sam, _ = mapper.map_batch_full(gidx, opt, packed, want_paf=True, want_cols=False)
+        st = paf_check.check_paf(paf, rd, gd, best_n=best_n)
+        assert st['lines'] >= len(reads) // 2 and st['as_equal'] >= 0.98 * st['lines'], st
+        assert paf_check.check_sam(sam, paf, rd, qd) >= len(allr)
+
+
+def test_mapq_grows_with_the_divergence_of_the_second_copy(libmpn):
+    """MAPQ reflects how much better the best locus is than the next one: the same read against targets that hold its locus
+    plus a copy of it at growing divergence must not lose mapping quality (constructed pairs; independent of the oracle)."""
+    from megapath_nano_amd import mapper, synth
+    rng = np.random.default_rng(123)
+    a = synth.random_genome(rng, 120000)
+    read = synth.ont_errors(rng, a[40000:46000].copy(), 0.03, 0.02, 0.03)
+    mapqs = []
+    for div in (0.0, 0.01, 0.03, 0.08, 0.2, None):
+        gens = [('A', a)]
+        if div is not None:
+            b = synth.random_genome(rng, 60000)
+            b[20000:30000] = synth.mutate_strain(rng, a[38000:48000], 1.0 - div) if div > 0 else a[38000:48000]
+            gens.append(('B', b))
+        idx = mapper.Index(gens)
+        paf = mapper.map_batch(idx, mapper.default_opt(), ['r'], [read])
+        idx.close()
+        first = paf.splitlines()[0].split('\t')
+        assert first[5] in ('A', 'B') and (div == 0.0 or first[5] == 'A')
+        mapqs.append(int(first[11]))
+    assert mapqs == sorted(mapqs) and mapqs[0] <= 3 and mapqs[-1] == 60, mapqs
+
+
 def test_edge_inputs_match_oracle(world):
     """Empty and degenerate batches through the C-ABI: no reads, reads shorter than k / shorter than one window, all-N,
     lower-case and IUPAC bases, duplicated names, a read that is a whole target, reads that map nowhere."""
