@@ -217,16 +217,20 @@ def main():
     rounds = max(st['dp_rounds'], 1)
     # Candidate kernels for the roofline line: device ns from HIP events around each launch (rank 0, per step), launches per
     # step, and ALGORITHMIC bytes per step (DESIGN.md section 5 states the per-unit figures):
-    #   sketch (count + fill pass) : 2 x 1 B per read base in + 16 B per minimizer out
-    #   seed lookup + fill         : 16 B per minimizer in, 8 B per index position gathered, 16 B per anchor out
-    #   anchor sort                : 32 B (16 in + 16 out) per record and effective radix pass (counted by the kernel)
-    #   chain DP                   : 16 B per anchor in + 16 B (f, p, t, v) out
-    #   strip DP <GL>              : 1 direction byte out per DP cell (qlen x tlen per window)
+    #   sketch (count + fill pass)   : 2 x 1 B per read base in + 16 B per minimizer out
+    #   seed lookup + fill           : 16 B per minimizer in, 8 B per index position gathered, 16 B per anchor out
+    #   anchor partition (MSD)       : 8 B key read for the histogram + 16 B record in + 16 B out per anchor
+    #   anchor window sort           : 16 B in + 16 B out per anchor
+    #   anchor compaction (2 passes) : 2 x 16 B per anchor in + 16 B per kept anchor out
+    #   chain DP                     : 16 B per kept anchor in + 16 B (f, p, t, v) out
+    #   strip DP <GL>                : 1 direction byte out per DP cell (qlen x tlen per window)
     cand = {
-        'sketch_chunk_kernel<count|fill>': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
+        'sketch_fast_kernel<count|fill>': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
         'seed_lookup_kernel+seed_fill_kernel': (st['k_seed_lookup_ns'] + st['k_seed_fill_ns'], 2 * nsub, 16 * st['minimizers'] + 24 * st['anchors']),
-        'seg_sort_kernel<4>': (st['ev_sort_ns'], nsub, 32 * st['sort_records_moved']),
-        'chain_dp_kernel': (st['k_chain_dp_ns'], nsub, 32 * st['anchors']),
+        'anchor_msd_kernel': (st['k_sort_msd_ns'], nsub, 40 * st['anchors']),
+        'anchor_window_sort_kernel': (st['k_sort_chunk_ns'], nsub, 32 * st['anchors']),
+        'anchor_compact_kernel<count|write>': (st['k_compact_ns'], 2 * nsub, 32 * st['anchors'] + 16 * st['anchors_kept']),
+        'chain_dp_kernel': (st['k_chain_dp_ns'], nsub, 32 * st['anchors_kept']),
         'ext_dp_strip_kernel<16>': (st['k_strip16_ns'], rounds, st['strip16_cells']),
         'ext_dp_strip_kernel<32>': (st['k_strip32_ns'], rounds, st['strip32_cells']),
         'ext_dp_strip_kernel<64>': (st['k_strip64_ns'], rounds, st['strip64_cells']),

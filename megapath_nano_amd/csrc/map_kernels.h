@@ -435,6 +435,14 @@ __device__ __forceinline__ uint32_t sort_digit(const u128 &r, int pass) {
 }
 
 // NY = 4: anchors, key (x, low 32 bits of y).  NY = 8: index records, key (x, y).
+// Statistics counter "records moved" (bench.py's algorithmic bytes of the sort).  It is spread over WORK_SLOTS addresses:
+// atomics of thousands of workgroups on ONE address serialise at the memory side and each workgroup then waits for its
+// own (measured: they were the largest cost of the window-sort and list kernels).
+constexpr int WORK_SLOTS = 256;
+__device__ __forceinline__ void add_work(unsigned long long *work, unsigned long long n) {
+    if (work) atomicAdd(&work[blockIdx.x & (WORK_SLOTS - 1)], n);
+}
+
 struct SegSortLds {
     uint32_t hist[256], bins[256], wcnt[4][256];
     int skip;
@@ -456,7 +464,7 @@ __device__ __forceinline__ void wg_radix_sort(SegSortLds &L, u128 *__restrict__ 
         if (L.hist[tid] == (uint32_t)n) L.skip = 1;
         __syncthreads();
         if (L.skip) { __syncthreads(); continue; }
-        if (work && tid == 0) atomicAdd(work, (unsigned long long)n);  // records moved by this pass (bench.py: bytes of the sort)
+        if (tid == 0) add_work(work, (unsigned long long)n);  // records moved by this pass
         // exclusive scan of the histogram (256 entries, thread per bin)
         {
             uint32_t v = L.hist[tid];
@@ -589,7 +597,7 @@ __device__ __forceinline__ void push_sort_seg(const SortLists &L, int64_t off, i
 __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst,
                                                                  const int64_t *__restrict__ anchor_off, int n_reads, BinParams bp,
                                                                  SortLists lists, unsigned long long *__restrict__ work) {
-    extern __shared__ uint32_t msd_lds[];  // MSD_NB counters + one total per wave (launch with (MSD_NB + 16) * 4 bytes)
+    extern __shared__ uint32_t msd_lds[];  // MSD_NB counters + one total per wave + 6 list words (launch with (MSD_NB + 32) * 4 bytes)
     uint32_t *cnt = msd_lds, *wtot = msd_lds + MSD_NB;
     constexpr int NT = MSD_THREADS, NW = NT / 64, PER_WAVE = MSD_NB / NW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -624,10 +632,27 @@ __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__r
             carry += __shfl(incl, 63);
         }
         __syncthreads();
-        // buckets the window kernel will not sort in LDS go to the work lists (their extents are known here)
+        // buckets the window kernel will not sort in LDS go to the work lists (their extents are known here).  The workgroup
+        // reserves its list entries with ONE atomic per list (thousands of workgroups pushing one by one would queue on it)
+        uint32_t *lcnt = wtot + NW, *lbase = lcnt + 3;  // [3] each
+        if (tid < 3) lcnt[tid] = 0;
+        __syncthreads();
         for (int b = tid; b < MSD_NB; b += NT) {
             const uint32_t st = cnt[b], en = b + 1 < MSD_NB ? cnt[b + 1] : (uint32_t)n;
-            if (en - st > SMALL_BUCKET) push_sort_seg(lists, base + st, (int64_t)(en - st));
+            const uint32_t len = en - st;
+            if (len > SMALL_BUCKET) atomicAdd(&lcnt[len <= BITONIC_SMALL ? 0 : len <= BITONIC_MID ? 1 : 2], 1u);
+        }
+        __syncthreads();
+        if (tid < 3) { lbase[tid] = lcnt[tid] ? atomicAdd(&lists.count[tid], lcnt[tid]) : 0u; lcnt[tid] = 0; }
+        __syncthreads();
+        for (int b = tid; b < MSD_NB; b += NT) {
+            const uint32_t st = cnt[b], en = b + 1 < MSD_NB ? cnt[b + 1] : (uint32_t)n;
+            const uint32_t len = en - st;
+            if (len > SMALL_BUCKET) {
+                const int c = len <= BITONIC_SMALL ? 0 : len <= BITONIC_MID ? 1 : 2;
+                const uint32_t w = lbase[c] + atomicAdd(&lcnt[c], 1u);
+                if (w < lists.cap[c]) lists.seg[c][w] = SortSeg{base + st, (int64_t)len};
+            }
         }
         __syncthreads();
         for (int64_t i0 = tid; i0 < n; i0 += 4 * NT) {
@@ -638,7 +663,7 @@ __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__r
             for (int u = 0; u < 4; ++u)
                 if (i0 + u * NT < n) { const uint32_t p = atomicAdd(&cnt[anchor_bin(r[u].x, bp)], 1u); out[p] = r[u]; }
         }
-        if (work && tid == 0) atomicAdd(work, (unsigned long long)n);
+        if (tid == 0) add_work(work, (unsigned long long)n);
         __syncthreads();
     }
 }
@@ -648,7 +673,7 @@ __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__r
 // first anchor) and loads SMALL_BUCKET more records so that an owned small bucket is complete.  Owners are unique, so
 // the windows are independent: the grid is the number of windows, not the number of reads.  Buckets of more than
 // SMALL_BUCKET anchors are left as they are (the partition kernel has put them on the work lists).
-constexpr int SORT_WIN = 2048, SORT_LOAD = SORT_WIN + SMALL_BUCKET;
+constexpr int SORT_WIN = 1024, SORT_LOAD = SORT_WIN + SMALL_BUCKET;
 
 __global__ __launch_bounds__(256) void anchor_window_sort_kernel(u128 *__restrict__ data, const int64_t *__restrict__ anchor_off,
                                                                  int n_reads, int64_t n_a, BinParams bp,
@@ -661,7 +686,14 @@ __global__ __launch_bounds__(256) void anchor_window_sort_kernel(u128 *__restric
         const int64_t g0 = win * SORT_WIN;
         const int cnt = (int)(n_a - g0 < SORT_LOAD ? n_a - g0 : SORT_LOAD);       // records loaded
         const int own = (int)(n_a - g0 < SORT_WIN ? n_a - g0 : SORT_WIN);         // positions whose buckets are ours
-        for (int i = tid; i < cnt; i += 256) { const u128 r = data[g0 + i]; kx[i] = r.x; ky[i] = r.y; }
+        {   // all loads of the window are issued before the first one is consumed (the kernel is bound by their latency)
+            constexpr int NL = (SORT_LOAD + 255) / 256;
+            u128 r[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) { const int i = tid + u * 256; if (i < cnt) r[u] = data[g0 + i]; }
+#pragma unroll
+            for (int u = 0; u < NL; ++u) { const int i = tid + u * 256; if (i < cnt) { kx[i] = r[u].x; ky[i] = r[u].y; } }
+        }
         for (int k = tid; k < SORT_LOAD / 64 + 2; k += 256) flags[k] = 0;
         __syncthreads();
         // the read that holds g0, then every read boundary inside the loaded range forces a bucket start
@@ -720,7 +752,7 @@ __global__ __launch_bounds__(256) void anchor_window_sort_kernel(u128 *__restric
             if (lo > own) lo = hi;  // no bucket starts in the owned range: nothing to write
         }
         for (int i = lo + tid; i < hi; i += 256) { u128 r; r.x = kx[i]; r.y = ky[i]; data[g0 + i] = r; }
-        if (work && tid == 0) atomicAdd(work, (unsigned long long)(hi > lo ? hi - lo : 0));
+        if (tid == 0 && hi > lo) add_work(work, (unsigned long long)(hi - lo));
         __syncthreads();
     }
 }
@@ -755,7 +787,7 @@ __global__ __launch_bounds__(256) void anchor_bitonic_list_kernel(u128 *__restri
                 __syncthreads();
             }
         for (int i = tid; i < len; i += 256) { u128 r; r.x = kx[i]; r.y = ky[i]; a[i] = r; }
-        if (work && tid == 0) atomicAdd(work, (unsigned long long)len);
+        if (tid == 0) add_work(work, (unsigned long long)len);
         __syncthreads();
     }
 }

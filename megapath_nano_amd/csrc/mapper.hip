@@ -169,7 +169,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     g_stats[2] += n_a;
     DevBuf<u128> tmp;
     if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
-        o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(3) || o.used.zero(st))
+        o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(2 + WORK_SLOTS) || o.used.zero(st))
         return -1;
     ev.mark(11);
     if (n_a > 0) {
@@ -201,7 +201,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             lists.cap[0] = (unsigned int)c0; lists.cap[1] = (unsigned int)c1; lists.cap[2] = (unsigned int)c2;
             lists.count = n_list.p;
         }
-        const size_t msd_lds = (size_t)(MSD_NB + 16) * sizeof(uint32_t);
+        const size_t msd_lds = (size_t)(MSD_NB + 32) * sizeof(uint32_t);
         static std::once_flag lds_attr;
         std::call_once(lds_attr, [&]() {
             (void)hipFuncSetAttribute((const void *)anchor_msd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_lds);
@@ -297,13 +297,13 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
 int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st) {
     h.anchor_off.resize((size_t)n + 1);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
-    unsigned long long used[3] = {0, 0, 0};
+    unsigned long long used[2 + WORK_SLOTS] = {0};
     if (o.anchor_off.download(h.anchor_off.data(), (size_t)n + 1, st) || o.n_chain.download(h.n_chain.data(), n, st) ||
         o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st) ||
-        o.u_pos.download(h.u_pos.data(), n, st) || o.b_pos.download(h.b_pos.data(), n, st) || o.used.download(used, 3, st))
+        o.u_pos.download(h.u_pos.data(), n, st) || o.b_pos.download(h.b_pos.data(), n, st) || o.used.download(used, 2 + WORK_SLOTS, st))
         return -1;
     MPN_HIP_CHECK(stream_sync(st));
-    g_stats[44] += (int64_t)used[2];
+    for (int k = 0; k < WORK_SLOTS; ++k) g_stats[44] += (int64_t)used[2 + k];
     ++g_stats[32];
     if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;
     if (o.u_compact.download(pin_u.as<uint64_t>(), (size_t)used[0], st) || o.chained.download(pin_b.as<u128>(), (size_t)used[1], st)) return -1;
