@@ -790,13 +790,16 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
                                                     const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
                                                     uint32_t *__restrict__ CIG, uint32_t *__restrict__ COMPACT,
                                                     unsigned long long *__restrict__ compact_used, ExtRes *__restrict__ res) {
+    // (no early exit: the whole wave meets again at the end to reserve its slice of the compact pool with ONE atomic --
+    // one atomic per job on a single counter serialises tens of thousands of lanes at the memory side)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_jobs) return;
-    const int jid = order[k];
-    if (jid < 0) return;  // padding of a strip launch list
-    const ExtJob jb = jobs[jid];
-    ExtRes r = res[jid];
-    if (!r.do_bt) { res[jid].cig_pos = 0; return; }
+    const int jid = k < n_jobs ? order[k] : -1;  // -1: also the padding of a strip launch list
+    const bool live = jid >= 0;
+    ExtJob jb = jobs[live ? jid : 0];
+    ExtRes r = res[live ? jid : 0];
+    const bool walk = live && r.do_bt;
+    if (live && !r.do_bt) res[jid].cig_pos = 0;
+    if (!walk) { jb.qlen = jb.tlen = 1; r.bt_i = r.bt_j = -1; }
     const int n_col = jb.n_col, n_r = jb.qlen + jb.tlen - 1;
     const uint8_t *p = P + jb.p_off;
     const int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
@@ -839,17 +842,29 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
         else if (state == 1 || state == 3) { MPN_PUSHOP(2, 1); --i; }
         else { MPN_PUSHOP(1, 1); --j; }
     }
-    if (i >= 0) MPN_PUSHOP(2, (uint32_t)(i + 1));
-    if (j >= 0) MPN_PUSHOP(1, (uint32_t)(j + 1));
-    MPN_FLUSH();
+    if (walk) {
+        if (i >= 0) MPN_PUSHOP(2, (uint32_t)(i + 1));
+        if (j >= 0) MPN_PUSHOP(1, (uint32_t)(j + 1));
+        MPN_FLUSH();
+    }
 #undef MPN_PUSHOP
 #undef MPN_FLUSH
     // hand the ops over in forward order through a compact pool, so that only used entries travel to the host
-    const unsigned long long pos = n ? atomicAdd(compact_used, (unsigned long long)n) : 0ULL;
-    const uint32_t *src = rev_cigar ? cbeg : cend - n;
-    for (int q = 0; q < n; ++q) COMPACT[pos + q] = src[q];
-    res[jid].n_cigar = n;
-    res[jid].cig_pos = (int64_t)pos;
+    const int lane = threadIdx.x & 63;
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const int total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(compact_used, (unsigned long long)total);
+    base = (unsigned long long)__shfl((long long)base, 0);
+    if (walk) {
+        const unsigned long long pos = base + (unsigned long long)(incl - n);
+        const uint32_t *src = rev_cigar ? cbeg : cend - n;
+        for (int q = 0; q < n; ++q) COMPACT[pos + q] = src[q];
+        res[jid].n_cigar = n;
+        res[jid].cig_pos = (int64_t)pos;
+    }
 }
 
 // z-drop test of a finished gap-fill CIGAR (minimap2 mm_test_zdrop without the inversion probe): one lane per job
