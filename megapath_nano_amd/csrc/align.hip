@@ -1360,6 +1360,17 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     WallTimer wt;
     HostChains h;
     {
+        // The seed + sort + chain stage is bound by HBM traffic and latency, the extension stage by VALU issue: workers in
+        // different stages share the GPU well, workers in the same memory-bound stage only queue on HBM.  At most
+        // MPN_SEED_SLOTS workers are inside this stage at a time (which also keeps the workers out of lock-step).
+        struct StageGate {
+            std::mutex mu; std::condition_variable cv; int free_slots;
+            StageGate() { const char *e = getenv("MPN_SEED_SLOTS"); free_slots = e ? std::max(1, atoi(e)) : 4; }
+            void enter() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return free_slots > 0; }); --free_slots; }
+            void leave() { { std::lock_guard<std::mutex> g(mu); ++free_slots; } cv.notify_one(); }
+        };
+        static StageGate gate;
+        struct Hold { StageGate &g; Hold(StageGate &x) : g(x) { g.enter(); } ~Hold() { g.leave(); } } hold(gate);
         SeedChainOut o;
         if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
         wt.stop_into(g_stats[17]);

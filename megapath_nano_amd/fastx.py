@@ -79,3 +79,66 @@ def read_fastx(path, with_qual=False):
     finally:
         stream.close()
     return recs if with_qual else [(n, s) for n, s, _ in recs]
+
+
+def iter_fastx_full(stream):
+    """Like iter_fastx but keeps the comment: yields (name, comment or None, sequence, quality or None)."""
+    line = stream.readline()
+    while line:
+        line = line.rstrip(b'\r\n')
+        if not line:
+            line = stream.readline()
+            continue
+        if line[:1] not in (b'>', b'@'):
+            raise ValueError('neither FASTA nor FASTQ: record header expected, got %r' % line[:20])
+        head = line[1:]
+        cut = len(head)
+        for k, ch in enumerate(head):
+            if ch in b' \t':
+                cut = k
+                break
+        name, comment = head[:cut], (head[cut + 1:] if cut < len(head) else None)
+        seq = []
+        line = stream.readline()
+        while line and line[:1] not in (b'>', b'@', b'+'):
+            seq.append(line.strip())
+            line = stream.readline()
+        seq = b''.join(seq)
+        qual = None
+        if line[:1] == b'+':
+            got, parts = 0, []
+            line = stream.readline()
+            while line and got < len(seq):
+                q = line.rstrip(b'\r\n')
+                parts.append(q)
+                got += len(q)
+                line = stream.readline()
+            qual = b''.join(parts)
+            if len(qual) != len(seq):
+                qual = None
+        yield name.decode(), comment, seq, qual
+
+
+def subseq(in_path, names, out):
+    """`seqtk subseq <in.fq> <name.lst>` (the reference writes the human/decoy-filtered reads with it,
+    bin/megapath_nano.py:1221-1233): the records whose name is listed, in input order, FASTQ records as
+    `@name[ comment]`, sequence, `+`, quality on single lines, FASTA records as `>name[ comment]` and the sequence.
+    names: iterable of read names; out: binary stream.  -> number of records written."""
+    wanted = {n if isinstance(n, str) else n.decode() for n in names}
+    kind, stream = open_once(in_path)
+    n = 0
+    try:
+        if kind == 'index':
+            raise ValueError(f'{in_path}: a saved index, not sequences')
+        for name, comment, seq, qual in iter_fastx_full(stream):
+            if name not in wanted:
+                continue
+            head = name.encode() + ((b' ' + comment) if comment is not None else b'')
+            if qual is not None:
+                out.write(b'@' + head + b'\n' + seq + b'\n+\n' + qual + b'\n')
+            else:
+                out.write(b'>' + head + b'\n' + seq + b'\n')
+            n += 1
+    finally:
+        stream.close()
+    return n

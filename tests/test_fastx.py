@@ -78,3 +78,15 @@ def test_fastq_records_and_qualities(tmp_path):
     bad.write_bytes(b'hello\n')
     with pytest.raises(ValueError):
         fastx.read_fastx(str(bad))
+
+
+def test_subseq_like_seqtk(tmp_path):
+    import io
+    fq = tmp_path / 'r.fq.gz'
+    with gzip.open(fq, 'wb') as f:
+        f.write(b'@r1 first read\nACGT\n+\nIIII\n@r2\nAC\nGT\n+\nII\nII\n>fa1 desc here\nAAAA\nCC\n@r3\tx\nGG\n+\n##\n')
+    out = io.BytesIO()
+    assert fastx.subseq(str(fq), ['r3', 'r2', b'fa1', 'missing'], out) == 3
+    assert out.getvalue() == b'@r2\nACGT\n+\nIIII\n>fa1 desc here\nAAAACC\n@r3 x\nGG\n+\n##\n'
+    out = io.BytesIO()
+    assert fastx.subseq(str(fq), [], out) == 0 and out.getvalue() == b''

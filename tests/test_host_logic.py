@@ -195,6 +195,52 @@ def test_human_decoy_classification_randomised_against_plain_loops():
         assert list(out['microbe_best_align_list']['read_id']) == sorted(micro)
 
 
+def test_abundance_statistic_against_plain_restatement():
+    """align_stat_by_assembly_id (megapath_nano.py:485-541, default configuration) on random tables: best row per
+    (read, assembly), sums, interval-union coverage with book-ended intervals merged, derived columns."""
+    import pandas as pd
+    from megapath_nano_amd.abundance import align_stat_by_assembly_id, covered_bp_by_assembly
+    t = pd.DataFrame({'assembly_id': ['A'] * 5 + ['B'] * 2, 'sequence_id': ['s1', 's1', 's1', 's2', 's1', 's1', 's1'],
+                      'sequence_from': [0, 10, 20, 0, 100, 5, 5], 'sequence_to': [10, 20, 25, 7, 130, 9, 9]})
+    assert covered_bp_by_assembly(t) == {'A': 25 + 7 + 30, 'B': 4}
+    rng = np.random.default_rng(11)
+    for trial in range(10):
+        rows = []
+        for r in range(int(rng.integers(1, 80))):
+            L = int(rng.integers(500, 9000))
+            for _ in range(int(rng.integers(1, 4))):
+                a = str(rng.choice(['A1', 'A2', 'A3']))
+                s0 = int(rng.integers(0, 3000))
+                e0 = s0 + int(rng.integers(1, 2500))
+                rows.append((f'r{r}', L, a, a + str(rng.choice(['_c1', '_c2'])), s0, e0, int(rng.integers(1, e0 - s0 + 1)), int(rng.integers(0, 200)),
+                             int(rng.choice([100, 200, 200, 900])), float(rng.random())))
+        al = pd.DataFrame(rows, columns=['read_id', 'read_length', 'assembly_id', 'sequence_id', 'sequence_from', 'sequence_to', 'match',
+                                         'edit_dist', 'alignment_score', 'alignment_score_tiebreaker'])
+        lens = pd.DataFrame({'assembly_id': ['A1', 'A2'], 'assembly_length': [4000, 0]})   # A3 unknown, A2 zero length
+        got = align_stat_by_assembly_id(al, lens).set_index('assembly_id')
+        best = {}
+        for row in rows:
+            key = (row[0], row[2])
+            if key not in best or (row[8], row[9]) > (best[key][8], best[key][9]):
+                best[key] = row
+        for a in sorted({k[1] for k in best}):
+            mine = [v for k, v in best.items() if k[1] == a]
+            covered = set()
+            for v in mine:
+                covered |= {(v[3], p) for p in range(v[4], v[5])}
+            L = {'A1': 4000, 'A2': 0}.get(a, 0)
+            tab = sum(v[5] - v[4] for v in mine)
+            g = got.loc[a]
+            assert (g['total_number_of_read'], g['total_read_bp'], g['total_aligned_bp'], g['match'], g['covered_bp']) == \
+                   (len(mine), sum(v[1] for v in mine), tab, sum(v[6] for v in mine), len(covered))
+            if L:
+                acp = len(covered) / L
+                assert abs(g['adjusted_average_depth'] - acp * tab / L) < 1e-12 and g['adjusted_total_aligned_bp'] == int(round(acp * tab / L * L))
+                assert abs(g['average_identity'] - sum(v[6] for v in mine) / tab) < 1e-12
+            else:
+                assert g['average_depth'] == 0 and g['adjusted_average_depth'] == 0 and g['adjusted_total_aligned_bp'] == 0
+
+
 def test_index_file_magic_detection(tmp_path):
     """`Align()` / bin/mpn-aligner treat a target as a saved index only if it carries the magic (no GPU needed to tell)."""
     from megapath_nano_amd.mapper import Index
