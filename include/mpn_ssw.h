@@ -15,8 +15,8 @@
  *
  * Domain: gap_open > gap_extend (all reference call sites use 8/2).  Outside it the
  * reference's SSE lazy-F early exits make results lane-layout dependent; libmpn refuses
- * (NULL / MPN_SSW_EDOMAIN) rather than return a different answer.  Read length <= 2048 in
- * this round (MPN_SSW_ETOOLONG otherwise).
+ * (NULL / MPN_SSW_EDOMAIN) rather than return a different answer.  Reads of up to 131072 bases are taken
+ * (MPN_SSW_ETOOLONG beyond); like the reference's 16-bit pass, scores are meaningful below 32768.
  */
 #ifndef MPN_SSW_H
 #define MPN_SSW_H
@@ -60,7 +60,7 @@ enum {
                               or traceback error) */
     MPN_SSW_EUNDEF = 2,    /* the reference's behaviour is undefined for this pair (walks outside its band) */
     MPN_SSW_EDOMAIN = 3,   /* gap_open <= gap_extend */
-    MPN_SSW_ETOOLONG = 4,  /* read longer than 2048 */
+    MPN_SSW_ETOOLONG = 4,  /* read longer than 131072 */
     MPN_SSW_ECIGAR_CAP = 5 /* cigar pool too small */
 };
 

@@ -208,6 +208,220 @@ __global__ __launch_bounds__(64) void ssw_score_kernel(SswDev p, const int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reads longer than 64 x 32 rows: the read is cut into STRIPS of 2048 rows; a strip is one score pass over the whole
+// reference with the rows in VGPRs as above, and what crosses a strip boundary travels through HBM scratch, one value
+// pair per reference column: H of the strip's last row (the next strip's diagonal / upper neighbour) and the vertical gap
+// state leaving it.  ssw.c's outputs are defined on whole columns (first column whose maximum exceeds every earlier
+// one; smallest read index holding it; abort of the 8-bit pass at the first saturating column), so the strips merge
+// their column maxima (colmax scratch) and the pass's results are derived from the merged columns afterwards: the
+// best column is the first one that attains the global maximum, the read end is the smallest row attaining it there.
+struct LongScratch {
+    int32_t *bh, *bf;      // per column: boundary H and F (int32[refLen] each)
+    int32_t *colmax;       // per scan position: maximum over the strips done so far
+};
+
+struct StripOut { int maxv, first_col, er; };
+
+// one strip: rows [rbase, rbase + 2048) of the (possibly reversed) read; prof is the strip's profile in LDS
+__device__ __forceinline__ StripOut score_strip(const int8_t *__restrict__ ref, int refLen, int dir, int P, int rbase, bool first_strip,
+                                                int gapO, int gapE, const int8_t *prof, LongScratch sc) {
+    constexpr int R = 32, PL = 64 * R;
+    const int lane = threadIdx.x & 63;
+    const int row0 = lane * R;
+    const int D = R * gapE;
+    int H[R], E[R], Hmax[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) H[k] = 0, E[k] = 0, Hmax[k] = 0;
+    StripOut o;
+    o.maxv = 0; o.first_col = -1;
+    int rc = 0, t_bh = 0, t_bf = NEG_INF, t_cm = 0, w_bh = 0, w_bf = 0, w_cm = 0, carry_diag = 0;
+    for (int c = 0; c < refLen; ++c) {
+        if ((c & 63) == 0) {
+            const int idx = c + lane;
+            rc = idx < refLen ? ref[dir ? refLen - 1 - idx : idx] : 0;
+            if (!first_strip && idx < refLen) { t_bh = sc.bh[idx]; t_bf = sc.bf[idx]; }
+            t_cm = (!first_strip && idx < refLen) ? sc.colmax[idx] : 0;
+        }
+        const int sym = __builtin_amdgcn_readlane(rc, c & 63);
+        const int in_h = first_strip ? 0 : __builtin_amdgcn_readlane(t_bh, c & 63);        // H(rbase - 1, c)
+        const int in_f = first_strip ? NEG_INF : __builtin_amdgcn_readlane(t_bf, c & 63);  // F entering row rbase at c
+        const int *pw = reinterpret_cast<const int *>(prof + sym * PL + row0);
+        const int sh = wave_shr1(H[R - 1], 0);
+        int diag = lane == 0 ? carry_diag : sh;
+        carry_diag = in_h;
+        int fl = NEG_INF;
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) {
+            const int w = pw[q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = q * 4 + b;
+                const int s = (w << (24 - 8 * b)) >> 24;
+                const int hold = H[k];
+                int a = max(diag + s, 0);
+                a = max(a, E[k]);
+                H[k] = a;
+                diag = hold;
+                fl = max(fl - gapE, a - gapO);
+            }
+        }
+        int t = wave_scan_max(fl + lane * D);
+        t = wave_shr1(t, NEG_INF);
+        // F entering this lane's first row: from the lanes before it, and from the previous strip decayed over their rows
+        int f = lane == 0 ? in_f : max(t - (lane - 1) * D, in_f - lane * D);
+        int cm = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int h = max(H[k], f);
+            H[k] = h;
+            E[k] = max(E[k] - gapE, h - gapO);
+            if (rbase + row0 + k < P) cm = max(cm, h);
+            f = max(f - gapE, h - gapO);
+        }
+        const int colmax = wave_reduce_max(cm);
+        if (colmax > o.maxv) {
+            o.maxv = colmax;
+            o.first_col = c;
+#pragma unroll
+            for (int k = 0; k < R; ++k) Hmax[k] = H[k];
+        }
+        // boundary for the next strip (lane 63's last row) and merged column maximum, flushed every 64 columns
+        const int out_h = __builtin_amdgcn_readlane(H[R - 1], 63), out_f = __builtin_amdgcn_readlane(f, 63);
+        const int merged = max(colmax, __builtin_amdgcn_readlane(t_cm, c & 63));
+        if (lane == (c & 63)) { w_bh = out_h; w_bf = out_f; w_cm = merged; }
+        if ((c & 63) == 63 || c == refLen - 1) {
+            const int idx = (c & ~63) + lane;
+            if (idx <= c) { sc.bh[idx] = w_bh; sc.bf[idx] = w_bf; sc.colmax[idx] = w_cm; }
+        }
+    }
+    int er = 1 << 30;
+#pragma unroll
+    for (int k = R - 1; k >= 0; --k)
+        if (Hmax[k] == o.maxv && rbase + row0 + k < P) er = rbase + row0 + k;
+    o.er = wave_reduce_min(er);
+    return o;
+}
+
+__device__ __forceinline__ void build_strip_profile(int8_t *prof, const int8_t *mat, int nsym, const int8_t *read, int readLen,
+                                                    bool reversed, int rbase) {
+    constexpr int PL = 64 * 32;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nsym * PL; idx += 64) {
+        const int sym = idx / PL, j = rbase + idx - sym * PL;
+        int8_t v = 0;
+        if (j < readLen) v = mat[sym * nsym + read[reversed ? readLen - 1 - j : j]];
+        prof[idx] = v;
+    }
+    __syncthreads();
+}
+
+// a whole pass = all strips; results as score_pass defines them
+__device__ __forceinline__ PassOut score_pass_long(const int8_t *__restrict__ ref, int refLen, int dir, const int8_t *read, int readLen,
+                                                   bool reversed, int sse_lanes, int gapO, int gapE, int bias, const int8_t *mat,
+                                                   int nsym, int8_t *prof, LongScratch sc, uint16_t *__restrict__ mcol) {
+    const int lane = threadIdx.x & 63;
+    const int P = (readLen + sse_lanes - 1) / sse_lanes * sse_lanes;
+    const int n_strips = (P + 2047) / 2048;
+    int best_er = 1 << 30, gmax = 0;
+    // the strips' own results are kept for the merge: (max, first column, row) per strip, lane s holds strip s (<= 64 strips)
+    int s_max = 0, s_col = -1, s_er = 1 << 30;
+    for (int s = 0; s < n_strips; ++s) {
+        build_strip_profile(prof, mat, nsym, read, readLen, reversed, s * 2048);
+        const StripOut so = score_strip(ref, refLen, dir, P, s * 2048, s == 0, gapO, gapE, prof, sc);
+        if (lane == (s & 63)) { s_max = so.maxv; s_col = so.first_col; s_er = so.er; }
+        gmax = max(gmax, so.maxv);
+    }
+    __syncthreads();  // the column maxima written by this wave are read back below
+    PassOut o;
+    o.maxv = gmax;
+    o.overflow = (sse_lanes == 16 && gmax + bias >= 255) ? 1 : 0;
+    o.end_ref = sse_lanes == 16 ? -1 : 0;
+    o.end_read = 0;
+    if (gmax > 0) {
+        int cand = 1 << 30;  // first scan position whose merged column maximum is the global one
+        for (int idx = lane; idx < refLen; idx += 64) if (sc.colmax[idx] == gmax) { cand = idx; break; }
+        const int cstar = wave_reduce_min(cand);
+        o.end_ref = dir ? refLen - 1 - cstar : cstar;
+        const int er = (s_max == gmax && s_col == cstar) ? s_er : (1 << 30);
+        best_er = wave_reduce_min(er);
+        o.end_read = min(readLen - 1, best_er);
+    }
+    if (mcol) for (int idx = lane; idx < refLen; idx += 64) mcol[idx] = (uint16_t)sc.colmax[idx];
+    return o;
+}
+
+__global__ __launch_bounds__(64) void ssw_score_long_kernel(SswDev p, const int32_t *__restrict__ order, int32_t *__restrict__ scratch,
+                                                            const int64_t *__restrict__ scratch_off) {
+    extern __shared__ __attribute__((aligned(16))) int8_t prof[];
+    const int job = order[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int readLen = p.read_len[job], refLen = p.ref_len[job], maskLen = p.mask_len[job];
+    const int8_t *read = p.reads + p.read_off[job];
+    const int8_t *ref = p.refs + p.ref_off[job];
+    uint16_t *mcol = p.mcol + p.mcol_off[job];
+    LongScratch sc;
+    sc.bh = scratch + scratch_off[job]; sc.bf = sc.bh + refLen; sc.colmax = sc.bf + refLen;
+    const bool have_byte = p.score_size == 0 || p.score_size == 2, have_word = p.score_size == 1 || p.score_size == 2;
+    int word = 0;
+    PassOut o;
+    if (have_byte) {
+        o = score_pass_long(ref, refLen, 0, read, readLen, false, 16, p.gapO, p.gapE, p.bias, p.mat, p.nsym, prof, sc, mcol);
+        if (o.overflow) {
+            if (!have_word) { if (lane == 0) p.status[job] = MPN_SSW_ENULL; return; }
+            o = score_pass_long(ref, refLen, 0, read, readLen, false, 8, p.gapO, p.gapE, 0, p.mat, p.nsym, prof, sc, mcol);
+            word = 1;
+        }
+    } else {
+        o = score_pass_long(ref, refLen, 0, read, readLen, false, 8, p.gapO, p.gapE, 0, p.mat, p.nsym, prof, sc, mcol);
+        word = 1;
+    }
+    int s2 = 0, r2 = 0;
+    {
+        int e1 = max(o.end_ref - maskLen, 0);
+        int e2 = min(o.end_ref + maskLen, refLen);
+        int start2 = word ? e2 : e2 + 1;
+        int bv = 0, bi = 1 << 30;
+        __syncthreads();
+        for (int idx = lane; idx < e1; idx += 64) { int v = mcol[idx]; if (v > bv) bv = v, bi = idx; }
+        for (int idx = start2 + lane; idx < refLen; idx += 64) { int v = mcol[idx]; if (v > bv) bv = v, bi = idx; }
+        s2 = wave_reduce_max(bv);
+        int cand = (bv == s2 && s2 > 0) ? bi : (1 << 30);
+        cand = wave_reduce_min(cand);
+        r2 = s2 > 0 ? cand : 0;
+    }
+    int ref_begin = -1, read_begin = -1, need = 0, st = MPN_SSW_OK;
+    const int score1 = o.maxv, ref_end1 = o.end_ref, read_end1 = o.end_read;
+    const bool stop = p.flag == 0 || (p.flag == 2 && score1 < p.filters);
+    if (!stop) {
+        const int rl = read_end1 + 1;
+        // the reverse pass stops at the column whose maximum equals score1: the first column attaining the pass's maximum
+        PassOut rv = score_pass_long(ref, ref_end1 + 1, 1, read, rl, true, word ? 8 : 16, p.gapO, p.gapE, word ? 0 : p.bias, p.mat,
+                                     p.nsym, prof, sc, nullptr);
+        ref_begin = rv.end_ref;
+        read_begin = read_end1 - rv.end_read;
+        const bool nocig = (7 & p.flag) == 0 || ((2 & p.flag) != 0 && score1 < p.filters) ||
+                           ((4 & p.flag) != 0 && (ref_end1 - ref_begin > p.filterd || read_end1 - read_begin > p.filterd));
+        if (!nocig) {
+            if (ref_begin < 0 || read_begin < 0 || ref_end1 - ref_begin + 1 <= 0 || read_end1 - read_begin + 1 <= 0)
+                st = MPN_SSW_EUNDEF;
+            else
+                need = 1;
+        }
+    }
+    if (lane == 0) {
+        p.score1[job] = score1;
+        p.ref_end1[job] = ref_end1;
+        p.read_end1[job] = read_end1;
+        p.score2[job] = maskLen >= 15 ? s2 : 0;
+        p.ref_end2[job] = maskLen >= 15 ? r2 : -1;
+        p.ref_begin1[job] = ref_begin;
+        p.read_begin1[job] = read_begin;
+        p.need_cigar[job] = need;
+        p.status[job] = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // banded traceback
 struct BandDev {
     SswDev s;
@@ -356,7 +570,9 @@ static int ssw_batch_impl(int32_t n_pairs, const int8_t *reads, const int64_t *r
     int64_t reads_total = 0, refs_total = 0;
     std::vector<int64_t> mcol_off(n_pairs);
     int64_t mcol_total = 0;
-    std::vector<int32_t> cls[4];
+    std::vector<int32_t> cls[5];  // [4]: reads of more than 2048 rows (strip kernel)
+    std::vector<int64_t> long_off(n_pairs, 0);
+    int64_t long_total = 0;
     for (int i = 0; i < n_pairs; ++i) {
         cigar_len[i] = 0; cigar_off[i] = 0;
         reads_total = std::max<int64_t>(reads_total, read_off[i] + std::max(read_len[i], 0));
@@ -365,11 +581,12 @@ static int ssw_batch_impl(int32_t n_pairs, const int8_t *reads, const int64_t *r
         mcol_total += ((int64_t)std::max(ref_len[i], 0) + 63) / 64 * 64;
         if (gap_open <= gap_extend) st_h[i] = MPN_SSW_EDOMAIN;
         else if (read_len[i] <= 0 || ref_len[i] < 0) st_h[i] = MPN_SSW_EUNDEF;
-        else if (read_len[i] > 2048) st_h[i] = MPN_SSW_ETOOLONG;
+        else if ((int64_t)read_len[i] > 64 * 2048) st_h[i] = MPN_SSW_ETOOLONG;  // (64 strips of 2048 rows)
         else if (score_size < 0 || score_size > 2) st_h[i] = MPN_SSW_ENULL;  // ssw.c:801-804
         else {
             int P = (read_len[i] + 15) / 16 * 16;
-            cls[P <= 256 ? 0 : P <= 512 ? 1 : P <= 1024 ? 2 : 3].push_back(i);
+            cls[P <= 256 ? 0 : P <= 512 ? 1 : P <= 1024 ? 2 : P <= 2048 ? 3 : 4].push_back(i);
+            if (P > 2048) { long_off[i] = long_total; long_total += 3 * (int64_t)std::max(ref_len[i], 1); }
         }
     }
     SswDev d;
@@ -402,12 +619,20 @@ static int ssw_batch_impl(int32_t n_pairs, const int8_t *reads, const int64_t *r
     d.mcol = d_mcol.p; d.mcol_off = d_mcol_off.p;
 
     std::vector<int32_t> order;
-    int cnt[4], base[4];
-    for (int c = 0; c < 4; ++c) { base[c] = (int)order.size(); cnt[c] = (int)cls[c].size(); order.insert(order.end(), cls[c].begin(), cls[c].end()); }
+    int cnt[5], base[5];
+    for (int c = 0; c < 5; ++c) { base[c] = (int)order.size(); cnt[c] = (int)cls[c].size(); order.insert(order.end(), cls[c].begin(), cls[c].end()); }
     if (d_order.upload(order.data(), order.size(), st)) return -1;
     if (launch_score<4>(d, d_order.p + base[0], cnt[0], st) || launch_score<8>(d, d_order.p + base[1], cnt[1], st) ||
         launch_score<16>(d, d_order.p + base[2], cnt[2], st) || launch_score<32>(d, d_order.p + base[3], cnt[3], st))
         return -1;
+    DevBuf<int32_t> d_long;
+    DevBuf<int64_t> d_long_off;
+    if (cnt[4] > 0) {
+        if (d_long.alloc((size_t)long_total) || d_long_off.upload(long_off.data(), n_pairs, st)) return -1;
+        hipLaunchKernelGGL(ssw_score_long_kernel, dim3(cnt[4]), dim3(64), (size_t)d.nsym * 64 * 32, st, d, d_order.p + base[4], d_long.p,
+                           (const int64_t *)d_long_off.p);
+        MPN_HIP_CHECK(hipGetLastError());
+    }
     std::vector<int32_t> res((size_t)n_pairs * 9);
     if (d_res.download(res.data(), res.size(), st)) return -1;
     MPN_HIP_CHECK(hipStreamSynchronize(st));

@@ -94,10 +94,10 @@ def test_edge_cases(libmpn, oracle_built):
     rng = np.random.default_rng(9)
     ref = rng.integers(0, 4, size=500).astype(np.int8)
     reads = [ref[:1].copy(), ref[100:116].copy(), np.full(40, 4, dtype=np.int8), ref[:2048 // 4].copy(),
-             np.concatenate([ref, ref, ref, ref, ref[:48]])[:2048], np.zeros(0, dtype=np.int8),
-             np.zeros(2049, dtype=np.int8)]
+             np.concatenate([ref, ref, ref, ref, ref[:48]])[:2048], np.zeros(2049, dtype=np.int8), np.zeros(0, dtype=np.int8),
+             np.zeros(64 * 2048 + 1, dtype=np.int8)]
     res = ssw_align_batch(reads, [ref] * len(reads), mat, 5, 2, 8, 2, 15, 0, 0, [15] * len(reads))
-    assert res[-1]['status'] == 4  # too long for this round
+    assert res[-1]['status'] == 4  # longer than 64 strips of 2048 rows
     assert res[-2]['status'] == STATUS_UNDEF  # empty read: reference indexes pvHStore[-1]
     for r, q in zip(res[:-2], reads[:-2]):
         want = oracle_align(read=q, ref=ref, mat=mat, gap_open=8, gap_extend=2, flag=15, filters=0, filterd=0, mask=15,
@@ -106,3 +106,48 @@ def test_edge_cases(libmpn, oracle_built):
     # refused domain
     res = ssw_align_batch(reads[:1], [ref], mat, 5, 2, 2, 2, 0, 0, 0, [15])
     assert res[0]['status'] == STATUS_DOMAIN
+
+
+def test_reads_longer_than_2048_match_oracle_and_reference(libmpn, oracle_built):
+    """ssw.c has no read-length limit (ssw_align :762-852); the strip kernel cuts the read into 2048-row strips.  Pairs with
+    reads of 2049 .. 9000 bases (boundaries of the strips and of the 16/8-row SSE padding), both score passes, all flag sets,
+    against the oracle and, where the box has it, the reference's own compiled ssw.c (oracle/_ref/libssw.so)."""
+    import os
+    from oracle.ssw_bindings import oracle_align
+    from ssw_cases import build_matrix, mutate
+    rng = np.random.default_rng(4242)
+    cases = []
+    for qlen, reflen, kind in ((2049, 2600, 1), (2064, 3000, 1), (4096, 4500, 2), (4097, 4200, 1), (4100, 900, 3), (6000, 7000, 1),
+                               (6150, 6100, 0), (9000, 2500, 4), (2500, 9000, 1), (3000, 3300, 5)):
+        ref = rng.integers(0, 4, size=reflen).astype(np.int8)
+        if kind == 0:
+            read = np.resize(ref, qlen).copy()                       # exact (tandem continuation past the end)
+        elif kind == 3:
+            read = np.concatenate([rng.integers(0, 4, size=(qlen - reflen) // 2).astype(np.int8), mutate(rng, ref, 0.02, 0.01, 0.01),
+                                   rng.integers(0, 4, size=qlen).astype(np.int8)])[:qlen]  # the reference inside a longer read
+        elif kind == 4:
+            read = np.concatenate([rng.integers(0, 4, size=5000).astype(np.int8), mutate(rng, ref[200:2300], 0.03, 0.02, 0.02),
+                                   rng.integers(0, 4, size=qlen).astype(np.int8)])[:qlen]  # hit deep inside the third strip
+        elif kind == 5:
+            read = rng.integers(0, 4, size=qlen).astype(np.int8)                          # unrelated
+        else:
+            src = np.resize(ref, max(qlen + 200, reflen))
+            read = mutate(rng, src[:qlen + 150], 0.01 * kind, 0.01, 0.01)[:qlen]
+            if kind == 2:
+                read[rng.integers(0, qlen, size=40)] = 4
+        for flag, score_size, mask in ((2, 2, qlen), (15, 2, qlen // 2), (0, 1, 15), (8, 2, 10), (1, 0, qlen)):
+            cases.append(dict(read=read, ref=ref, flag=flag, filters=0, filterd=0, mask=mask, score_size=score_size,
+                              mat=build_matrix(2, 3, True), gap_open=4, gap_extend=1))
+    got = run_batch_grouped(cases)
+    ref_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'libssw.so')
+    n_checked_ref = 0
+    for c, g in zip(cases, got):
+        kw = dict(read=c['read'], ref=c['ref'], mat=c['mat'], gap_open=c['gap_open'], gap_extend=c['gap_extend'], flag=c['flag'],
+                  filters=c['filters'], filterd=c['filterd'], mask=c['mask'], score_size=c['score_size'])
+        want = oracle_align(**kw)
+        assert g == want, (len(c['read']), len(c['ref']), c['flag'], c['score_size'])
+        if os.path.exists(ref_lib):
+            from oracle.ssw_bindings import ref_align
+            assert ref_align(**kw) == want
+            n_checked_ref += 1
+    assert any(g is not None and g != 'undefined' and g[0] > 2000 for g in got)
