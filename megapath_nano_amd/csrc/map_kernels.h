@@ -391,37 +391,79 @@ __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict_
     }
 }
 
+// Anchor emission as a load-balanced expand: a wave takes 64 consecutive minimizers, whose anchors form ONE contiguous
+// range of the output (the per-read offsets are a global prefix sum), and walks that range 64 output slots at a time.
+// A lane finds the minimizer that owns its slot by a 6-step search over the wave's start offsets (LDS), gathers the
+// index position -- lanes of one minimizer read consecutive words -- and stores its 16-byte anchor: the stores of a
+// wave are one contiguous KB.  (One lane per minimizer writing its own run of anchors cost 3.1 bytes of HBM writes per
+// byte of anchors: every 16-byte store was a partial line.)
 __global__ __launch_bounds__(256) void seed_fill_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz,
                                                         const int32_t *__restrict__ occ, const int64_t *__restrict__ pos_start,
                                                         const int64_t *__restrict__ rel_off, const uint64_t *__restrict__ pos,
                                                         const int64_t *__restrict__ anchor_off, const int32_t *__restrict__ seq_len,
                                                         u128 *__restrict__ anchors) {
-    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_mz; m += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t t = occ[m];
-        if (t <= 0) continue;
-        const uint64_t mx = mz[m].x, my = mz[m].y;
-        const int read = (int)(my >> 32);
-        const uint32_t q_pos = (uint32_t)my, q_span = mx & 0xff;
-        const int32_t qlen = seq_len[read];
-        bool tandem = false;
-        if (m > mz_off[read] && mz[m - 1].x >> 8 == mx >> 8) tandem = true;
-        if (m + 1 < mz_off[read + 1] && mz[m + 1].x >> 8 == mx >> 8) tandem = true;
-        u128 *out = anchors + anchor_off[read] + rel_off[m];
-        const uint64_t *cr = pos + pos_start[m];
-        for (int32_t k = 0; k < t; ++k) {
-            const uint64_t r = cr[k];
-            const uint32_t rpos = (uint32_t)r >> 1;
-            u128 a;
-            if ((r & 1) == (q_pos & 1)) {
-                a.x = (r & 0xffffffff00000000ULL) | rpos;
-                a.y = (uint64_t)q_span << 32 | q_pos >> 1;
-            } else {
-                a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
-                a.y = (uint64_t)q_span << 32 | (uint32_t)(qlen - ((int32_t)(q_pos >> 1) + 1 - (int32_t)q_span) - 1);
-            }
-            if (tandem) a.y |= 1ULL << 42;
-            out[k] = a;
+    __shared__ int64_t s_g[4][64], s_ps[4][64];
+    __shared__ uint64_t s_y[4][64];   // flags | span << 32 | query position (forward strand), qlen in s_q
+    __shared__ int32_t s_q[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t *g = s_g[wv], *ps = s_ps[wv];
+    uint64_t *yy = s_y[wv];
+    int32_t *qq = s_q[wv];
+    const int64_t n_blocks = (n_mz + 63) / 64;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wv; blk < n_blocks; blk += (int64_t)gridDim.x * 4) {
+        const int64_t m = blk * 64 + lane;
+        int32_t t = 0;
+        int64_t g0 = 0;
+        if (m < n_mz) {
+            t = occ[m];
+            if (t < 0) t = 0;
+            const uint64_t mx = mz[m].x, my = mz[m].y;
+            const int read = (int)(my >> 32);
+            bool tandem = false;
+            if (m > mz_off[read] && mz[m - 1].x >> 8 == mx >> 8) tandem = true;
+            if (m + 1 < mz_off[read + 1] && mz[m + 1].x >> 8 == mx >> 8) tandem = true;
+            g0 = anchor_off[read] + rel_off[m];
+            ps[lane] = pos_start[m];
+            // query side of the anchor: span, position + strand bit of the minimizer, the tandem flag
+            yy[lane] = (tandem ? 1ULL << 42 : 0ULL) | (uint64_t)(mx & 0xff) << 32 | (uint32_t)my;
+            qq[lane] = seq_len[read];
         }
+        // lanes past the end of the list continue the last real offset so that the search never lands on them
+        const int64_t end_own = g0 + t;
+        int64_t end_all = end_own;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) { const int64_t o = __shfl_xor(end_all, d); end_all = o > end_all ? o : end_all; }
+        g[lane] = m < n_mz ? g0 : end_all;
+        const int64_t first = __shfl(g0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t p0 = first; p0 < end_all; p0 += 64) {
+            const int64_t p = p0 + lane;
+            if (p < end_all) {
+                int lo = 0, hi = 63;  // last lane whose range starts at or before p
+#pragma unroll
+                for (int step = 0; step < 6; ++step) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (g[mid] <= p) lo = mid; else hi = mid - 1;
+                }
+                const int64_t k = p - g[lo];
+                const uint64_t r = pos[ps[lo] + k];
+                const uint64_t y = yy[lo];
+                const uint32_t q_pos = (uint32_t)y, q_span = (uint32_t)(y >> 32) & 0xff;
+                const uint32_t rpos = (uint32_t)r >> 1;
+                u128 a;
+                if ((r & 1) == (q_pos & 1)) {
+                    a.x = (r & 0xffffffff00000000ULL) | rpos;
+                    a.y = (uint64_t)q_span << 32 | q_pos >> 1;
+                } else {
+                    a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+                    a.y = (uint64_t)q_span << 32 | (uint32_t)(qq[lo] - ((int32_t)(q_pos >> 1) + 1 - (int32_t)q_span) - 1);
+                }
+                a.y |= y & (1ULL << 42);
+                anchors[p] = a;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

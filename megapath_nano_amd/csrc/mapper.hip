@@ -175,7 +175,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     if (n_a > 0) {
         // anchors in (minimizer, hit) order -> tmp; partition per read on the top key bits -> o.anchors; small buckets are
         // sorted in LDS, the large ones (true loci) by radix passes with tmp as the bounce buffer
-        hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
+        hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d((n_mz + 63) / 64, 4, 256 * 64)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
                            pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, tmp.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(11, 36);
