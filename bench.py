@@ -40,6 +40,15 @@ def log(msg):
     print(f'[bench {time.time() - T00:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
+def cpu_quota():
+    """CPUs this container may use (cgroup quota), or None when unlimited: the library sizes its host pool by it."""
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        return None if q == 'max' else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def community(args):
     """10 members with log-normal abundance, including a close-relative pair (genome 0 and its 99 % copy)."""
     n = args.genomes
@@ -68,7 +77,7 @@ def cpu_baseline(genomes, packed, opt_kw, seconds_target=15.0):
     from concurrent.futures import ThreadPoolExecutor
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'libmm2_oracle.so'], stdout=subprocess.DEVNULL)
     from oracle import mm2_bindings as mb
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = max(1, min(16, os.cpu_count() or 1, int(cpu_quota() or 16)))
     t0 = time.time()
     oidx = mb.Index(genomes)
     idx_s = time.time() - t0
@@ -171,6 +180,7 @@ def main():
     mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     stats_acc = {}
     counts = None
     bases = 0
@@ -186,6 +196,7 @@ def main():
     torch.cuda.synchronize()
     mdist.barrier()
     dt = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0
     if world > 1:
         import torch.distributed as dist
         rd = red_device if red_device is not None else 'cpu'
@@ -260,9 +271,10 @@ def main():
                         f'batches rotated over the steps), -N 50 -p 1 -x map-ont -c',
             'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': args.genomes, 'index_bp': args.genomes * args.genome_len,
             'index_build_s': round(index_s, 2), 'index_minimizers': int(idx.n_minimizers), 'mid_occ': int(opt.mid_occ),
-            'parallelism': f'reads sharded over {world} GPU(s), index replicated', 'host_cpus': os.cpu_count(),
+            'parallelism': f'reads sharded over {world} GPU(s), index replicated', 'host_cpus': os.cpu_count(), 'cpu_quota': cpu_quota(),
         },
         'pcie_inclusive_gbp_per_min': None if pcie is None else round(pcie, 2),
+        'host_cpu_s_per_step': round(host_cpu_s / K, 3),
         'roofline': {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,

@@ -1504,6 +1504,30 @@ struct mpn_hits {
     std::vector<int32_t> lens;
 };
 
+// Threads of the host pool: what the caller asks for, else the cores this process may actually use -- the container's CPU
+// quota (cgroup v2 cpu.max / v1 cfs quota) counts, not just the visible cores: with 256 visible cores and a quota of 16
+// a pool of 32 threads is throttled and loses 5 % -- capped at 32.
+static int default_host_threads(const mpn_map_opt *opt) {
+    if (const char *e = getenv("MPN_HOST_THREADS")) return std::max(1, atoi(e));
+    if (opt->host_threads > 0) return opt->host_threads;
+    static const int detected = []() {
+        int n = std::min(32, std::max(1, (int)std::thread::hardware_concurrency()));
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+        }
+        if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)((quota + period - 1) / period)));
+        return n;
+    }();
+    return detected;
+}
+
 // the mapping itself: every read's final hits against ONE index -> rs, rep_len (no text)
 static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                           const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off, const int32_t *r_len,
@@ -1524,9 +1548,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     }
     MPN_HIP_CHECK(hipStreamSynchronize(st0));
     wt.stop_into(g_stats[16]);
-    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
-    if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
-    if (n_threads < 1) n_threads = 1;
+    int n_threads = default_host_threads(opt);
     *n_threads_out = n_threads;
     g_pool.ensure(n_threads);
     // sub-batches of ~24 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
@@ -1809,9 +1831,7 @@ extern "C" int64_t mpn_hits_finish(mpn_hits *acc, const mpn_map_opt *opt, int32_
     std::lock_guard<std::mutex> call_guard(g_call_mu);
     if (cols) cols->n_rows = 0;
     if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; g_kept = Kept(); if (opt->out_sam == 2) g_kept.has_sam = true; return 0; }
-    int n_threads = opt->host_threads > 0 ? opt->host_threads : std::min(32, (int)std::thread::hardware_concurrency());
-    if (const char *e = getenv("MPN_HOST_THREADS")) n_threads = atoi(e);
-    if (n_threads < 1) n_threads = 1;
+    const int n_threads = default_host_threads(opt);
     g_pool.ensure(n_threads);
     if (!acc->n_parts) { set_error("mpn_hits_finish: no part was mapped"); return -1; }
     parallel_for(n, n_threads, [&](int i, int) { merge_regs(opt, acc->k, acc->regs[(size_t)i], acc->rep_len[(size_t)i]); });
