@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <thread>
+#include <time.h>
 #include <atomic>
 #include <functional>
 #include <mutex>
@@ -716,10 +717,12 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
 // through its burst while the threads of the workers that wait on the GPU sleep.  Every burst is a job in one queue and
 // every idle pool thread helps the oldest open job; the posting thread works on its own job too, so a job always
 // advances.  fn(i, slot): slot < max_par identifies the helping thread (per-thread accumulators of the caller).
+static bool g_cpu_on = false;                 // MPN_DEBUG_CPU=1: thread CPU time of every parallel region, by tag
+static std::atomic<long long> g_cpu_ns[32];
 class HostPool {
     struct Job {
         const std::function<void(int, int)> *fn;
-        int n, max_par;
+        int n, max_par, tag = 0;
         std::atomic<int> next{0};
         int slots = 1, active = 0;  // guarded by mu (slot 0 is the posting thread)
     };
@@ -730,7 +733,12 @@ class HostPool {
     bool stop = false;
 
     static void run(Job &j, int slot) {
+        if (!g_cpu_on) { for (;;) { const int i = j.next.fetch_add(1); if (i >= j.n) break; (*j.fn)(i, slot); } return; }
+        timespec a, b;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &a);
         for (;;) { const int i = j.next.fetch_add(1); if (i >= j.n) break; (*j.fn)(i, slot); }
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b);
+        g_cpu_ns[j.tag & 31] += (b.tv_sec - a.tv_sec) * 1000000000LL + (b.tv_nsec - a.tv_nsec);
     }
     Job *pick(int *slot) {  // mu held
         for (Job *j : jobs)
@@ -756,10 +764,10 @@ public:
         std::lock_guard<std::mutex> g(mu);
         while ((int)threads.size() < n_threads - 1) threads.emplace_back([this]() { worker(); });
     }
-    void parallel_for(int n, int max_par, const std::function<void(int, int)> &fn) {
+    void parallel_for(int n, int max_par, const std::function<void(int, int)> &fn, int tag = 0) {
         if (max_par <= 1 || n < 2) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
         Job j;
-        j.fn = &fn; j.n = n; j.max_par = max_par;
+        j.fn = &fn; j.n = n; j.max_par = max_par; j.tag = tag;
         { std::lock_guard<std::mutex> g(mu); jobs.push_back(&j); }
         cv_work.notify_all();
         run(j, 0);
@@ -775,7 +783,7 @@ public:
 };
 static HostPool g_pool;
 
-static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn) { g_pool.parallel_for(n, n_threads, fn); }
+static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn, int tag = 0) { g_pool.parallel_for(n, n_threads, fn, tag); }
 
 struct ReadState {
     std::vector<Reg> regs;
@@ -946,10 +954,10 @@ static thread_local Slot *tl_slot = &g_slots[0];
 
 static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 3 workgroup kernel, 4 strip (else band), 5 band
 
-static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn) {
+static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn, int tag = 0) {
     if (n_threads <= 1 || n < 8192) { fn(0, n, 0); return; }
     // chunk t of n_threads equal ranges; the chunk index is what the callers use for their per-thread accumulators
-    g_pool.parallel_for(n_threads, n_threads, [&](int t, int) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+    g_pool.parallel_for(n_threads, n_threads, [&](int t, int) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); }, tag);
 }
 
 // the second pass of a gap fill whose CIGAR failed the z-drop test: exact maximum, band (or anti-diagonal) layout
@@ -1048,7 +1056,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             }
             list_id[j] = (int8_t)lid;
         }
-    });
+    }, 6);
     Acc M;
     for (const Acc &A : accs) {
         for (int c = 0; c < 5; ++c) M.lds_need[c] = std::max(M.lds_need[c], A.lds_need[c]);
@@ -1096,7 +1104,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             std::sort(flat + base[l], flat + base[l] + cnt[l], [&](int32_t x, int32_t y) {
                 return jobs[x].qlen != jobs[y].qlen ? jobs[x].qlen > jobs[y].qlen : x < y;
             });
-    });
+    }, 7);
     if (getenv("MPN_DEBUG_JOBS")) {
         static const char *const fam[] = {"lds", "wg", "strip", "band"};
         for (int l = 0; l < N_LISTS; ++l) {
@@ -1117,7 +1125,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         SL.pool_used.ensure(16))
         return -1;
     // the H2D copies leave from pinned memory, so they are truly asynchronous
-    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int) { memcpy(SL.pin_jobs.as<ExtJob>() + lo, jobs + lo, (size_t)(hi - lo) * sizeof(ExtJob)); });
+    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int) { memcpy(SL.pin_jobs.as<ExtJob>() + lo, jobs + lo, (size_t)(hi - lo) * sizeof(ExtJob)); }, 8);
     wt.stop_into(g_stats[27]);
     struct { ExtJob *p; } d_jobs{SL.pool_jobs.as<ExtJob>()};
     struct { uint8_t *p; } P{SL.pool_P.as<uint8_t>()};
@@ -1403,7 +1411,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             for (int j = 0; j < qlen; ++j) f[j] = g_nt4.fwd[(unsigned char)s[j]];
             for (int j = 0; j < qlen; ++j) rc[j] = g_nt4.comp[f[qlen - 1 - j]];
         }
-    });
+    }, 1);
     wt.stop_into(g_stats[19]);
     if (opt->with_cigar) {
         for (int round = 0; round < 64; ++round) {
@@ -1422,7 +1430,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
                     S.plans.emplace_back();
                     plan_align(opt, idx, i, seq_len[i], r, S.n_a, S.a.data(), S.plans.back(), sinks[i]);
                 }
-            });
+            }, 2);
             JobSink sink;
             std::vector<int> job_base(n, 0);
             {
@@ -1440,7 +1448,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
                     if (pl.right_job >= 0) pl.right_job += base;
                     for (Seg &sg : pl.segs) if (sg.job >= 0) sg.job += base;
                 }
-            });
+            }, 3);
             wt.stop_into(g_stats[20]);
             if (!any) break;
             ++g_stats[7];
@@ -1463,7 +1471,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
                     const bool has = stitch_align(opt, idx, seq_len[i], q2, S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs.data(), cig);
                     if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
                 }
-            });
+            }, 4);
             wt.stop_into(g_stats[22]);
         }
     }
@@ -1488,7 +1496,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         std::vector<u128>().swap(S.a);
         std::vector<uint8_t>().swap(S.q4[0]);
         std::vector<uint8_t>().swap(S.q4[1]);
-    });
+    }, 5);
     g_stats[6] += n_aln;
     wt.stop_into(g_stats[23]);
     return 0;
@@ -1604,6 +1612,9 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     std::string err;
     const bool dbg_workers = getenv("MPN_DEBUG_WORKERS") != nullptr;
     g_phase_log.on = getenv("MPN_DEBUG_PHASES") != nullptr;
+    g_cpu_on = getenv("MPN_DEBUG_CPU") != nullptr;
+    if (g_cpu_on) { for (auto &c : g_cpu_ns) c = 0; for (auto &c : g_worker_cpu_ns) c = 0; }
+    g_worker_cpu_on = g_cpu_on;
     if (g_phase_log.on) { g_phase_log.recs.clear(); g_phase_log.origin = std::chrono::steady_clock::now(); }
     const auto t_call = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
@@ -1653,6 +1664,14 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     if (g_phase_log.on) {
         for (const auto &r : g_phase_log.recs) fprintf(stderr, "[phase] %d %d %lld %lld\n", r.worker, r.slot, (long long)r.t0, (long long)r.t1);
         fprintf(stderr, "[phase-end]\n");
+    }
+    if (g_cpu_on) {
+        static const char *const nm[] = {"other", "hits", "plan", "plan-copy", "stitch", "final", "dp-group-A", "strip-sort", "job-copy"};
+        fprintf(stderr, "[cpu] thread CPU ms in parallel regions:");
+        for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.0f", nm[k], g_cpu_ns[k].load() / 1e6);
+        fprintf(stderr, "\n[cpu] worker-thread CPU ms by phase slot:");
+        for (int k = 0; k < 64; ++k) if (g_worker_cpu_ns[k].load() > 500000) fprintf(stderr, " [%d] %.0f", k, g_worker_cpu_ns[k].load() / 1e6);
+        fprintf(stderr, "\n");
     }
     if (failed) { set_error("%s", err.empty() ? "worker failed" : err.c_str()); return -1; }
     {

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string.h>
+#include <time.h>
 #include <sys/stat.h>
 #include <string>
 #include <vector>
@@ -13,20 +14,60 @@
 namespace mpn {
 
 hipError_t stream_sync(hipStream_t st) {
-    struct Ev {  // one blocking-sync event per host thread
+    struct Ev {  // one event per host thread
         hipEvent_t e = nullptr;
         ~Ev() { if (e) (void)hipEventDestroy(e); }
     };
     static thread_local Ev ev;
     hipError_t rc;
-    if (!ev.e && (rc = hipEventCreateWithFlags(&ev.e, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return rc;
+    if (!ev.e && (rc = hipEventCreateWithFlags(&ev.e, hipEventDisableTiming)) != hipSuccess) return rc;
     if ((rc = hipEventRecord(ev.e, st)) != hipSuccess) return rc;
-    return hipEventSynchronize(ev.e);
+    // Poll with sleeps instead of hipEventSynchronize: on ROCm 7.2 even a blocking-sync event wait keeps the calling thread
+    // on a core for most of the wait (measured: the 8 workers burnt ~4 CPU-seconds per 0.9 s step waiting for the GPU,
+    // a quarter of the container's CPU quota, which the host phases of the other workers need).
+    unsigned int us = 20;
+    for (;;) {
+        rc = hipEventQuery(ev.e);
+        if (rc != hipErrorNotReady) return rc;
+        timespec ts{0, (long)us * 1000};
+        nanosleep(&ts, nullptr);
+        if (us < 200) us += 20;
+    }
 }
 
 
+// Small device -> host reads go through pinned memory of the calling thread: a copy into pageable memory is synchronous
+// inside the runtime, which waits for the stream with the thread spinning on a core.
+struct PinScratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes) {
+        if (bytes > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+            cap = want;
+        }
+        return p;
+    }
+    ~PinScratch() { if (p) (void)hipHostFree(p); }
+};
+static thread_local PinScratch tl_pin;
+
+static int read_i64(const int64_t *d, int64_t *out, hipStream_t st) {
+    int64_t *s = (int64_t *)tl_pin.get(64);
+    if (!s) { set_error("pinned scratch allocation failed"); return -1; }
+    MPN_HIP_CHECK(hipMemcpyAsync(s, d, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    *out = *s;
+    return 0;
+}
+
 thread_local int64_t g_stats[MPN_NSTATS] = {0};
 PhaseLog g_phase_log;
+bool g_worker_cpu_on = false;
+std::atomic<long long> g_worker_cpu_ns[64];
 thread_local int tl_worker_id = -1;
 
 void pack_2bit(const uint8_t *codes, int64_t n, std::vector<uint32_t> &words, std::vector<int64_t> &ns, std::vector<int64_t> &ne) {
@@ -108,8 +149,7 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, cnt.p, mz_off.p, n);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t total = 0;
-    MPN_HIP_CHECK(hipMemcpyAsync(&total, mz_off.p + n, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(stream_sync(st));
+    if (read_i64(mz_off.p + n, &total, st)) return -1;
     if (mz.alloc((size_t)total)) return -1;
     if (ev) ev->mark(10);
     if (total > 0) {
@@ -163,8 +203,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, n_anchor_d.p, o.anchor_off.p, n);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_a = 0;
-    MPN_HIP_CHECK(hipMemcpyAsync(&n_a, o.anchor_off.p + n, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(stream_sync(st));
+    if (read_i64(o.anchor_off.p + n, &n_a, st)) return -1;
     o.n_anchors = n_a;
     g_stats[2] += n_a;
     DevBuf<u128> tmp;
@@ -249,8 +288,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, piece_kept.p, piece_off.p, (int)n_pieces);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_c = 0;
-    MPN_HIP_CHECK(hipMemcpyAsync(&n_c, o.c_off.p + n, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(stream_sync(st));
+    if (read_i64(o.c_off.p + n, &n_c, st)) return -1;
     g_stats[45] += n_c;
     DevBuf<int32_t> F, P, T, V;
     DevBuf<uint64_t> Utmp;
@@ -298,11 +336,23 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolB
     h.anchor_off.resize((size_t)n + 1);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
     unsigned long long used[2 + WORK_SLOTS] = {0};
-    if (o.anchor_off.download(h.anchor_off.data(), (size_t)n + 1, st) || o.n_chain.download(h.n_chain.data(), n, st) ||
-        o.n_chained.download(h.n_chained.data(), n, st) || o.rep_len.download(h.rep_len.data(), n, st) ||
-        o.u_pos.download(h.u_pos.data(), n, st) || o.b_pos.download(h.b_pos.data(), n, st) || o.used.download(used, 2 + WORK_SLOTS, st))
-        return -1;
-    MPN_HIP_CHECK(stream_sync(st));
+    {   // the per-read tables: one pinned staging block, one wait
+        const size_t N = (size_t)n;
+        const size_t o0 = 0, o1 = o0 + (N + 1) * 8, o2 = o1 + N * 8, o3 = o2 + N * 8, o4 = o3 + N * 8, o5 = o4 + N * 4, o6 = o5 + N * 4,
+                     tot = o6 + sizeof(used);
+        char *pn = (char *)tl_pin.get(tot + 64);
+        if (!pn) { set_error("pinned scratch allocation failed"); return -1; }
+        if (o.anchor_off.download((int64_t *)(pn + o0), N + 1, st) || o.n_chained.download((int64_t *)(pn + o1), N, st) ||
+            o.u_pos.download((int64_t *)(pn + o2), N, st) || o.b_pos.download((int64_t *)(pn + o3), N, st) ||
+            o.n_chain.download((int32_t *)(pn + o4), N, st) || o.rep_len.download((int32_t *)(pn + o5), N, st) ||
+            o.used.download((unsigned long long *)(pn + o6), 2 + WORK_SLOTS, st))
+            return -1;
+        MPN_HIP_CHECK(stream_sync(st));
+        memcpy(h.anchor_off.data(), pn + o0, (N + 1) * 8); memcpy(h.n_chained.data(), pn + o1, N * 8);
+        memcpy(h.u_pos.data(), pn + o2, N * 8); memcpy(h.b_pos.data(), pn + o3, N * 8);
+        memcpy(h.n_chain.data(), pn + o4, N * 4); memcpy(h.rep_len.data(), pn + o5, N * 4);
+        memcpy(used, pn + o6, sizeof(used));
+    }
     for (int k = 0; k < WORK_SLOTS; ++k) g_stats[44] += (int64_t)used[2 + k];
     ++g_stats[32];
     if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;

@@ -2,7 +2,9 @@
 #pragma once
 #include "mpn_common.h"
 
+#include <atomic>
 #include <chrono>
+#include <time.h>
 #include <mutex>
 #include <stdint.h>
 #include <string>
@@ -149,12 +151,23 @@ struct PhaseLog {
 extern PhaseLog g_phase_log;
 extern thread_local int tl_worker_id;
 
+// MPN_DEBUG_CPU=1: thread CPU time of the calling (worker) thread per phase slot, next to the wall time
+extern bool g_worker_cpu_on;
+extern std::atomic<long long> g_worker_cpu_ns[64];
+static inline long long thread_cpu_ns() {
+    timespec t;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t);
+    return t.tv_sec * 1000000000LL + t.tv_nsec;
+}
+
 struct WallTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    long long c0 = g_worker_cpu_on ? thread_cpu_ns() : 0;
     void stop_into(int64_t &acc) {
         auto t1 = std::chrono::steady_clock::now();
         acc += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
         if (g_phase_log.on) g_phase_log.add(tl_worker_id, (int)(&acc - g_stats), t0, t1);
+        if (g_worker_cpu_on) { const long long c1 = thread_cpu_ns(); g_worker_cpu_ns[(&acc - g_stats) & 63] += c1 - c0; c0 = c1; }
         t0 = t1;
     }
 };
