@@ -628,12 +628,6 @@ struct SortLists {           // three work lists in one allocation: [0] <= BITON
     unsigned int cap[3];
 };
 
-__device__ __forceinline__ void push_sort_seg(const SortLists &L, int64_t off, int64_t len) {
-    const int c = len <= BITONIC_SMALL ? 0 : len <= BITONIC_MID ? 1 : 2;
-    const unsigned int w = atomicAdd(&L.count[c], 1u);
-    if (w < L.cap[c]) L.seg[c][w] = SortSeg{off, len};
-}
-
 // 16 waves per workgroup, two workgroups per CU (64 KB of counters each): the loops are bound by the latency of their
 // global loads, so what counts is loads in flight -- resident waves x the 4 independent loads each lane issues per step.
 __global__ __launch_bounds__(MSD_THREADS) void anchor_msd_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst,
