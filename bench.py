@@ -229,18 +229,22 @@ def main():
     # Candidate kernels for the roofline line: device ns from HIP events around each launch (rank 0, per step), launches per
     # step, and ALGORITHMIC bytes per step (DESIGN.md section 5 states the per-unit figures):
     #   sketch (count + fill pass)   : 2 x 1 B per read base in + 16 B per minimizer out
-    #   seed lookup + fill           : 16 B per minimizer in, 8 B per index position gathered, 16 B per anchor out
-    #   anchor partition (MSD)       : 8 B key read for the histogram + 16 B record in + 16 B out per anchor
-    #   anchor window sort           : 16 B in + 16 B out per anchor
-    #   anchor compaction (2 passes) : 2 x 16 B per anchor in + 16 B per kept anchor out
+    #   seed lookup                  : 16 B per minimizer in + 12 B (count, first position) out
+    #   stray-hit filter (2 passes)  : 2 x 8 B per index position gathered + 1 keep bit per position out
+    #   anchor emission              : 8 B per EMITTED position gathered + 16 B per emitted anchor out
+    #   anchor partition (MSD)       : 8 B key read for the histogram + 16 B record in + 16 B out per emitted anchor
+    #   anchor window sort           : 16 B in + 16 B out per emitted anchor
+    #   anchor compaction (2 passes) : 2 x 16 B per emitted anchor in + 16 B per kept anchor out
     #   chain DP                     : 16 B per kept anchor in + 16 B (f, p, t, v) out
     #   strip DP <GL>                : 1 direction byte out per DP cell (qlen x tlen per window)
     cand = {
         'sketch_fast_kernel<count|fill>': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
-        'seed_lookup_kernel+seed_fill_kernel': (st['k_seed_lookup_ns'] + st['k_seed_fill_ns'], 2 * nsub, 16 * st['minimizers'] + 24 * st['anchors']),
-        'anchor_msd_kernel': (st['k_sort_msd_ns'], nsub, 40 * st['anchors']),
-        'anchor_window_sort_kernel': (st['k_sort_chunk_ns'], nsub, 32 * st['anchors']),
-        'anchor_compact_kernel<count|write>': (st['k_compact_ns'], 2 * nsub, 32 * st['anchors'] + 16 * st['anchors_kept']),
+        'seed_lookup_kernel': (st['k_seed_lookup_ns'], nsub, 28 * st['minimizers']),
+        'seed_filter_kernel': (st['k_seed_filter_ns'], nsub, 16 * st['anchors'] + st['anchors'] / 8),
+        'seed_emit_kernel': (st['k_seed_fill_ns'], nsub, 24 * st['anchors_emitted']),
+        'anchor_msd_kernel': (st['k_sort_msd_ns'], nsub, 40 * st['anchors_emitted']),
+        'anchor_window_sort_kernel': (st['k_sort_chunk_ns'], nsub, 32 * st['anchors_emitted']),
+        'anchor_compact_kernel<count|write>': (st['k_compact_ns'], 2 * nsub, 32 * st['anchors_emitted'] + 16 * st['anchors_kept']),
         'chain_dp_kernel': (st['k_chain_dp_ns'], nsub, 32 * st['anchors_kept']),
         'ext_dp_strip_kernel<16>': (st['k_strip16_ns'], rounds, st['strip16_cells']),
         'ext_dp_strip_kernel<32>': (st['k_strip32_ns'], rounds, st['strip32_cells']),

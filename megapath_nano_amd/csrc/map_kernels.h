@@ -353,21 +353,27 @@ __global__ __launch_bounds__(256) void seed_lookup_kernel(const uint64_t *__rest
 // per read (one wave): anchor offsets of its minimizers, anchor total and rep_len (minimap2 collect_matches).
 // rep_len is the length of the union of the query intervals [st, en) of the too-frequent minimizers; their `en` grows
 // with the minimizer index, so an interval adds en - max(st, en of the previous such interval): a max-scan, no loop.
+// span_sum = sum of the seed lengths of ALL the read's anchors (mm_chain_dp's average seed length is taken over every
+// anchor, also over those the stray-hit filter below never materialises); n_blk = 64-minimizer blocks of the read.
 __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int n,
                                                          const int32_t *__restrict__ occ, int64_t *__restrict__ rel_off,
-                                                         int64_t *__restrict__ n_anchor, int32_t *__restrict__ rep_len) {
+                                                         int64_t *__restrict__ n_anchor, int32_t *__restrict__ rep_len,
+                                                         unsigned long long *__restrict__ span_sum, int64_t *__restrict__ n_blk) {
     const int lane = threadIdx.x;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int64_t m0 = mz_off[i], m1 = mz_off[i + 1];
         int64_t run = 0;
         int32_t rl = 0, prev_en = 0;
+        unsigned long long ss = 0;
         for (int64_t c = m0; c < m1; c += 64) {
             const int64_t m = c + lane;
             int32_t t = 0, st = 0, en = 0;
+            uint32_t q_span = 0;
             if (m < m1) {
                 t = occ[m];
+                q_span = mz[m].x & 0xff;
                 if (t < 0) {
-                    const uint32_t q_pos = (uint32_t)mz[m].y, q_span = mz[m].x & 0xff;
+                    const uint32_t q_pos = (uint32_t)mz[m].y;
                     en = (int)(q_pos >> 1) + 1; st = en - (int)q_span;
                 }
             }
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict_
             // exclusive prefix sum of the hit counts of this tile
             int32_t incl = t > 0 ? t : 0;
             const int32_t own = incl;
+            ss += (unsigned long long)own * q_span;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
             if (m < m1) rel_off[m] = run + (incl - own);
@@ -387,67 +394,206 @@ __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict_
             rl += add;
             prev_en = max(prev_en, __builtin_amdgcn_readlane(e_incl, 63));
         }
-        if (lane == 0) { n_anchor[i] = run; rep_len[i] = rl; }
+        for (int d = 32; d; d >>= 1) ss += __shfl_xor(ss, d);
+        if (lane == 0) { n_anchor[i] = run; rep_len[i] = rl; span_sum[i] = ss; n_blk[i] = (m1 - m0 + 63) / 64; }
     }
 }
 
-// Anchor emission as a load-balanced expand: a wave takes 64 consecutive minimizers, whose anchors form ONE contiguous
-// range of the output (the per-read offsets are a global prefix sum), and walks that range 64 output slots at a time.
-// A lane finds the minimizer that owns its slot by a 6-step search over the wave's start offsets (LDS), gathers the
-// index position -- lanes of one minimizer read consecutive words -- and stores its 16-byte anchor: the stores of a
-// wave are one contiguous KB.  (One lane per minimizer writing its own run of anchors cost 3.1 bytes of HBM writes per
-// byte of anchors: every 16-byte store was a partial line.)
-__global__ __launch_bounds__(256) void seed_fill_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int64_t n_mz,
+// ---------------------------------------------------------------------------------------------------------
+// Stray-hit filter.  Against a large target set a read minimizer finds tens of index positions, of which one or two
+// belong to the read's true locus; the rest are isolated hits that cannot chain.  The anchor compaction below drops
+// every SEGMENT (maximal run of a read's sorted anchors on one strand of one target whose consecutive reference gaps
+// are <= max_dist_x) of fewer than min_cnt anchors.  A member of a segment of >= min_cnt anchors has T = min(min_cnt, 3)
+// consecutive members around it that span <= (T-1) * max_dist_x reference bases, so with bins of width W >= 2 (T-1)
+// max_dist_x it shares an "A" bin (pos / W) or a "B" bin ((pos + W/2) / W) with T-1 other anchors of its read.  The filter
+// counts a read's hits per bin WITHOUT materialising the anchors and emits only those whose A or B bin holds >= T hits:
+// a superset of what the compaction keeps, so the chains are identical, while the anchor array, its partition, sort and
+// compaction shrink by an order of magnitude.
+// Counting: one workgroup per read, counters in LDS as count-min sketches (two hash functions per bin family) of
+// saturating 3-level counters -- three bitmaps "seen once / twice / three times", raised by atomicOr (the returned old
+// word tells whether to climb a level).  Collisions only make the filter keep more.
+// The hits are walked like a load-balanced expand: a wave takes 64 consecutive minimizers of its read, whose hits are one
+// contiguous range of virtual slots, four 64-slot windows per step (four independent gathers in flight per lane).
+// Pass 1 counts, pass 2 (after a barrier) gathers again, tests, and leaves one keep word per window + the block's total.
+constexpr int FLT_THREADS = 1024, FLT_WAVES = FLT_THREADS / 64;
+constexpr int FLT_SLOTS = 81920, FLT_WORDS = FLT_SLOTS / 32;      // bits / words per bitmap; 4 tables x 3 levels = 120 KB
+constexpr size_t FLT_LDS_BYTES = (size_t)12 * FLT_WORDS * 4 + (size_t)FLT_WAVES * 64 * 16;
+struct FilterParams { int shift; uint32_t half; int level; };    // bin = pos >> shift; level = T - 1 (bitmap tested)
+
+__device__ __forceinline__ void flt_slots(uint32_t hi, uint32_t bin, uint32_t &s1, uint32_t &s2) {
+    uint32_t k = hi * 0x9E3779B1u ^ (bin + 0x7F4A7C15u) * 0x85EBCA77u;
+    k ^= k >> 15; k *= 0x2C1B3C6Du; k ^= k >> 12;
+    s1 = __umulhi(k, (uint32_t)FLT_SLOTS);
+    uint32_t k2 = k * 0x297A2D39u; k2 ^= k2 >> 15;
+    s2 = __umulhi(k2 * 0x85EBCA6Bu, (uint32_t)FLT_SLOTS);
+}
+__device__ __forceinline__ void flt_add(uint32_t *tab, uint32_t slot) {  // tab: the 3 level bitmaps of one table
+    const uint32_t w = slot >> 5, bit = 1u << (slot & 31);
+    if (atomicOr(&tab[w], bit) & bit)
+        if (atomicOr(&tab[FLT_WORDS + w], bit) & bit) atomicOr(&tab[2 * FLT_WORDS + w], bit);
+}
+__device__ __forceinline__ bool flt_test(const uint32_t *tab, uint32_t slot, int level) {
+    return tab[level * FLT_WORDS + (slot >> 5)] >> (slot & 31) & 1;
+}
+
+// word of the keep bitmap that holds window `it` of block gblk whose first virtual slot is vfirst: blocks are unaligned
+// ranges of the virtual slot space, one extra word per block keeps them disjoint
+__device__ __forceinline__ int64_t flt_word(int64_t vfirst, int64_t gblk, int64_t it) { return (vfirst >> 6) + gblk + it; }
+
+__global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off, int n_reads,
+                                                                  const int32_t *__restrict__ occ, const int64_t *__restrict__ pos_start,
+                                                                  const int64_t *__restrict__ rel_off, const uint64_t *__restrict__ pos,
+                                                                  const int64_t *__restrict__ full_off, const int64_t *__restrict__ blk_base,
+                                                                  FilterParams fp, unsigned long long *__restrict__ keep,
+                                                                  int64_t *__restrict__ blk_kept, int32_t *__restrict__ blk_read) {
+    extern __shared__ uint32_t flt_lds[];
+    uint32_t *bm = flt_lds;                                            // [table A1, A2, B1, B2][level][FLT_WORDS]
+    int64_t *g_all = (int64_t *)(flt_lds + 12 * FLT_WORDS);           // per wave: block-relative first slot of each minimizer
+    int64_t *ps_all = g_all + FLT_WAVES * 64;                          // per wave: index position of its first hit | parity << 62
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int64_t *g = g_all + wv * 64, *ps = ps_all + wv * 64;
+    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+        const int64_t m0 = mz_off[read], m1 = mz_off[read + 1];
+        const int64_t v0 = full_off[read];
+        if (full_off[read + 1] == v0) continue;                        // no hits: its blocks keep blk_kept = 0
+        const int64_t nblk = (m1 - m0 + 63) / 64, gb0 = blk_base[read];
+        for (int k = tid; k < 12 * FLT_WORDS; k += FLT_THREADS) bm[k] = 0;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int64_t b = wv; b < nblk; b += FLT_WAVES) {
+                const int64_t m = m0 + b * 64 + lane;
+                int32_t t = 0;
+                int64_t rel = 0;
+                if (m < m1) {
+                    t = occ[m];
+                    if (t < 0) t = 0;
+                    rel = rel_off[m];
+                    ps[lane] = pos_start[m] | (int64_t)((uint32_t)mz[m].y & 1) << 62;
+                }
+                const int64_t first = __shfl(rel, 0);
+                const int64_t end_own = rel - first + t;
+                int64_t end_all = end_own;
+#pragma unroll
+                for (int d = 32; d; d >>= 1) { const int64_t o = __shfl_xor(end_all, d); end_all = o > end_all ? o : end_all; }
+                g[lane] = m < m1 ? rel - first : end_all;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int64_t vfirst = v0 + first;
+                int64_t kept = 0;
+                for (int64_t p0 = 0, it = 0; p0 < end_all; p0 += 256, it += 4) {
+                    uint64_t r[4];
+                    uint32_t par[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t p = p0 + u * 64 + lane;
+                        r[u] = 0; par[u] = 0;
+                        if (p < end_all) {
+                            int lo = 0, hi = 63;  // last lane whose range starts at or before p
+#pragma unroll
+                            for (int step = 0; step < 6; ++step) {
+                                const int mid = (lo + hi + 1) >> 1;
+                                if (g[mid] <= p) lo = mid; else hi = mid - 1;
+                            }
+                            const int64_t pv = ps[lo];
+                            par[u] = (uint32_t)(pv >> 62) & 1;
+                            r[u] = pos[(pv & 0x3fffffffffffffffLL) + (p - g[lo])];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t p = p0 + u * 64 + lane;
+                        bool keep_it = false;
+                        if (p < end_all) {
+                            const uint32_t hi = (uint32_t)(r[u] >> 32) | (((uint32_t)r[u] & 1) ^ par[u]) << 31;   // strand | target
+                            const uint32_t rpos = (uint32_t)r[u] >> 1;
+                            const uint32_t ba = (uint32_t)((uint64_t)rpos >> fp.shift), bb = (uint32_t)(((uint64_t)rpos + fp.half) >> fp.shift);
+                            uint32_t a1, a2, b1, b2;
+                            flt_slots(hi, ba, a1, a2);
+                            flt_slots(hi ^ 0x5bd1e995u, bb, b1, b2);
+                            if (pass == 0) {
+                                flt_add(bm, a1); flt_add(bm + 3 * FLT_WORDS, a2);
+                                flt_add(bm + 6 * FLT_WORDS, b1); flt_add(bm + 9 * FLT_WORDS, b2);
+                            } else {
+                                keep_it = (flt_test(bm, a1, fp.level) && flt_test(bm + 3 * FLT_WORDS, a2, fp.level)) ||
+                                          (flt_test(bm + 6 * FLT_WORDS, b1, fp.level) && flt_test(bm + 9 * FLT_WORDS, b2, fp.level));
+                            }
+                        }
+                        if (pass == 1 && p0 + u * 64 < end_all) {
+                            const unsigned long long km = __ballot(keep_it);
+                            if (lane == 0) keep[flt_word(vfirst, gb0 + b, it + u)] = km;
+                            kept += __popcll(km);
+                        }
+                    }
+                }
+                if (pass == 1 && lane == 0) { blk_kept[gb0 + b] = kept; blk_read[gb0 + b] = read; }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// anchor offsets per read from the block offsets: the blocks of a read are consecutive
+__global__ __launch_bounds__(256) void seed_read_off_kernel(const int64_t *__restrict__ blk_off, const int64_t *__restrict__ blk_base, int n,
+                                                            int64_t *__restrict__ anchor_off) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n) anchor_off[r] = blk_off[blk_base[r]];
+}
+
+// Emission of the kept hits: one wave per 64-minimizer block; it walks the block's keep words, and a lane whose bit is set
+// finds the owner of its slot, gathers the index position and stores the 16-byte anchor at the block's offset + its rank.
+__global__ __launch_bounds__(256) void seed_emit_kernel(const u128 *__restrict__ mz, const int64_t *__restrict__ mz_off,
                                                         const int32_t *__restrict__ occ, const int64_t *__restrict__ pos_start,
                                                         const int64_t *__restrict__ rel_off, const uint64_t *__restrict__ pos,
-                                                        const int64_t *__restrict__ anchor_off, const int32_t *__restrict__ seq_len,
-                                                        u128 *__restrict__ anchors) {
+                                                        const int64_t *__restrict__ full_off, const int64_t *__restrict__ blk_base, int n_reads,
+                                                        const unsigned long long *__restrict__ keep, const int64_t *__restrict__ blk_kept,
+                                                        const int64_t *__restrict__ blk_off, const int32_t *__restrict__ blk_read,
+                                                        const int32_t *__restrict__ seq_len, u128 *__restrict__ anchors) {
     __shared__ int64_t s_g[4][64], s_ps[4][64];
-    __shared__ uint64_t s_y[4][64];   // flags | span << 32 | query position (forward strand), qlen in s_q
-    __shared__ int32_t s_q[4][64];
+    __shared__ uint64_t s_y[4][64];   // flags | span << 32 | query position (forward strand)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int64_t *g = s_g[wv], *ps = s_ps[wv];
     uint64_t *yy = s_y[wv];
-    int32_t *qq = s_q[wv];
-    const int64_t n_blocks = (n_mz + 63) / 64;
-    for (int64_t blk = (int64_t)blockIdx.x * 4 + wv; blk < n_blocks; blk += (int64_t)gridDim.x * 4) {
-        const int64_t m = blk * 64 + lane;
+    const int64_t n_blocks = blk_base[n_reads];
+    for (int64_t gblk = (int64_t)blockIdx.x * 4 + wv; gblk < n_blocks; gblk += (int64_t)gridDim.x * 4) {
+        if (blk_kept[gblk] == 0) continue;
+        const int read = blk_read[gblk];
+        const int64_t m0 = mz_off[read], m1 = mz_off[read + 1];
+        const int64_t m = m0 + (gblk - blk_base[read]) * 64 + lane;
+        const int32_t qlen = seq_len[read];
         int32_t t = 0;
-        int64_t g0 = 0;
-        if (m < n_mz) {
+        int64_t rel = 0;
+        if (m < m1) {
             t = occ[m];
             if (t < 0) t = 0;
             const uint64_t mx = mz[m].x, my = mz[m].y;
-            const int read = (int)(my >> 32);
             bool tandem = false;
-            if (m > mz_off[read] && mz[m - 1].x >> 8 == mx >> 8) tandem = true;
-            if (m + 1 < mz_off[read + 1] && mz[m + 1].x >> 8 == mx >> 8) tandem = true;
-            g0 = anchor_off[read] + rel_off[m];
+            if (m > m0 && mz[m - 1].x >> 8 == mx >> 8) tandem = true;
+            if (m + 1 < m1 && mz[m + 1].x >> 8 == mx >> 8) tandem = true;
+            rel = rel_off[m];
             ps[lane] = pos_start[m];
-            // query side of the anchor: span, position + strand bit of the minimizer, the tandem flag
             yy[lane] = (tandem ? 1ULL << 42 : 0ULL) | (uint64_t)(mx & 0xff) << 32 | (uint32_t)my;
-            qq[lane] = seq_len[read];
         }
-        // lanes past the end of the list continue the last real offset so that the search never lands on them
-        const int64_t end_own = g0 + t;
-        int64_t end_all = end_own;
+        const int64_t first = __shfl(rel, 0);
+        int64_t end_all = rel - first + t;
 #pragma unroll
         for (int d = 32; d; d >>= 1) { const int64_t o = __shfl_xor(end_all, d); end_all = o > end_all ? o : end_all; }
-        g[lane] = m < n_mz ? g0 : end_all;
-        const int64_t first = __shfl(g0, 0);
+        g[lane] = m < m1 ? rel - first : end_all;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (int64_t p0 = first; p0 < end_all; p0 += 64) {
-            const int64_t p = p0 + lane;
-            if (p < end_all) {
-                int lo = 0, hi = 63;  // last lane whose range starts at or before p
+        const int64_t vfirst = full_off[read] + first;
+        int64_t out = blk_off[gblk];
+        for (int64_t p0 = 0, it = 0; p0 < end_all; p0 += 64, ++it) {
+            const unsigned long long km = keep[flt_word(vfirst, gblk, it)];
+            if (km >> lane & 1) {
+                const int64_t p = p0 + lane;
+                int lo = 0, hi = 63;
 #pragma unroll
                 for (int step = 0; step < 6; ++step) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (g[mid] <= p) lo = mid; else hi = mid - 1;
                 }
-                const int64_t k = p - g[lo];
-                const uint64_t r = pos[ps[lo] + k];
+                const uint64_t r = pos[ps[lo] + (p - g[lo])];
                 const uint64_t y = yy[lo];
                 const uint32_t q_pos = (uint32_t)y, q_span = (uint32_t)(y >> 32) & 0xff;
                 const uint32_t rpos = (uint32_t)r >> 1;
@@ -457,11 +603,12 @@ __global__ __launch_bounds__(256) void seed_fill_kernel(const u128 *__restrict__
                     a.y = (uint64_t)q_span << 32 | q_pos >> 1;
                 } else {
                     a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
-                    a.y = (uint64_t)q_span << 32 | (uint32_t)(qq[lo] - ((int32_t)(q_pos >> 1) + 1 - (int32_t)q_span) - 1);
+                    a.y = (uint64_t)q_span << 32 | (uint32_t)(qlen - ((int32_t)(q_pos >> 1) + 1 - (int32_t)q_span) - 1);
                 }
                 a.y |= y & (1ULL << 42);
-                anchors[p] = a;
+                anchors[out + __popcll(km & ((1ULL << lane) - 1))] = a;
             }
+            out += __popcll(km);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -877,15 +1024,13 @@ struct ChainSeg { int32_t read, start, end; };
 // The batch's anchor array is cut into pieces of COMPACT_PIECE anchors regardless of read boundaries; one wave per piece.
 // Start-of-segment flags of the current and the next 64-anchor tile (a read's first anchor always starts a segment) give
 // every anchor the saturated distances to its segment's start and end.
-// WRITE = false: piece_kept[piece]; per read (atomics): anchors kept and the sum of the seed lengths of ALL its anchors
-//                (mm_chain_dp's average uses every anchor).   WRITE = true: kept anchors -> out, in order.
+// WRITE = false: piece_kept[piece]; per read (atomics): anchors kept.   WRITE = true: kept anchors -> out, in order.
 constexpr int COMPACT_PIECE = 4096;
 
 template <bool WRITE>
 __global__ __launch_bounds__(64) void anchor_compact_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
                                                             int n_reads, int64_t n_a, int max_dist_x, int min_cnt,
                                                             int64_t *__restrict__ piece_kept, unsigned long long *__restrict__ read_kept,
-                                                            unsigned long long *__restrict__ read_span,
                                                             const int64_t *__restrict__ piece_off, u128 *__restrict__ out) {
     const int lane = threadIdx.x;
     const int K = min_cnt < 64 ? (min_cnt > 1 ? min_cnt : 1) : 64;
@@ -923,7 +1068,7 @@ __global__ __launch_bounds__(64) void anchor_compact_kernel(const u128 *__restri
         load(g0, cur, s_cur, r_cur, rb_cur, re_cur);
         int64_t run = 0;
         int acc_r = -1;                                         // count pass: totals of the read the wave is inside (uniform)
-        unsigned long long acc_k = 0, acc_s = 0;
+        unsigned long long acc_k = 0;
         for (int64_t t0 = g0; t0 < g1; t0 += 64) {
             const bool has_next = t0 + 64 < n_a;
             r_nxt = r_cur; rb_nxt = rb_cur; re_nxt = re_cur;
@@ -947,41 +1092,38 @@ __global__ __launch_bounds__(64) void anchor_compact_kernel(const u128 *__restri
             if (WRITE) {
                 if (keep) out[piece_off[piece] + run + __popcll(km & ((1ULL << lane) - 1))] = cur;
             } else {
-                const unsigned long long span = act ? (cur.y >> 32 & 0xff) : 0ULL;
                 const int r_first = __builtin_amdgcn_readfirstlane(r_cur);  // (lane 0 is active: t0 < g1)
                 const bool uniform = __ballot(act && r_cur != r_first) == 0;
-                if (!uniform || r_first != acc_r) {  // leaving the read the totals belong to: flush them (one atomic pair per run)
-                    if (lane == 0 && acc_r >= 0) { if (acc_k) atomicAdd(&read_kept[acc_r], acc_k); atomicAdd(&read_span[acc_r], acc_s); }
-                    acc_r = -1; acc_k = 0; acc_s = 0;
+                if (!uniform || r_first != acc_r) {  // leaving the read the total belongs to: flush it (one atomic per run)
+                    if (lane == 0 && acc_r >= 0 && acc_k) atomicAdd(&read_kept[acc_r], acc_k);
+                    acc_r = -1; acc_k = 0;
                 }
                 if (uniform) {
-                    unsigned long long ssum = span;
-                    for (int d = 32; d; d >>= 1) ssum += __shfl_xor(ssum, d);
-                    acc_r = r_first; acc_k += (unsigned long long)__popcll(km); acc_s += ssum;
-                } else if (act) {
-                    if (keep) atomicAdd(&read_kept[r_cur], 1ULL);
-                    atomicAdd(&read_span[r_cur], span);
+                    acc_r = r_first; acc_k += (unsigned long long)__popcll(km);
+                } else if (act && keep) {
+                    atomicAdd(&read_kept[r_cur], 1ULL);
                 }
             }
             run += __popcll(km);
             since = m_cur ? 64 - (63 - __builtin_clzll(m_cur)) : since + 64;
             cur = nxt; s_cur = s_nxt; r_cur = r_nxt; rb_cur = rb_nxt; re_cur = re_nxt;
         }
-        if (!WRITE && lane == 0 && acc_r >= 0) { if (acc_k) atomicAdd(&read_kept[acc_r], acc_k); atomicAdd(&read_span[acc_r], acc_s); }
+        if (!WRITE && lane == 0 && acc_r >= 0 && acc_k) atomicAdd(&read_kept[acc_r], acc_k);
         if (!WRITE && lane == 0) piece_kept[piece] = run;
     }
 }
 
-// per read: kept anchors as int64 (input of the offset scan) and the average seed length over all its anchors
-__global__ __launch_bounds__(256) void anchor_compact_finish_kernel(const int64_t *__restrict__ anchor_off, int n_reads,
+// per read: kept anchors as int64 (input of the offset scan) and the average seed length over ALL its anchors (n_full
+// hits, seed lengths summed by seed_prefix_kernel: mm_chain_dp's average uses every anchor)
+__global__ __launch_bounds__(256) void anchor_compact_finish_kernel(const int64_t *__restrict__ n_full, int n_reads,
                                                                     const unsigned long long *__restrict__ read_kept,
-                                                                    const unsigned long long *__restrict__ read_span,
+                                                                    const unsigned long long *__restrict__ span_sum,
                                                                     int64_t *__restrict__ kept, float *__restrict__ avg_qspan) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    const int64_t n = anchor_off[r + 1] - anchor_off[r];
+    const int64_t n = n_full[r];
     kept[r] = (int64_t)read_kept[r];
-    avg_qspan[r] = n > 0 ? (float)read_span[r] / (float)n : 0.f;
+    avg_qspan[r] = n > 0 ? (float)span_sum[r] / (float)n : 0.f;
 }
 
 __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,

@@ -187,9 +187,10 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     g_stats[1] += n_mz;
     const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
     DevBuf<int32_t> occ;
-    DevBuf<int64_t> pos_start, rel_off, n_anchor_d;
-    if (occ.alloc(n_mz) || pos_start.alloc(n_mz) || rel_off.alloc(n_mz) || n_anchor_d.alloc((size_t)n + 1) ||
-        o.rep_len.alloc(n) || o.anchor_off.alloc((size_t)n + 1))
+    DevBuf<int64_t> pos_start, rel_off, full_off, n_blk, blk_base;
+    DevBuf<unsigned long long> span_sum;
+    if (occ.alloc(n_mz) || pos_start.alloc(n_mz) || rel_off.alloc(n_mz) || o.n_anchor.alloc((size_t)n + 1) || full_off.alloc((size_t)n + 1) ||
+        n_blk.alloc((size_t)n + 1) || blk_base.alloc((size_t)n + 1) || span_sum.alloc(n) || o.rep_len.alloc(n) || o.anchor_off.alloc((size_t)n + 1))
         return -1;
     if (n_mz > 0) {
         hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p,
@@ -198,24 +199,61 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         ev.mark(11, 35);
     }
     hipLaunchKernelGGL(seed_prefix_kernel, dim3(std::max(1, std::min(n, 256 * 32))), dim3(64), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
-                       n_anchor_d.p, o.rep_len.p);
+                       o.n_anchor.p, o.rep_len.p, span_sum.p, n_blk.p);
     MPN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, n_anchor_d.p, o.anchor_off.p, n);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, o.n_anchor.p, full_off.p, n);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, n_blk.p, blk_base.p, n);
+    MPN_HIP_CHECK(hipGetLastError());
+    int64_t n_full = 0;  // hits of the batch's minimizers; only those that pass the stray-hit filter become anchors
+    if (read_i64(full_off.p + n, &n_full, st)) return -1;
+    g_stats[2] += n_full;
+    // stray-hit filter: keep words over the virtual hit slots + per-block totals, then the kept hits' offsets
+    const int64_t nb_cap = n_mz / 64 + n + 1;
+    DevBuf<unsigned long long> keep;
+    DevBuf<int64_t> blk_kept, blk_off;
+    DevBuf<int32_t> blk_read;
+    if (keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
+        blk_read.alloc((size_t)nb_cap + 1) || blk_kept.zero(st))
+        return -1;
+    if (nb_cap > 0x7fffffff) { set_error("sub-batch too large for the seed filter"); return -1; }
+    if (n_full > 0) {
+        FilterParams fp;
+        {
+            const int T = std::max(1, std::min(opt->min_cnt, 3));
+            const int64_t need = 2 * (int64_t)(T - 1) * std::max(opt->max_gap, 1);
+            int sh = 1;
+            while (sh < 32 && ((int64_t)1 << sh) < need) ++sh;
+            fp.shift = sh; fp.half = (uint32_t)((uint64_t)1 << (sh - 1)); fp.level = T - 1;
+        }
+        static std::once_flag flt_attr;
+        std::call_once(flt_attr, [&]() {
+            (void)hipFuncSetAttribute((const void *)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLT_LDS_BYTES);
+        });
+        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
+                           pos_start.p, rel_off.p, idx->pos.p, (const int64_t *)full_off.p, (const int64_t *)blk_base.p, fp, keep.p, blk_kept.p,
+                           blk_read.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(11, 50);
+    }
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, blk_kept.p, blk_off.p, (int)nb_cap);
+    hipLaunchKernelGGL(seed_read_off_kernel, dim3((n + 256) / 256), dim3(256), 0, st, (const int64_t *)blk_off.p, (const int64_t *)blk_base.p, n,
+                       o.anchor_off.p);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_a = 0;
     if (read_i64(o.anchor_off.p + n, &n_a, st)) return -1;
     o.n_anchors = n_a;
-    g_stats[2] += n_a;
+    g_stats[51] += n_a;
     DevBuf<u128> tmp;
     if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
         o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(2 + WORK_SLOTS) || o.used.zero(st))
         return -1;
     ev.mark(11);
     if (n_a > 0) {
-        // anchors in (minimizer, hit) order -> tmp; partition per read on the top key bits -> o.anchors; small buckets are
+        // kept hits in (minimizer, hit) order -> tmp; partition per read on the top key bits -> o.anchors; small buckets are
         // sorted in LDS, the large ones (true loci) by radix passes with tmp as the bounce buffer
-        hipLaunchKernelGGL(seed_fill_kernel, dim3(grid_1d((n_mz + 63) / 64, 4, 256 * 64)), dim3(256), 0, st, mz.p, mz_off.p, n_mz, occ.p,
-                           pos_start.p, rel_off.p, idx->pos.p, o.anchor_off.p, d_len, tmp.p);
+        hipLaunchKernelGGL(seed_emit_kernel, dim3(grid_1d(nb_cap, 4, 256 * 64)), dim3(256), 0, st, mz.p, mz_off.p, occ.p, pos_start.p, rel_off.p,
+                           idx->pos.p, (const int64_t *)full_off.p, (const int64_t *)blk_base.p, n, (const unsigned long long *)keep.p,
+                           (const int64_t *)blk_kept.p, (const int64_t *)blk_off.p, (const int32_t *)blk_read.p, d_len, tmp.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(11, 36);
         BinParams bp;
@@ -271,19 +309,19 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     // anchors of segments too short to chain are dropped; everything below runs on the compact list (c_off, tmp)
     const int64_t n_pieces = (n_a + COMPACT_PIECE - 1) / COMPACT_PIECE;
     DevBuf<int64_t> kept, piece_kept, piece_off;
-    DevBuf<unsigned long long> read_kept, read_span;
+    DevBuf<unsigned long long> read_kept;
     DevBuf<float> avg_qspan;
     if (kept.alloc((size_t)n + 1) || o.c_off.alloc((size_t)n + 1) || avg_qspan.alloc(n) || piece_kept.alloc((size_t)n_pieces + 1) ||
-        piece_off.alloc((size_t)n_pieces + 1) || read_kept.alloc(n) || read_span.alloc(n) || read_kept.zero(st) || read_span.zero(st))
+        piece_off.alloc((size_t)n_pieces + 1) || read_kept.alloc(n) || read_kept.zero(st))
         return -1;
     const int gp = (int)std::max<int64_t>(1, std::min<int64_t>(n_pieces, 256 * 64));
     if (n_a > 0) {
         hipLaunchKernelGGL(anchor_compact_kernel<false>, dim3(gp), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n, n_a,
-                           cp.max_dist_x, cp.min_cnt, piece_kept.p, read_kept.p, read_span.p, (const int64_t *)nullptr, (u128 *)nullptr);
+                           cp.max_dist_x, cp.min_cnt, piece_kept.p, read_kept.p, (const int64_t *)nullptr, (u128 *)nullptr);
         MPN_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(anchor_compact_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)o.anchor_off.p, n,
-                       (const unsigned long long *)read_kept.p, (const unsigned long long *)read_span.p, kept.p, avg_qspan.p);
+    hipLaunchKernelGGL(anchor_compact_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)o.n_anchor.p, n,
+                       (const unsigned long long *)read_kept.p, (const unsigned long long *)span_sum.p, kept.p, avg_qspan.p);
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, kept.p, o.c_off.p, n);
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, piece_kept.p, piece_off.p, (int)n_pieces);
     MPN_HIP_CHECK(hipGetLastError());
@@ -296,8 +334,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     u128 *ca = tmp.p;  // the sort's bounce buffer is free now: it receives the compact anchors
     if (n_a > 0) {
         hipLaunchKernelGGL(anchor_compact_kernel<true>, dim3(gp), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n, n_a,
-                           cp.max_dist_x, cp.min_cnt, (int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                           (const int64_t *)piece_off.p, ca);
+                           cp.max_dist_x, cp.min_cnt, (int64_t *)nullptr, (unsigned long long *)nullptr, (const int64_t *)piece_off.p, ca);
         MPN_HIP_CHECK(hipGetLastError());
     }
     ev.mark(46);
@@ -333,7 +370,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
 
 // download the compact chain pools of a batch (pinned staging owned by the caller) and the per-read tables
 int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st) {
-    h.anchor_off.resize((size_t)n + 1);
+    h.n_anchor.resize((size_t)n);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
     unsigned long long used[2 + WORK_SLOTS] = {0};
     {   // the per-read tables: one pinned staging block, one wait
@@ -342,13 +379,13 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolB
                      tot = o6 + sizeof(used);
         char *pn = (char *)tl_pin.get(tot + 64);
         if (!pn) { set_error("pinned scratch allocation failed"); return -1; }
-        if (o.anchor_off.download((int64_t *)(pn + o0), N + 1, st) || o.n_chained.download((int64_t *)(pn + o1), N, st) ||
+        if (o.n_anchor.download((int64_t *)(pn + o0), N, st) || o.n_chained.download((int64_t *)(pn + o1), N, st) ||
             o.u_pos.download((int64_t *)(pn + o2), N, st) || o.b_pos.download((int64_t *)(pn + o3), N, st) ||
             o.n_chain.download((int32_t *)(pn + o4), N, st) || o.rep_len.download((int32_t *)(pn + o5), N, st) ||
             o.used.download((unsigned long long *)(pn + o6), 2 + WORK_SLOTS, st))
             return -1;
         MPN_HIP_CHECK(stream_sync(st));
-        memcpy(h.anchor_off.data(), pn + o0, (N + 1) * 8); memcpy(h.n_chained.data(), pn + o1, N * 8);
+        memcpy(h.n_anchor.data(), pn + o0, N * 8); memcpy(h.n_chained.data(), pn + o1, N * 8);
         memcpy(h.u_pos.data(), pn + o2, N * 8); memcpy(h.b_pos.data(), pn + o3, N * 8);
         memcpy(h.n_chain.data(), pn + o4, N * 4); memcpy(h.rep_len.data(), pn + o5, N * 4);
         memcpy(used, pn + o6, sizeof(used));
@@ -788,7 +825,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     PoolBuf pin_u{nullptr, 0, true}, pin_b{nullptr, 0, true};
     struct Free { PoolBuf &a, &b; ~Free() { a.release(); b.release(); } } free_pins{pin_u, pin_b};
     if (download_chains(n, o, h, pin_u, pin_b, st)) return -1;
-    for (int i = 0; i < n; ++i) { n_anchor[i] = h.anchor_off[i + 1] - h.anchor_off[i]; rep_len[i] = h.rep_len[i]; }
+    for (int i = 0; i < n; ++i) { n_anchor[i] = h.n_anchor[i]; rep_len[i] = h.rep_len[i]; }
     memcpy(chain_off, h.chain_off.data(), ((size_t)n + 1) * 8);
     memcpy(anchor_off, h.b_off.data(), ((size_t)n + 1) * 8);
     if (h.chain_off[n] > u_cap || h.b_off[n] > b_cap) return -3;

@@ -54,7 +54,8 @@ struct u128;
 
 struct SeedChainOut {
     int64_t n_anchors = 0;
-    DevBuf<int64_t> anchor_off, c_off, n_chained, u_pos, b_pos;  // c_off: CSR of the anchors kept for chaining
+    DevBuf<int64_t> n_anchor;                                    // per read: index hits of its minimizers (what minimap2 calls n_a)
+    DevBuf<int64_t> anchor_off, c_off, n_chained, u_pos, b_pos;  // anchor_off: CSR of the hits that passed the stray-hit filter; c_off: of those kept for chaining
     DevBuf<int32_t> rep_len, n_ends, n_chain;
     DevBuf<u128> anchors, chained;
     DevBuf<uint64_t> u, u_compact;
@@ -62,7 +63,7 @@ struct SeedChainOut {
 };
 
 struct HostChains {
-    std::vector<int64_t> anchor_off, chain_off, b_off;  // per read: anchors found; prefix sums of chains and of chained anchors
+    std::vector<int64_t> n_anchor, chain_off, b_off;    // per read: anchors found; prefix sums of chains and of chained anchors
     std::vector<int64_t> n_chained, u_pos, b_pos;       // per read: chained anchors; start in the compact pools
     std::vector<int32_t> n_chain, rep_len;
     const uint64_t *u_all = nullptr;                    // compact pools as downloaded (caller-owned pinned memory)
