@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict_
 // Pass 1 counts, pass 2 (after a barrier) gathers again, tests, and leaves one keep word per window + the block's total.
 constexpr int FLT_THREADS = 1024, FLT_WAVES = FLT_THREADS / 64;
 constexpr int FLT_SLOTS = 81920, FLT_WORDS = FLT_SLOTS / 32;      // bits / words per bitmap; 4 tables x 3 levels = 120 KB
-constexpr size_t FLT_LDS_BYTES = (size_t)12 * FLT_WORDS * 4 + (size_t)FLT_WAVES * 64 * 16;
+constexpr size_t FLT_LDS_BYTES = (size_t)12 * FLT_WORDS * 4 + (size_t)FLT_WAVES * 64 * 16 + 16;
 struct FilterParams { int shift; uint32_t half; int level; };    // bin = pos >> shift; level = T - 1 (bitmap tested)
 
 __device__ __forceinline__ void flt_slots(uint32_t hi, uint32_t bin, uint32_t &s1, uint32_t &s2) {
@@ -444,23 +444,31 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                                                                   const int32_t *__restrict__ occ, const int64_t *__restrict__ pos_start,
                                                                   const int64_t *__restrict__ rel_off, const uint64_t *__restrict__ pos,
                                                                   const int64_t *__restrict__ full_off, const int64_t *__restrict__ blk_base,
-                                                                  FilterParams fp, unsigned long long *__restrict__ keep,
+                                                                  const int32_t *__restrict__ order, FilterParams fp,
+                                                                  unsigned long long *__restrict__ keep,
                                                                   int64_t *__restrict__ blk_kept, int32_t *__restrict__ blk_read) {
     extern __shared__ uint32_t flt_lds[];
     uint32_t *bm = flt_lds;                                            // [table A1, A2, B1, B2][level][FLT_WORDS]
     int64_t *g_all = (int64_t *)(flt_lds + 12 * FLT_WORDS);           // per wave: block-relative first slot of each minimizer
     int64_t *ps_all = g_all + FLT_WAVES * 64;                          // per wave: index position of its first hit | parity << 62
+    uint32_t *next_blk = (uint32_t *)(ps_all + FLT_WAVES * 64);        // [2]: the block queue of each pass
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int64_t *g = g_all + wv * 64, *ps = ps_all + wv * 64;
-    for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
+    for (int ri = blockIdx.x; ri < n_reads; ri += gridDim.x) {
+        const int read = order[ri];                                    // reads with many hits first (the grid's long pole)
         const int64_t m0 = mz_off[read], m1 = mz_off[read + 1];
         const int64_t v0 = full_off[read];
         if (full_off[read + 1] == v0) continue;                        // no hits: its blocks keep blk_kept = 0
         const int64_t nblk = (m1 - m0 + 63) / 64, gb0 = blk_base[read];
         for (int k = tid; k < 12 * FLT_WORDS; k += FLT_THREADS) bm[k] = 0;
+        if (tid < 2) next_blk[tid] = 0;
         __syncthreads();
         for (int pass = 0; pass < 2; ++pass) {
-            for (int64_t b = wv; b < nblk; b += FLT_WAVES) {
+            for (;;) {  // the waves take the read's blocks from a queue: the blocks differ in their hit counts
+                uint32_t bq = 0;
+                if (lane == 0) bq = atomicAdd(&next_blk[pass], 1u);
+                const int64_t b = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)bq);
+                if (b >= nblk) break;
                 const int64_t m = m0 + b * 64 + lane;
                 int32_t t = 0;
                 int64_t rel = 0;
@@ -531,6 +539,19 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
             __syncthreads();
         }
     }
+}
+
+// processing order of the filter's workgroups: reads by decreasing hit count, in classes of a factor of two (one workgroup)
+__global__ __launch_bounds__(1024) void seed_order_kernel(const int64_t *__restrict__ n_anchor, int n, int32_t *__restrict__ order) {
+    __shared__ uint32_t cnt[64], cur[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) cnt[tid] = 0;
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) atomicAdd(&cnt[__clzll((unsigned long long)n_anchor[r] + 1)], 1u);  // class 0 = the largest
+    __syncthreads();
+    if (tid == 0) { uint32_t run = 0; for (int c = 0; c < 64; ++c) { cur[c] = run; run += cnt[c]; } }
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) order[atomicAdd(&cur[__clzll((unsigned long long)n_anchor[r] + 1)], 1u)] = r;
 }
 
 // anchor offsets per read from the block offsets: the blocks of a read are consecutive

@@ -211,8 +211,8 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     const int64_t nb_cap = n_mz / 64 + n + 1;
     DevBuf<unsigned long long> keep;
     DevBuf<int64_t> blk_kept, blk_off;
-    DevBuf<int32_t> blk_read;
-    if (keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
+    DevBuf<int32_t> blk_read, order;
+    if (order.alloc(n) || keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
         blk_read.alloc((size_t)nb_cap + 1) || blk_kept.zero(st))
         return -1;
     if (nb_cap > 0x7fffffff) { set_error("sub-batch too large for the seed filter"); return -1; }
@@ -229,9 +229,10 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         std::call_once(flt_attr, [&]() {
             (void)hipFuncSetAttribute((const void *)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLT_LDS_BYTES);
         });
-        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, 256 * 8))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
-                           pos_start.p, rel_off.p, idx->pos.p, (const int64_t *)full_off.p, (const int64_t *)blk_base.p, fp, keep.p, blk_kept.p,
-                           blk_read.p);
+        hipLaunchKernelGGL(seed_order_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)o.n_anchor.p, n, order.p);
+        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, 1 << 20))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
+                           pos_start.p, rel_off.p, idx->pos.p, (const int64_t *)full_off.p, (const int64_t *)blk_base.p, (const int32_t *)order.p,
+                           fp, keep.p, blk_kept.p, blk_read.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(11, 50);
     }
