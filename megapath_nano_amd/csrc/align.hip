@@ -36,6 +36,8 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolB
 
 const char *get_error();
 
+static bool g_cpu_on = false;                 // MPN_DEBUG_CPU=1: thread CPU time of every parallel region, by tag
+static std::atomic<long long> g_cpu_ns[32];
 static const int PARENT_UNSET = -1, PARENT_TMP_PRI = -2;
 static const uint64_t SEED_LONG_JOIN = 1ULL << 40, SEED_IGNORE = 1ULL << 41, SEED_TANDEM = 1ULL << 42;
 
@@ -599,12 +601,39 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
         const uint32_t op = r.cigar[k] & 0xf, len = r.cigar[k] >> 4;
         if (op == 0) {
             int n_ambi = 0, n_diff = 0;
-            for (uint32_t l = 0; l < len; ++l) {
-                const int cq = qseq[qoff + l], ct = tseq[toff + l];
-                if (ct > 3 || cq > 3) ++n_ambi;
-                else if (ct != cq) ++n_diff;
-                s += mat[ct * 5 + cq];
-                if (s < 0) s = 0; else max = max > s ? max : s;
+            const uint8_t *qp = qseq + qoff, *tp = tseq + toff;
+            if (mat[0] > 0) {
+                // Eight columns at a time (both sequences are padded by 8 bytes): the columns that are not plain matches are the
+                // non-zero bytes of a word; between them the score only rises (s >= 0 holds after every column), so a run's
+                // last column carries its maximum -- same s and max as column by column.  ONT alignments are runs of ~12
+                // columns between gaps, most of them without a mismatch: one word compare per run instead of a loop.
+                for (uint32_t l = 0; l < len; l += 8) {
+                    const uint32_t c = len - l < 8 ? len - l : 8;
+                    uint64_t a, b;
+                    memcpy(&a, qp + l, 8); memcpy(&b, tp + l, 8);
+                    uint64_t ev = (a ^ b) | ((a | b) & 0xFCFCFCFCFCFCFCFCULL);
+                    if (c < 8) ev &= (1ULL << (8 * c)) - 1;
+                    uint32_t done = 0;
+                    while (ev) {
+                        const uint32_t p = (uint32_t)__builtin_ctzll(ev) >> 3;
+                        if (p > done) { s += (int32_t)(p - done) * mat[0]; max = max > s ? max : s; }
+                        const int cq = qp[l + p], ct = tp[l + p];
+                        if (ct > 3 || cq > 3) ++n_ambi; else ++n_diff;
+                        s += mat[ct * 5 + cq];
+                        if (s < 0) s = 0; else max = max > s ? max : s;
+                        done = p + 1;
+                        ev &= ~(0xFFULL << (8 * p));
+                    }
+                    if (c > done) { s += (int32_t)(c - done) * mat[0]; max = max > s ? max : s; }
+                }
+            } else {
+                for (uint32_t l = 0; l < len; ++l) {
+                    const int cq = qp[l], ct = tp[l];
+                    if (ct > 3 || cq > 3) ++n_ambi;
+                    else if (ct != cq) ++n_diff;
+                    s += mat[ct * 5 + cq];
+                    if (s < 0) s = 0; else max = max > s ? max : s;
+                }
             }
             r.blen += len - n_ambi; r.mlen += len - (n_ambi + n_diff); r.n_ambi += n_ambi;
             toff += len; qoff += len;
@@ -627,6 +656,14 @@ static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const
     r.dp_max = max;
 }
 
+// MPN_DEBUG_CPU: thread CPU time of the sections of a host phase (g_cpu_ns[16 + k])
+struct CpuSect {
+    timespec t;
+    bool on;
+    explicit CpuSect(bool o) : on(o) { if (on) clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); }
+    void lap(int k);
+};
+
 // returns true if a split remainder was produced in r2
 static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, const uint8_t *qseq_strand[2], Reg &r, Reg &r2,
                          const u128 *a, const Plan &pl, const ExtRes *res, const ExtJob *jobs,
@@ -643,6 +680,7 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
         return cig_pool + e.cig_pos;
     };
     bool has_r2 = false;
+    CpuSect sect(g_cpu_on);
     int32_t rs = pl.rs, qs = pl.qs, rs1, qs1, re1, qe1, dropped = 0;
     r2.cnt = 0;
     if (qs > 0 && rs > 0) {
@@ -701,11 +739,14 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
     r.rs = rs1; r.re = re1;
     if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; }
     else { r.qs = qs1; r.qe = qe1; }
+    sect.lap(0);
     if (r.has_p) {
         static thread_local std::vector<uint8_t> tbuf;  // target codes of the aligned interval
-        tbuf.resize((size_t)std::max(0, re1 - rs1) + 1);
+        tbuf.resize((size_t)std::max(0, re1 - rs1) + 8);  // (update_extra reads whole 8-byte words)
         mi->fetch_codes(mi->seq_off[rid] + rs1, re1 - rs1, tbuf.data());
+        sect.lap(1);
         update_extra(r, qseq_strand[rev] + qs1, tbuf.data(), mat, (int8_t)opt->q, (int8_t)opt->e);
+        sect.lap(2);
     }
     r.aligned = 1;
     return has_r2;
@@ -717,8 +758,13 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
 // through its burst while the threads of the workers that wait on the GPU sleep.  Every burst is a job in one queue and
 // every idle pool thread helps the oldest open job; the posting thread works on its own job too, so a job always
 // advances.  fn(i, slot): slot < max_par identifies the helping thread (per-thread accumulators of the caller).
-static bool g_cpu_on = false;                 // MPN_DEBUG_CPU=1: thread CPU time of every parallel region, by tag
-static std::atomic<long long> g_cpu_ns[32];
+void CpuSect::lap(int k) {
+    if (!on) return;
+    timespec b;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b);
+    g_cpu_ns[16 + k] += (b.tv_sec - t.tv_sec) * 1000000000LL + (b.tv_nsec - t.tv_nsec);
+    t = b;
+}
 class HostPool {
     struct Job {
         const std::function<void(int, int)> *fn;
@@ -1393,9 +1439,11 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         const int nc = h.n_chain[i];
         if (nc == 0) return;
         const int qlen = seq_len[i];
+        CpuSect sect(g_cpu_on);
         std::vector<uint64_t> u_loc(nc);
         S.a.resize((size_t)h.n_chained[i]);
         h.read_chains(i, u_loc.data(), S.a.data());
+        sect.lap(3);
         uint32_t hash = names && names[lo + i] ? x31_hash(names[lo + i]) : 0;
         hash ^= wang32((uint32_t)qlen) + wang32(opt->seed);
         hash = wang32(hash);
@@ -1403,13 +1451,24 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
         select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
         join_long(opt, qlen, S.regs, S.a.data());
+        sect.lap(4);
         if (opt->with_cigar) {
             S.n_a = squeeze_a(S.regs, S.a.data());
+            sect.lap(5);
             const char *s = seqs + seq_off[i];
-            S.q4[0].resize(qlen); S.q4[1].resize(qlen);
+            S.q4[0].resize((size_t)qlen + 8); S.q4[1].resize((size_t)qlen + 8);  // (+8: update_extra reads whole 8-byte words)
             uint8_t *f = S.q4[0].data(), *rc = S.q4[1].data();
             for (int j = 0; j < qlen; ++j) f[j] = g_nt4.fwd[(unsigned char)s[j]];
-            for (int j = 0; j < qlen; ++j) rc[j] = g_nt4.comp[f[qlen - 1 - j]];
+            int j = 0;
+            for (; j + 8 <= qlen; j += 8) {  // eight codes at a time: byte-reverse, 3 - c for a base, 4 stays 4
+                uint64_t x;
+                memcpy(&x, f + qlen - 8 - j, 8);
+                x = __builtin_bswap64(x);
+                x = 0x0303030303030303ULL - (x & 0x0303030303030303ULL) + (x >> 2 & 0x0101010101010101ULL);
+                memcpy(rc + j, &x, 8);
+            }
+            for (; j < qlen; ++j) rc[j] = g_nt4.comp[f[qlen - 1 - j]];
+            sect.lap(6);
         }
     }, 1);
     wt.stop_into(g_stats[19]);
@@ -1669,6 +1728,9 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         static const char *const nm[] = {"other", "hits", "plan", "plan-copy", "stitch", "final", "dp-group-A", "strip-sort", "job-copy"};
         fprintf(stderr, "[cpu] thread CPU ms in parallel regions:");
         for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.0f", nm[k], g_cpu_ns[k].load() / 1e6);
+        fprintf(stderr, "\n[cpu] sections: stitch-append %.0f stitch-fetch %.0f stitch-extra %.0f", g_cpu_ns[16].load() / 1e6, g_cpu_ns[17].load() / 1e6,
+                g_cpu_ns[18].load() / 1e6);
+        for (int k = 3; k < 16; ++k) if (g_cpu_ns[16 + k].load() > 500000) fprintf(stderr, " s%d %.0f", k, g_cpu_ns[16 + k].load() / 1e6);
         fprintf(stderr, "\n[cpu] worker-thread CPU ms by phase slot:");
         for (int k = 0; k < 64; ++k) if (g_worker_cpu_ns[k].load() > 500000) fprintf(stderr, " [%d] %.0f", k, g_worker_cpu_ns[k].load() / 1e6);
         fprintf(stderr, "\n");
