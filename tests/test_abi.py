@@ -15,15 +15,15 @@ def declared_symbols():
         text = re.sub(r'//[^\n]*', '', text)
         for m in re.finditer(r'\b([A-Za-z_][A-Za-z0-9_]*)\s*\(', text):
             name = m.group(1)
-            if name.startswith(('mpn_', 'ssw_')) or name in ('init_destroy', 'align_destroy'):
+            if name.startswith(('mpn_', 'ssw_')) or name in ('init_destroy', 'align_destroy', 'realign_reads', 'free_memory'):
                 syms.add(name)
     return syms
 
 
 def test_headers_declare_something():
     syms = declared_symbols()
-    assert {'ssw_init', 'ssw_align', 'init_destroy', 'align_destroy', 'mpn_ssw_align_batch',
-            'mpn_last_error'} <= syms
+    assert {'ssw_init', 'ssw_align', 'init_destroy', 'align_destroy', 'mpn_ssw_align_batch', 'mpn_last_error', 'realign_reads',
+            'free_memory', 'mpn_realign_batch', 'mpn_realign_free_cigars'} <= syms
 
 
 def test_library_exports_all_declared_symbols(libmpn):
@@ -41,7 +41,7 @@ def test_s_align_layout_matches_reference_struct():
 def test_product_does_not_import_oracle():
     """The product path must never import, load or link anything under oracle/ (it is the checker)."""
     import re
-    pat = re.compile(r'(^|\n)\s*(from\s+oracle|import\s+oracle)|libssw_oracle|libmm2_oracle|mm2_oracle\.h|reassign_oracle|_ref/libssw')
+    pat = re.compile(r'(^|\n)\s*(from\s+oracle|import\s+oracle)|libssw_oracle|libmm2_oracle|mm2_oracle\.h|reassign_oracle|realign_oracle|_ref/libssw|_ref/librealigner')
     for path in glob.glob(os.path.join(ROOT, 'megapath_nano_amd', '**', '*'), recursive=True):
         if path.endswith(('.py', '.hip', '.h', '.cpp')):
             assert not pat.search(open(path).read()), f'{path} uses the oracle'
