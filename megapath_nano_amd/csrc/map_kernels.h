@@ -413,11 +413,12 @@ __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict_
 // saturating 3-level counters -- three bitmaps "seen once / twice / three times", raised by atomicOr (the returned old
 // word tells whether to climb a level).  Collisions only make the filter keep more.
 // The hits are walked like a load-balanced expand: a wave takes 64 consecutive minimizers of its read, whose hits are one
-// contiguous range of virtual slots, four 64-slot windows per step (four independent gathers in flight per lane).
+// contiguous range of virtual slots, FLT_UNROLL 64-slot windows per step (as many independent gathers in flight per lane).
 // Pass 1 counts, pass 2 (after a barrier) gathers again, tests, and leaves one keep word per window + the block's total.
-constexpr int FLT_THREADS = 1024, FLT_WAVES = FLT_THREADS / 64;
+constexpr int FLT_THREADS = 1024, FLT_WAVES = FLT_THREADS / 64, FLT_UNROLL = 4;  // windows of 64 slots per wave step
 constexpr int FLT_SLOTS = 81920, FLT_WORDS = FLT_SLOTS / 32;      // bits / words per bitmap; 4 tables x 3 levels = 120 KB
-constexpr size_t FLT_LDS_BYTES = (size_t)12 * FLT_WORDS * 4 + (size_t)FLT_WAVES * 64 * 16 + 16;
+constexpr int FLT_CHUNK = 4096;                                   // slots per start-bit chunk of a wave (64 words)
+constexpr size_t FLT_LDS_BYTES = (size_t)12 * FLT_WORDS * 4 + (size_t)FLT_WAVES * (64 * 8 + FLT_CHUNK / 8 + 64 * 4) + 16;
 struct FilterParams { int shift; uint32_t half; int level; };    // bin = pos >> shift; level = T - 1 (bitmap tested)
 
 __device__ __forceinline__ void flt_slots(uint32_t hi, uint32_t bin, uint32_t &s1, uint32_t &s2) {
@@ -449,11 +450,16 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                                                                   int64_t *__restrict__ blk_kept, int32_t *__restrict__ blk_read) {
     extern __shared__ uint32_t flt_lds[];
     uint32_t *bm = flt_lds;                                            // [table A1, A2, B1, B2][level][FLT_WORDS]
-    int64_t *g_all = (int64_t *)(flt_lds + 12 * FLT_WORDS);           // per wave: block-relative first slot of each minimizer
-    int64_t *ps_all = g_all + FLT_WAVES * 64;                          // per wave: index position of its first hit | parity << 62
-    uint32_t *next_blk = (uint32_t *)(ps_all + FLT_WAVES * 64);        // [2]: the block queue of each pass
+    // per wave: the block's minimizers that have hits, compacted -- index position of the first hit | parity << 62,
+    // block-relative first slot -- and the start-of-minimizer bits of the chunk of FLT_CHUNK slots being walked
+    unsigned long long *ps_all = (unsigned long long *)(flt_lds + 12 * FLT_WORDS);
+    unsigned long long *sb_all = ps_all + FLT_WAVES * 64;
+    uint32_t *g_all = (uint32_t *)(sb_all + FLT_WAVES * (FLT_CHUNK / 64));
+    uint32_t *next_blk = g_all + FLT_WAVES * 64;                       // [2]: the block queue of each pass
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int64_t *g = g_all + wv * 64, *ps = ps_all + wv * 64;
+    unsigned long long *ps = ps_all + wv * 64, *sb = sb_all + wv * (FLT_CHUNK / 64);
+    uint32_t *g = g_all + wv * 64;
+    const unsigned long long lane_le = lane == 63 ? ~0ULL : (2ULL << lane) - 1;
     for (int ri = blockIdx.x; ri < n_reads; ri += gridDim.x) {
         const int read = order[ri];                                    // reads with many hits first (the grid's long pole)
         const int64_t m0 = mz_off[read], m1 = mz_off[read + 1];
@@ -472,66 +478,80 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                 const int64_t m = m0 + b * 64 + lane;
                 int32_t t = 0;
                 int64_t rel = 0;
+                unsigned long long psv = 0;
                 if (m < m1) {
                     t = occ[m];
                     if (t < 0) t = 0;
                     rel = rel_off[m];
-                    ps[lane] = pos_start[m] | (int64_t)((uint32_t)mz[m].y & 1) << 62;
+                    psv = (unsigned long long)pos_start[m] | (unsigned long long)((uint32_t)mz[m].y & 1) << 62;
                 }
                 const int64_t first = __shfl(rel, 0);
-                const int64_t end_own = rel - first + t;
-                int64_t end_all = end_own;
+                const uint32_t start = m < m1 ? (uint32_t)(rel - first) : 0u;   // (64 minimizers x mid_occ hits: far below 2^32)
+                uint32_t end_all = start + (uint32_t)t;
 #pragma unroll
-                for (int d = 32; d; d >>= 1) { const int64_t o = __shfl_xor(end_all, d); end_all = o > end_all ? o : end_all; }
-                g[lane] = m < m1 ? rel - first : end_all;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)end_all, d); end_all = o > end_all ? o : end_all; }
+                // owners of the slots: the minimizers with hits, compacted, so that their starts are distinct
+                const unsigned long long nz = __ballot(t > 0);
+                if (t > 0) { const int c = __popcll(nz & (lane_le >> 1)); g[c] = start; ps[c] = psv; }
                 const int64_t vfirst = v0 + first;
                 int64_t kept = 0;
-                for (int64_t p0 = 0, it = 0; p0 < end_all; p0 += 256, it += 4) {
-                    uint64_t r[4];
-                    uint32_t par[4];
+                for (uint32_t c0 = 0; c0 < end_all; c0 += FLT_CHUNK) {
+                    sb[lane] = 0;                                       // (FLT_CHUNK / 64 == 64 words)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if (t > 0 && start >= c0 && start - c0 < (uint32_t)FLT_CHUNK) atomicOr(&sb[(start - c0) >> 6], 1ULL << ((start - c0) & 63));
+                    int before = __popcll(__ballot(t > 0 && start < c0));  // owners that start before the chunk
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t c_end = end_all - c0 < (uint32_t)FLT_CHUNK ? end_all - c0 : (uint32_t)FLT_CHUNK;
+                    for (uint32_t q0 = 0; q0 < c_end; q0 += 64 * FLT_UNROLL) {
+                        uint64_t r[FLT_UNROLL];
+                        uint32_t par[FLT_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int64_t p = p0 + u * 64 + lane;
-                        r[u] = 0; par[u] = 0;
-                        if (p < end_all) {
-                            int lo = 0, hi = 63;  // last lane whose range starts at or before p
-#pragma unroll
-                            for (int step = 0; step < 6; ++step) {
-                                const int mid = (lo + hi + 1) >> 1;
-                                if (g[mid] <= p) lo = mid; else hi = mid - 1;
-                            }
-                            const int64_t pv = ps[lo];
-                            par[u] = (uint32_t)(pv >> 62) & 1;
-                            r[u] = pos[(pv & 0x3fffffffffffffffLL) + (p - g[lo])];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int64_t p = p0 + u * 64 + lane;
-                        bool keep_it = false;
-                        if (p < end_all) {
-                            const uint32_t hi = (uint32_t)(r[u] >> 32) | (((uint32_t)r[u] & 1) ^ par[u]) << 31;   // strand | target
-                            const uint32_t rpos = (uint32_t)r[u] >> 1;
-                            const uint32_t ba = (uint32_t)((uint64_t)rpos >> fp.shift), bb = (uint32_t)(((uint64_t)rpos + fp.half) >> fp.shift);
-                            uint32_t a1, a2, b1, b2;
-                            flt_slots(hi, ba, a1, a2);
-                            flt_slots(hi ^ 0x5bd1e995u, bb, b1, b2);
-                            if (pass == 0) {
-                                flt_add(bm, a1); flt_add(bm + 3 * FLT_WORDS, a2);
-                                flt_add(bm + 6 * FLT_WORDS, b1); flt_add(bm + 9 * FLT_WORDS, b2);
-                            } else {
-                                keep_it = (flt_test(bm, a1, fp.level) && flt_test(bm + 3 * FLT_WORDS, a2, fp.level)) ||
-                                          (flt_test(bm + 6 * FLT_WORDS, b1, fp.level) && flt_test(bm + 9 * FLT_WORDS, b2, fp.level));
+                        for (int u = 0; u < FLT_UNROLL; ++u) {
+                            r[u] = 0; par[u] = 0;
+                            const uint32_t w0 = q0 + u * 64;
+                            if (w0 < c_end) {                           // (uniform)
+                                const unsigned long long word = sb[w0 >> 6];
+                                const uint32_t p = c0 + w0 + lane;
+                                if (p < end_all) {
+                                    const int own = before + __popcll(word & lane_le) - 1;   // last owner that starts at or before p
+                                    const unsigned long long pv = ps[own];
+                                    par[u] = (uint32_t)(pv >> 62) & 1;
+                                    r[u] = pos[(pv & 0x3fffffffffffffffULL) + (p - g[own])];
+                                }
+                                before += __popcll(word);
                             }
                         }
-                        if (pass == 1 && p0 + u * 64 < end_all) {
-                            const unsigned long long km = __ballot(keep_it);
-                            if (lane == 0) keep[flt_word(vfirst, gb0 + b, it + u)] = km;
-                            kept += __popcll(km);
+#pragma unroll
+                        for (int u = 0; u < FLT_UNROLL; ++u) {
+                            const uint32_t w0 = q0 + u * 64;
+                            if (w0 >= c_end) break;
+                            const uint32_t p = c0 + w0 + lane;
+                            bool keep_it = false;
+                            if (p < end_all) {
+                                const uint32_t hi = (uint32_t)(r[u] >> 32) | (((uint32_t)r[u] & 1) ^ par[u]) << 31;   // strand | target
+                                const uint32_t rpos = (uint32_t)r[u] >> 1;
+                                const uint32_t ba = (uint32_t)((uint64_t)rpos >> fp.shift), bb = (uint32_t)(((uint64_t)rpos + fp.half) >> fp.shift);
+                                uint32_t a1, a2, b1, b2;
+                                flt_slots(hi, ba, a1, a2);
+                                flt_slots(hi ^ 0x5bd1e995u, bb, b1, b2);
+                                if (pass == 0) {
+                                    flt_add(bm, a1); flt_add(bm + 3 * FLT_WORDS, a2);
+                                    flt_add(bm + 6 * FLT_WORDS, b1); flt_add(bm + 9 * FLT_WORDS, b2);
+                                } else {
+                                    keep_it = (flt_test(bm, a1, fp.level) && flt_test(bm + 3 * FLT_WORDS, a2, fp.level)) ||
+                                              (flt_test(bm + 6 * FLT_WORDS, b1, fp.level) && flt_test(bm + 9 * FLT_WORDS, b2, fp.level));
+                                }
+                            }
+                            if (pass == 1) {
+                                const unsigned long long km = __ballot(keep_it);
+                                if (lane == 0) keep[flt_word(vfirst, gb0 + b, (int64_t)((c0 + w0) >> 6))] = km;
+                                kept += __popcll(km);
+                            }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (pass == 1 && lane == 0) { blk_kept[gb0 + b] = kept; blk_read[gb0 + b] = read; }
                 __builtin_amdgcn_wave_barrier();

@@ -216,6 +216,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         blk_read.alloc((size_t)nb_cap + 1) || blk_kept.zero(st))
         return -1;
     if (nb_cap > 0x7fffffff) { set_error("sub-batch too large for the seed filter"); return -1; }
+    if (mid_occ > (1 << 25)) { set_error("occurrence cut-off %d too large (a block of 64 minimizers must hold fewer than 2^32 hits)", mid_occ); return -1; }
     if (n_full > 0) {
         FilterParams fp;
         {
