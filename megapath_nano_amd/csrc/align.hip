@@ -8,6 +8,7 @@
 // whose alignment z-drops is split and its remainder goes through another round.
 #include "map_types.h"
 #include "ext_kernels.h"
+#include "fin_kernels.h"
 #include "mapper_internal.h"
 #include "../../include/mpn_map.h"
 
@@ -48,6 +49,7 @@ struct Reg {
     int32_t has_p = 0, dp_score = 0, dp_max = 0, dp_max2 = 0, n_ambi = 0;
     std::vector<uint32_t> cigar;
     int32_t aligned = 0;  // base-level extension already done (or not needed)
+    int32_t fin_pending = 0, fin_qs1 = 0, fin_rs1 = 0, fin_qspan = 0, fin_tspan = 0;  // stitched this round: CIGAR fix-up and statistics are due
 };
 
 static inline uint64_t hash64(uint64_t key) {
@@ -531,131 +533,6 @@ static void append_cigar(Reg &r, int n_cigar, const uint32_t *cigar) {
     } else r.cigar.insert(r.cigar.end(), cigar, cigar + n_cigar);
 }
 
-static void fix_cigar(Reg &r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift) {
-    int32_t toff = 0, qoff = 0, to_shrink = 0;
-    *qshift = *tshift = 0;
-    int n_cigar = (int)r.cigar.size();
-    uint32_t *cigar = r.cigar.data();
-    if (n_cigar <= 1) return;
-    for (int k = 0; k < n_cigar; ++k) {
-        const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
-        if (len == 0) to_shrink = 1;
-        if (op == 0) { toff += len; qoff += len; }
-        else if (op == 1 || op == 2) {
-            if (k > 0 && k < n_cigar - 1 && (cigar[k - 1] & 0xf) == 0 && (cigar[k + 1] & 0xf) == 0) {
-                int l;
-                const int prev_len = cigar[k - 1] >> 4;
-                if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
-                else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
-                if (l > 0) { cigar[k - 1] -= l << 4; cigar[k + 1] += l << 4; qoff -= l; toff -= l; }
-                if (l == prev_len) to_shrink = 1;
-            }
-            if (op == 1) qoff += len; else toff += len;
-        }
-    }
-    for (int k = 0; k < n_cigar - 2; ++k) {
-        if ((cigar[k] & 0xf) > 0 && (cigar[k] & 0xf) + (cigar[k + 1] & 0xf) == 3) {
-            uint32_t l, s[3] = {0, 0, 0};
-            for (l = k; l < (uint32_t)n_cigar; ++l) {
-                const uint32_t op = cigar[l] & 0xf;
-                if (op == 1 || op == 2 || cigar[l] >> 4 == 0) s[op] += cigar[l] >> 4;
-                else break;
-            }
-            if (s[1] > 0 && s[2] > 0 && l - k > 2) {
-                cigar[k] = s[1] << 4 | 1;
-                cigar[k + 1] = s[2] << 4 | 2;
-                for (k += 2; k < (int)l; ++k) cigar[k] &= 0xf;
-                to_shrink = 1;
-            }
-            k = l;
-        }
-    }
-    if (to_shrink) {
-        int32_t l = 0;
-        for (int k = 0; k < n_cigar; ++k) if (cigar[k] >> 4 != 0) cigar[l++] = cigar[k];
-        n_cigar = l;
-        l = 0;
-        for (int k = 0; k < n_cigar; ++k)
-            if (k == n_cigar - 1 || (cigar[k] & 0xf) != (cigar[k + 1] & 0xf)) cigar[l++] = cigar[k];
-            else cigar[k + 1] += cigar[k] >> 4 << 4;
-        n_cigar = l;
-    }
-    if ((cigar[0] & 0xf) == 1 || (cigar[0] & 0xf) == 2) {
-        const int32_t l = cigar[0] >> 4;
-        if ((cigar[0] & 0xf) == 1) { if (r.rev) r.qe -= l; else r.qs += l; *qshift = l; }
-        else { r.rs += l; *tshift = l; }
-        --n_cigar;
-        memmove(cigar, cigar + 1, (size_t)n_cigar * 4);
-    }
-    r.cigar.resize(n_cigar);
-}
-
-static void update_extra(Reg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e) {
-    if (!r.has_p) return;
-    int qshift, tshift;
-    int32_t s = 0, max = 0, toff = 0, qoff = 0;
-    fix_cigar(r, qseq, tseq, &qshift, &tshift);
-    qseq += qshift; tseq += tshift;
-    r.blen = r.mlen = 0;
-    for (size_t k = 0; k < r.cigar.size(); ++k) {
-        const uint32_t op = r.cigar[k] & 0xf, len = r.cigar[k] >> 4;
-        if (op == 0) {
-            int n_ambi = 0, n_diff = 0;
-            const uint8_t *qp = qseq + qoff, *tp = tseq + toff;
-            if (mat[0] > 0) {
-                // Eight columns at a time (both sequences are padded by 8 bytes): the columns that are not plain matches are the
-                // non-zero bytes of a word; between them the score only rises (s >= 0 holds after every column), so a run's
-                // last column carries its maximum -- same s and max as column by column.  ONT alignments are runs of ~12
-                // columns between gaps, most of them without a mismatch: one word compare per run instead of a loop.
-                for (uint32_t l = 0; l < len; l += 8) {
-                    const uint32_t c = len - l < 8 ? len - l : 8;
-                    uint64_t a, b;
-                    memcpy(&a, qp + l, 8); memcpy(&b, tp + l, 8);
-                    uint64_t ev = (a ^ b) | ((a | b) & 0xFCFCFCFCFCFCFCFCULL);
-                    if (c < 8) ev &= (1ULL << (8 * c)) - 1;
-                    uint32_t done = 0;
-                    while (ev) {
-                        const uint32_t p = (uint32_t)__builtin_ctzll(ev) >> 3;
-                        if (p > done) { s += (int32_t)(p - done) * mat[0]; max = max > s ? max : s; }
-                        const int cq = qp[l + p], ct = tp[l + p];
-                        if (ct > 3 || cq > 3) ++n_ambi; else ++n_diff;
-                        s += mat[ct * 5 + cq];
-                        if (s < 0) s = 0; else max = max > s ? max : s;
-                        done = p + 1;
-                        ev &= ~(0xFFULL << (8 * p));
-                    }
-                    if (c > done) { s += (int32_t)(c - done) * mat[0]; max = max > s ? max : s; }
-                }
-            } else {
-                for (uint32_t l = 0; l < len; ++l) {
-                    const int cq = qp[l], ct = tp[l];
-                    if (ct > 3 || cq > 3) ++n_ambi;
-                    else if (ct != cq) ++n_diff;
-                    s += mat[ct * 5 + cq];
-                    if (s < 0) s = 0; else max = max > s ? max : s;
-                }
-            }
-            r.blen += len - n_ambi; r.mlen += len - (n_ambi + n_diff); r.n_ambi += n_ambi;
-            toff += len; qoff += len;
-        } else if (op == 1) {
-            int n_ambi = 0;
-            for (uint32_t l = 0; l < len; ++l) if (qseq[qoff + l] > 3) ++n_ambi;
-            r.blen += len - n_ambi; r.n_ambi += n_ambi;
-            s -= q + e * len;
-            if (s < 0) s = 0;
-            qoff += len;
-        } else if (op == 2) {
-            int n_ambi = 0;
-            for (uint32_t l = 0; l < len; ++l) if (tseq[toff + l] > 3) ++n_ambi;
-            r.blen += len - n_ambi; r.n_ambi += n_ambi;
-            s -= q + e * len;
-            if (s < 0) s = 0;
-            toff += len;
-        }
-    }
-    r.dp_max = max;
-}
-
 // MPN_DEBUG_CPU: thread CPU time of the sections of a host phase (g_cpu_ns[16 + k])
 struct CpuSect {
     timespec t;
@@ -665,13 +542,10 @@ struct CpuSect {
 };
 
 // returns true if a split remainder was produced in r2
-static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, const uint8_t *qseq_strand[2], Reg &r, Reg &r2,
+static bool stitch_align(const mpn_map_opt *opt, int qlen, Reg &r, Reg &r2,
                          const u128 *a, const Plan &pl, const ExtRes *res, const ExtJob *jobs,
                          const uint32_t *cig_pool) {
-    const int32_t rid = a[r.as].x << 1 >> 33, rev = a[r.as].x >> 63;
-    int8_t mat[25];
-    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = i == j ? opt->a : -opt->b; mat[i * 5 + 4] = -opt->sc_ambi; }
-    for (int i = 0; i < 5; ++i) mat[20 + i] = -opt->sc_ambi;
+    const int32_t rev = a[r.as].x >> 63;
     auto cig_of = [&](int job, int *n) -> const uint32_t * {
         const ExtRes &e = res[job];
         const ExtJob &j = jobs[job];
@@ -740,14 +614,8 @@ static bool stitch_align(const mpn_map_opt *opt, const mpn_index *mi, int qlen, 
     if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; }
     else { r.qs = qs1; r.qe = qe1; }
     sect.lap(0);
-    if (r.has_p) {
-        static thread_local std::vector<uint8_t> tbuf;  // target codes of the aligned interval
-        tbuf.resize((size_t)std::max(0, re1 - rs1) + 8);  // (update_extra reads whole 8-byte words)
-        mi->fetch_codes(mi->seq_off[rid] + rs1, re1 - rs1, tbuf.data());
-        sect.lap(1);
-        update_extra(r, qseq_strand[rev] + qs1, tbuf.data(), mat, (int8_t)opt->q, (int8_t)opt->e);
-        sect.lap(2);
-    }
+    // the CIGAR fix-up and the alignment statistics (mm_update_extra) are done for the whole round by aln_finish_kernel
+    if (r.has_p) { r.fin_pending = 1; r.fin_qs1 = qs1; r.fin_rs1 = rs1; r.fin_qspan = std::max(0, qe1 - qs1); r.fin_tspan = std::max(0, re1 - rs1); }
     r.aligned = 1;
     return has_r2;
 }
@@ -835,7 +703,6 @@ struct ReadState {
     std::vector<Reg> regs;
     std::vector<u128> a;   // chained anchors (squeezed)
     int n_a = 0;
-    std::vector<uint8_t> q4[2];
     std::vector<Plan> plans;  // per reg (only for regs being aligned this round)
     std::vector<int> pending; // reg indices aligned this round
 };
@@ -994,6 +861,7 @@ struct Slot {
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
+    PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_jobs{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
 };
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
@@ -1386,16 +1254,101 @@ static int run_jobs(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int
 
 using namespace mpn;
 
-static const struct Nt4Tables {  // ASCII -> 0..4 code, and the complement of a code
-    uint8_t fwd[256], comp[8];
-    Nt4Tables() {
-        memset(fwd, 4, sizeof(fwd));
-        const char *b = "ACGT";
-        for (int i = 0; i < 4; ++i) { fwd[(unsigned char)b[i]] = (uint8_t)i; fwd[(unsigned char)(b[i] | 0x20)] = (uint8_t)i; }
-        fwd[(unsigned char)'U'] = fwd[(unsigned char)'u'] = 3;
-        for (int i = 0; i < 8; ++i) comp[i] = (uint8_t)(i < 4 ? 3 - i : 4);
+// CIGAR fix-up + statistics of every alignment stitched in this round, on the device (fin_kernels.h): the stitched CIGARs
+// go up in one block, the fixed ones and eight integers per alignment come back.
+static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadState *rs, int n, const uint8_t *d_seqs, const int64_t *d_off,
+                             const int32_t *d_len, int n_threads, hipStream_t st) {
+    std::vector<int64_t> op_off((size_t)n + 1, 0);
+    std::vector<int32_t> job_off((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        int64_t ops = 0;
+        int32_t jobs = 0;
+        for (Reg &r : rs[i].regs) {
+            if (!r.fin_pending) continue;
+            if (r.cigar.empty()) { r.fin_pending = 0; r.blen = r.mlen = 0; r.dp_max = 0; continue; }  // (what update_extra leaves for an empty CIGAR)
+            ops += (int64_t)r.cigar.size(); ++jobs;
+        }
+        op_off[(size_t)i + 1] = op_off[(size_t)i] + ops; job_off[(size_t)i + 1] = job_off[(size_t)i] + jobs;
     }
-} g_nt4;
+    const int64_t n_ops = op_off[(size_t)n];
+    const int n_jobs = job_off[(size_t)n];
+    if (n_jobs == 0) return 0;
+    Slot &SL = *tl_slot;
+    if (SL.pin_fin_cig.ensure((size_t)n_ops * 4 + 16) || SL.pin_fin_jobs.ensure((size_t)n_jobs * sizeof(FinJob) + 16) ||
+        SL.pin_fin_out.ensure((size_t)n_jobs * sizeof(FinOut) + 16))
+        return -1;
+    uint32_t *h_cig = SL.pin_fin_cig.as<uint32_t>();
+    FinJob *h_jobs = SL.pin_fin_jobs.as<FinJob>();
+    FinOut *h_out = SL.pin_fin_out.as<FinOut>();
+    parallel_for(n, n_threads, [&](int i, int) {
+        int64_t o = op_off[(size_t)i];
+        int32_t j = job_off[(size_t)i];
+        for (Reg &r : rs[i].regs) {
+            if (!r.fin_pending) continue;
+            memcpy(h_cig + o, r.cigar.data(), r.cigar.size() * 4);
+            h_jobs[j++] = FinJob{o, 0, (int32_t)r.cigar.size(), i, r.rid, (int32_t)r.rev, r.fin_qs1, r.fin_rs1, r.fin_qspan, r.fin_tspan};
+            o += (int64_t)r.cigar.size();
+        }
+    }, 9);
+    // launch lists by LDS need (CIGAR, shift table, both code arrays): three LDS classes, the rest works in global scratch
+    static const size_t kLds[3] = {(size_t)24 << 10, (size_t)48 << 10, (size_t)152 << 10};
+    std::vector<int32_t> lists[4];
+    int64_t code_bytes = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const size_t codes = (size_t)((h_jobs[j].qspan + 3) & ~3) + (size_t)((h_jobs[j].tspan + 3) & ~3);
+        const size_t need = (size_t)h_jobs[j].n_cigar * 8 + codes + 16;
+        const int c = need <= kLds[0] ? 0 : need <= kLds[1] ? 1 : need <= kLds[2] ? 2 : 3;
+        if (c == 3) { h_jobs[j].code_off = code_bytes; code_bytes += (int64_t)codes; }
+        lists[c].push_back(j);
+    }
+    DevBuf<uint32_t> d_cig, d_aux;
+    DevBuf<uint8_t> d_codes;
+    DevBuf<FinJob> d_jobs;
+    DevBuf<FinOut> d_out;
+    if (d_cig.alloc((size_t)n_ops) || d_jobs.alloc((size_t)n_jobs) || d_out.alloc((size_t)n_jobs)) return -1;
+    if (!lists[3].empty() && (d_aux.alloc((size_t)n_ops) || d_codes.alloc((size_t)code_bytes + 16))) return -1;
+    MPN_HIP_CHECK(hipMemcpyAsync(d_cig.p, h_cig, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, h_jobs, (size_t)n_jobs * sizeof(FinJob), hipMemcpyHostToDevice, st));
+    FinParams prm;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) prm.mat[i * 5 + j] = (int8_t)(i == j ? opt->a : -opt->b); prm.mat[i * 5 + 4] = (int8_t)-opt->sc_ambi; }
+    for (int i = 0; i < 5; ++i) prm.mat[20 + i] = (int8_t)-opt->sc_ambi;
+    prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e;
+    std::vector<int32_t> order;
+    int base[4];
+    for (int c = 0; c < 4; ++c) { base[c] = (int)order.size(); order.insert(order.end(), lists[c].begin(), lists[c].end()); }
+    DevBuf<int32_t> d_list;
+    if (d_list.upload(order.data(), order.size(), st)) return -1;
+    const RefView rvw{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
+    static std::once_flag fin_attr;
+    std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[2]); });
+    for (int c = 0; c < 3; ++c)
+        if (!lists[c].empty())
+            hipLaunchKernelGGL(aln_finish_wave_kernel<true>, dim3((unsigned)std::min<size_t>(lists[c].size(), 256 * 64)), dim3(64), kLds[c], st, (const FinJob *)d_jobs.p,
+                               (const int32_t *)d_list.p + base[c], (int)lists[c].size(), d_cig.p, (uint32_t *)nullptr, (uint8_t *)nullptr, d_seqs, d_off, d_len, rvw, prm, d_out.p);
+    if (!lists[3].empty())
+        hipLaunchKernelGGL(aln_finish_wave_kernel<false>, dim3((unsigned)std::min<size_t>(lists[3].size(), 256 * 64)), dim3(64), 0, st, (const FinJob *)d_jobs.p,
+                           (const int32_t *)d_list.p + base[3], (int)lists[3].size(), d_cig.p, d_aux.p, d_codes.p, d_seqs, d_off, d_len, rvw, prm, d_out.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    MPN_HIP_CHECK(hipMemcpyAsync(h_out, d_out.p, (size_t)n_jobs * sizeof(FinOut), hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_cig, d_cig.p, (size_t)n_ops * 4, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    parallel_for(n, n_threads, [&](int i, int) {
+        int64_t o = op_off[(size_t)i];
+        int32_t j = job_off[(size_t)i];
+        for (Reg &r : rs[i].regs) {
+            if (!r.fin_pending) continue;
+            const FinOut &f = h_out[j++];
+            const size_t old_n = r.cigar.size();
+            r.cigar.assign(h_cig + o, h_cig + o + f.n_cigar);
+            o += (int64_t)old_n;
+            if (f.qshift) { if (r.rev) r.qe -= f.qshift; else r.qs += f.qshift; }
+            r.rs += f.tshift;
+            r.blen = f.blen; r.mlen = f.mlen; r.n_ambi += f.n_ambi; r.dp_max = f.dp_max;
+            r.fin_pending = 0;
+        }
+    }, 9);
+    return 0;
+}
 
 // One contiguous range [lo, hi) of the batch through the whole path, on the calling worker's stream and arena.
 // Fills rs[lo..hi) (the final hits of every read) and rep_len[lo..hi).
@@ -1455,20 +1408,6 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         if (opt->with_cigar) {
             S.n_a = squeeze_a(S.regs, S.a.data());
             sect.lap(5);
-            const char *s = seqs + seq_off[i];
-            S.q4[0].resize((size_t)qlen + 8); S.q4[1].resize((size_t)qlen + 8);  // (+8: update_extra reads whole 8-byte words)
-            uint8_t *f = S.q4[0].data(), *rc = S.q4[1].data();
-            for (int j = 0; j < qlen; ++j) f[j] = g_nt4.fwd[(unsigned char)s[j]];
-            int j = 0;
-            for (; j + 8 <= qlen; j += 8) {  // eight codes at a time: byte-reverse, 3 - c for a base, 4 stays 4
-                uint64_t x;
-                memcpy(&x, f + qlen - 8 - j, 8);
-                x = __builtin_bswap64(x);
-                x = 0x0303030303030303ULL - (x & 0x0303030303030303ULL) + (x >> 2 & 0x0101010101010101ULL);
-                memcpy(rc + j, &x, 8);
-            }
-            for (; j < qlen; ++j) rc[j] = g_nt4.comp[f[qlen - 1 - j]];
-            sect.lap(6);
         }
     }, 1);
     wt.stop_into(g_stats[19]);
@@ -1522,15 +1461,15 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
                 if (S.pending.empty()) return;
-                const uint8_t *q2[2] = {S.q4[0].data(), S.q4[1].data()};
                 int shift = 0;
                 for (size_t pi = 0; pi < S.pending.size(); ++pi) {
                     const int k = S.pending[pi] + shift;
                     Reg r2;
-                    const bool has = stitch_align(opt, idx, seq_len[i], q2, S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs.data(), cig);
+                    const bool has = stitch_align(opt, seq_len[i], S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs.data(), cig);
                     if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
                 }
             }, 4);
+            if (finish_alignments(idx, opt, rs, n, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
             wt.stop_into(g_stats[22]);
         }
     }
@@ -1553,8 +1492,6 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         n_aln += (int64_t)S.regs.size();
         // the per-read scratch is no longer needed
         std::vector<u128>().swap(S.a);
-        std::vector<uint8_t>().swap(S.q4[0]);
-        std::vector<uint8_t>().swap(S.q4[1]);
     }, 5);
     g_stats[6] += n_aln;
     wt.stop_into(g_stats[23]);
@@ -1573,7 +1510,7 @@ struct mpn_hits {
 
 // Threads of the host pool: what the caller asks for, else the cores this process may actually use -- the container's CPU
 // quota (cgroup v2 cpu.max / v1 cfs quota) counts, not just the visible cores: with 256 visible cores and a quota of 16
-// a pool of 32 threads is throttled and loses 5 % -- capped at 32.
+// a pool sized by the visible cores is throttled -- capped at 32.
 static int default_host_threads(const mpn_map_opt *opt) {
     if (const char *e = getenv("MPN_HOST_THREADS")) return std::max(1, atoi(e));
     if (opt->host_threads > 0) return opt->host_threads;
@@ -1589,7 +1526,10 @@ static int default_host_threads(const mpn_map_opt *opt) {
             fclose(g);
             if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
         }
-        if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)((quota + period - 1) / period)));
+        // twice the quota: the pool's threads mostly serve short bursts between GPU waits, and with the stray-hit filter the
+        // step is short enough that a burst waiting for a free pool thread costs more than the quota's throttling (measured
+        // on a 16-CPU quota: 16 threads 84.7, 24: 86.4, 32: 88.2, 48: 84.1 Gbp/min)
+        if (quota > 0 && period > 0) n = std::min(n, 2 * std::max(1, (int)((quota + period - 1) / period)));
         return n;
     }();
     return detected;
@@ -1725,11 +1665,10 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         fprintf(stderr, "[phase-end]\n");
     }
     if (g_cpu_on) {
-        static const char *const nm[] = {"other", "hits", "plan", "plan-copy", "stitch", "final", "dp-group-A", "strip-sort", "job-copy"};
+        static const char *const nm[] = {"other", "hits", "plan", "plan-copy", "stitch", "final", "dp-group-A", "strip-sort", "job-copy", "finish-copy"};
         fprintf(stderr, "[cpu] thread CPU ms in parallel regions:");
-        for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.0f", nm[k], g_cpu_ns[k].load() / 1e6);
-        fprintf(stderr, "\n[cpu] sections: stitch-append %.0f stitch-fetch %.0f stitch-extra %.0f", g_cpu_ns[16].load() / 1e6, g_cpu_ns[17].load() / 1e6,
-                g_cpu_ns[18].load() / 1e6);
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.0f", nm[k], g_cpu_ns[k].load() / 1e6);
+        fprintf(stderr, "\n[cpu] sections: stitch-append %.0f", g_cpu_ns[16].load() / 1e6);
         for (int k = 3; k < 16; ++k) if (g_cpu_ns[16 + k].load() > 500000) fprintf(stderr, " s%d %.0f", k, g_cpu_ns[16 + k].load() / 1e6);
         fprintf(stderr, "\n[cpu] worker-thread CPU ms by phase slot:");
         for (int k = 0; k < 64; ++k) if (g_worker_cpu_ns[k].load() > 500000) fprintf(stderr, " [%d] %.0f", k, g_worker_cpu_ns[k].load() / 1e6);
