@@ -237,6 +237,7 @@ def main():
     #   anchor compaction (2 passes) : 2 x 16 B per emitted anchor in + 16 B per kept anchor out
     #   chain DP                     : 16 B per kept anchor in + 16 B (f, p, t, v) out
     #   strip DP <GL>                : 1 direction byte out per DP cell (qlen x tlen per window)
+    #   alignment finishing          : 4 B per CIGAR op in + 4 B out, ~1 B per aligned query base + 0.25 B per target base in
     cand = {
         'sketch_fast_kernel<count|fill>': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
         'seed_lookup_kernel': (st['k_seed_lookup_ns'], nsub, 28 * st['minimizers']),
@@ -249,6 +250,7 @@ def main():
         'ext_dp_strip_kernel<16>': (st['k_strip16_ns'], rounds, st['strip16_cells']),
         'ext_dp_strip_kernel<32>': (st['k_strip32_ns'], rounds, st['strip32_cells']),
         'ext_dp_strip_kernel<64>': (st['k_strip64_ns'], rounds, st['strip64_cells']),
+        'aln_finish_wave_kernel': (st['k_finish_ns'], 4 * rounds, 8 * st['cigar_ops'] + 2 * st['bases']),
     }
     dom = max(cand, key=lambda k: cand[k][0])
     ns, launches, abytes = cand[dom]

@@ -1291,7 +1291,7 @@ static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadS
         }
     }, 9);
     // launch lists by LDS need (CIGAR, shift table, both code arrays): three LDS classes, the rest works in global scratch
-    static const size_t kLds[3] = {(size_t)24 << 10, (size_t)48 << 10, (size_t)152 << 10};
+    static const size_t kLds[3] = {(size_t)16 << 10, (size_t)32 << 10, (size_t)64 << 10};
     std::vector<int32_t> lists[4];
     int64_t code_bytes = 0;
     for (int j = 0; j < n_jobs; ++j) {
@@ -1319,6 +1319,7 @@ static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     DevBuf<int32_t> d_list;
     if (d_list.upload(order.data(), order.size(), st)) return -1;
     const RefView rvw{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
+    EvTimer ev(st);
     static std::once_flag fin_attr;
     std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[2]); });
     for (int c = 0; c < 3; ++c)
@@ -1329,9 +1330,12 @@ static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadS
         hipLaunchKernelGGL(aln_finish_wave_kernel<false>, dim3((unsigned)std::min<size_t>(lists[3].size(), 256 * 64)), dim3(64), 0, st, (const FinJob *)d_jobs.p,
                            (const int32_t *)d_list.p + base[3], (int)lists[3].size(), d_cig.p, d_aux.p, d_codes.p, d_seqs, d_off, d_len, rvw, prm, d_out.p);
     MPN_HIP_CHECK(hipGetLastError());
+    ev.mark(52);
     MPN_HIP_CHECK(hipMemcpyAsync(h_out, d_out.p, (size_t)n_jobs * sizeof(FinOut), hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(hipMemcpyAsync(h_cig, d_cig.p, (size_t)n_ops * 4, hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(stream_sync(st));
+    ev.resolve();
+    g_stats[53] += n_ops;
     parallel_for(n, n_threads, [&](int i, int) {
         int64_t o = op_off[(size_t)i];
         int32_t j = job_off[(size_t)i];
@@ -1372,7 +1376,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         // MPN_SEED_SLOTS workers are inside this stage at a time (which also keeps the workers out of lock-step).
         struct StageGate {
             std::mutex mu; std::condition_variable cv; int free_slots;
-            StageGate() { const char *e = getenv("MPN_SEED_SLOTS"); free_slots = e ? std::max(1, atoi(e)) : 4; }
+            StageGate() { const char *e = getenv("MPN_SEED_SLOTS"); free_slots = e ? std::max(1, atoi(e)) : 8; }
             void enter() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return free_slots > 0; }); --free_slots; }
             void leave() { { std::lock_guard<std::mutex> g(mu); ++free_slots; } cv.notify_one(); }
         };
@@ -1561,7 +1565,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     // sub-batches of ~24 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
     // device arena, so that the host phases of one sub-batch overlap the GPU phases of the others and the
     // latency-bound kernels (chain DP, long extensions) of one overlap the throughput-bound ones of another
-    int n_workers = 8;
+    int n_workers = 12;
     if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(16, atoi(e)));
     std::vector<int> cut{0};
     {
