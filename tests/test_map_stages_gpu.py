@@ -107,3 +107,61 @@ def test_seed_chain_matches_oracle(world, mid_occ):
         assert np.array_equal(g['b'], b), r['name']
         n_chains += len(u)
     assert n_chains > len(reads) // 2
+
+
+@pytest.mark.parametrize('min_cnt,max_gap', [(1, 5000), (2, 5000), (5, 5000), (3, 300), (3, 40000), (2, 100)])
+def test_seed_chain_other_segment_rules(world, min_cnt, max_gap):
+    """the stray-hit filter derives its threshold and bin width from -n and -g: the chains must not depend on either"""
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    gen, reads, gidx, oidx = world
+    gopt = mapper.default_opt(min_cnt=min_cnt, max_gap=max_gap)
+    oopt = mb.default_opt(min_cnt=min_cnt, max_gap=max_gap)
+    got = mapper.seed_chain_batch(gidx, gopt, [r['seq'] for r in reads])
+    n_chains = 0
+    for r, g in zip(reads, got):
+        mv = mb.sketch(r['seq'], 10, 15, 0)
+        a, rep = mb.collect_anchors(oidx, oidx.mid_occ(), mv, len(r['seq']))
+        u, b = mb.chain(oopt, a)
+        assert g['n_anchor'] == len(a) and g['rep_len'] == rep, r['name']
+        assert np.array_equal(g['u'], u) and np.array_equal(g['b'], b), (r['name'], min_cnt, max_gap)
+        n_chains += len(u)
+    assert n_chains > 10
+
+
+def test_seed_chain_with_saturated_filter(libmpn, oracle_built):
+    """150 near-identical copies of one sequence and no occurrence cut-off: a read minimizer hits every copy, a read's
+    hundreds of thousands of hits overfill the filter's counters (it then keeps everything) and every bin is a true locus."""
+    from megapath_nano_amd import mapper, synth
+    from oracle import mm2_bindings as mb
+    rng = np.random.default_rng(5)
+    base = synth.ALPHA[rng.integers(0, 4, size=30000)]
+    gen = []
+    for c in range(150):
+        s = base.copy()
+        pos = rng.integers(0, len(s), size=300)
+        s[pos] = synth.ALPHA[rng.integers(0, 4, size=300)]
+        gen.append(('copy%d' % c, s))
+    reads = []
+    for k in range(6):
+        st = int(rng.integers(0, 14000))
+        q = base[st:st + 15000].copy()
+        pos = rng.integers(0, len(q), size=150)
+        q[pos] = synth.ALPHA[rng.integers(0, 4, size=150)]
+        reads.append(q if k % 2 == 0 else synth.COMP[q[::-1]])
+    gidx, oidx = mapper.Index(gen), mb.Index(gen)
+    try:
+        gopt, oopt = mapper.default_opt(mid_occ=100000), mb.default_opt(mid_occ=100000)
+        got = mapper.seed_chain_batch(gidx, gopt, reads)
+        tot = 0
+        for q, g in zip(reads, got):
+            mv = mb.sketch(q, 10, 15, 0)
+            a, rep = mb.collect_anchors(oidx, 100000, mv, len(q))
+            u, b = mb.chain(oopt, a)
+            assert g['n_anchor'] == len(a) and g['rep_len'] == rep
+            assert np.array_equal(g['u'], u) and np.array_equal(g['b'], b)
+            tot += len(a)
+        assert tot > 6 * 150000   # far more hits per read than the filter has counters
+    finally:
+        gidx.close()
+        oidx.close()
