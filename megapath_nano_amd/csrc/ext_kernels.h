@@ -615,7 +615,9 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
 //  * the substitution score is a bit-field extract: each row keeps its five scores (vs A,C,G,T,N) as 6-bit fields of one
 //    register and the query base travels as the field offset;
 //  * the gap states are stored without their -(q+e) offset, which folds into the three-operand adds of the next cell;
-//  * the direction is "first operand that equals the maximum", the continuation flags come from the new gap states;
+//  * the direction is "first operand that equals the maximum": the states are pre-scaled by 8 and the candidates carry their rank in
+//    the low bits, so one max gives value and direction (stored as the rank, decoded by the traceback); the continuation flags come
+//    from the new gap states;
 //  * the corner score is summed along row 0 and then down the last column, which costs one add per step.
 // Same recurrences, boundary rules and direction codes as ext_dp_kernel.  Directions are stored step-major: cell
 // (t, j) lives at [j + t/S][t], so the S bytes a lane produces in one step are contiguous and the whole wave writes one
@@ -660,7 +662,10 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-#define MPN_BND(R) ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2)
+    // All states are kept PRE-SCALED by 8: the low three bits of the five candidates of a cell then carry their rank (score
+    // 4, a 3, b 2, a2 1, b2 0), so ONE max yields both the cell's value and "the first operand that equals the maximum"
+    // (the direction) -- no compare/select chain.  Differences stay far below 2^12, so the 16-bit halves do not overflow.
+#define MPN_BND(R) (8 * ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2))
     // Difference states as pairs of 16-bit lanes of one register (they are small integers): the two gap types of a cell go
     // through v_pk_add/sub/max/min_i16 together.  UL: u of the previous column, both halves equal; YL: (y + (q+e) | y2 + (q2+e2))
     // of the previous column, both start at 0.  Vp: v of the row above, both halves equal; Xp: (x + (q+e) | x2 + (q2+e2)).
@@ -690,9 +695,11 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     uint8_t *prow = P + p_off + t0;
     int out_v = 0, out_x = 0, qsh = 24;
     int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
-    const s16x2 MQ = {(short)-qe, (short)-qe2}, Qp = {(short)q, (short)q2}, ZERO = {0, 0};
-    const u16x2 K7FFF = {0x7fff, 0x7fff}, SH15 = {15, 15};
-    const int mch = prm.sc_mch;
+    const s16x2 MQA = {(short)(-8 * qe + 3), (short)(-8 * qe2 + 1)}, MQB = {(short)(-8 * qe + 2), (short)(-8 * qe2)};
+    const s16x2 Qp = {(short)(8 * q), (short)(8 * q2)}, ZERO = {0, 0};
+    const uint32_t EIGHT = 0x00080008u;
+    const uint32_t RANK_CLR = 0xfff8fff8u;
+    const int mch8 = 8 * prm.sc_mch;
     const bool head = gl == 0;
     for (int step = 0; step < max_steps; ++step) {
         // query bases and bottom-row states move one lane to the right; the first lane of a group takes the boundary
@@ -704,34 +711,38 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         qsh = head ? q_in : qsh_s;
         s16x2 Vp = head ? bcast(bj) : __builtin_bit_cast(s16x2, v_s), Xp = head ? ZERO : __builtin_bit_cast(s16x2, x_s);
         if (j >= 0 && j < qlen && gl < n_lanes) {
-            uint32_t dw[(S + 3) / 4];
-#pragma unroll
-            for (int k = 0; k < (S + 3) / 4; ++k) dw[k] = 0;
+            uint32_t dw[(S + 3) / 4], dcell[4] = {0, 0, 0, 0};
             int nv0 = 0;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                const int sc = __builtin_amdgcn_sbfe((int)TB[k], qsh, 6);
+                const int sc8 = __builtin_amdgcn_sbfe((int)TB[k], qsh, 6) * 8 + 4;
                 const s16x2 Up = UL[k];
-                s16x2 A = Xp + Vp + MQ, B = YL[k] + Up + MQ;     // (a | a2), (b | b2)
+                s16x2 A = Xp + Vp + MQA, B = YL[k] + Up + MQB;   // 8 (a | a2) + (3 | 1), 8 (b | b2) + (2 | 0)
                 const s16x2 M = __builtin_elementwise_max(A, B);
-                const int z0 = max(max((int)M.x, (int)M.y), sc);
-                int d = 4;                 // first operand (sc, a, b, a2, b2) that equals the maximum
-                d = (int)A.y == z0 ? 3 : d;
-                d = (int)B.x == z0 ? 2 : d;
-                d = (int)A.x == z0 ? 1 : d;
-                d = sc == z0 ? 0 : d;
-                const s16x2 Zp = bcast(min(z0, mch));
+                const int z8 = max(max((int)M.x, (int)M.y), sc8);
+                int d = z8 & 7;            // rank of the winner; the traceback reads the operand index as 4 - rank
+                // both halves = min(z, match score), rank bits cleared: one byte permute + one mask
+                const s16x2 Zp = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)min(z8, mch8 + 7), 0u, 0x05040504u) & RANK_CLR);
                 const s16x2 nu = Zp - Vp, nv = Zp - Up, ZQ = Zp - Qp;
-                A = __builtin_elementwise_max(A - ZQ, ZERO);
-                B = __builtin_elementwise_max(B - ZQ, ZERO);
-                // (x > 0) for x >= 0, per half: (x + 0x7fff) >> 15 -- two packed ops instead of compare + select per half
-                const uint32_t H = __builtin_bit_cast(uint32_t, (__builtin_bit_cast(u16x2, A) + K7FFF) >> SH15) |
-                                   __builtin_bit_cast(uint32_t, (__builtin_bit_cast(u16x2, B) + K7FFF) >> SH15) << 1;
-                d |= (int)(H & 3u) << 3;   // a > 0, b > 0
-                d |= (int)(H >> 16) << 5;  // a2 > 0, b2 > 0
+                A = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, __builtin_elementwise_max(A - ZQ, ZERO)) & RANK_CLR);
+                B = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, __builtin_elementwise_max(B - ZQ, ZERO)) & RANK_CLR);
+                // Continuation flags (x > 0) of the four gap states, which are multiples of 8: min(x, 8) as unsigned leaves bit 3
+                // of each half (written as the instruction: the compiler turns the expression into compares and selects).
+                // F: bit 3 a, 4 b, 19 a2, 20 b2; the byte is rank | F | F >> 14 -- its bits above 7 are dropped by the byte
+                // permutes that assemble four cells into a word.
+                uint32_t HA, HB;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, A)), "v"(EIGHT));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, B)), "v"(EIGHT));
+                const uint32_t F = HA | HB << 1;
+                dcell[k & 3] = (uint32_t)d | F | F >> 14;
                 UL[k] = nu; YL[k] = B;
                 Vp = nv; Xp = A;
-                dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
+                if ((k & 3) == 3 || k == S - 1) {
+                    // bytes 0 of up to four cells -> one word (0x0c selects a zero byte)
+                    const uint32_t lo = __builtin_amdgcn_perm((k & 3) >= 1 ? dcell[1] : 0u, dcell[0], 0x0c0c0400u);
+                    const uint32_t hi = (k & 3) >= 2 ? __builtin_amdgcn_perm((k & 3) == 3 ? dcell[3] : 0u, dcell[2], 0x04000c0cu) : 0u;
+                    dw[k >> 2] = lo | hi;
+                }
                 if (k == 0) nv0 = (int)nv.x;
             }
             out_v = __builtin_bit_cast(int, Vp); out_x = __builtin_bit_cast(int, Xp);
@@ -750,11 +761,13 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     }
 #undef MPN_BND
     // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1); a lane's UL froze at its last column
-    int32_t tot = head ? row0 - qe : 0;
+    // (the sums are of pre-scaled differences, exact multiples of 8)
+    int32_t tot = head ? row0 - 8 * qe : 0;
 #pragma unroll
     for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x : 0;
 #pragma unroll
     for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
+    tot >>= 3;
     if (head && jid >= 0) {
         ExtRes out;
         out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = ok ? tot : NEG_INF;
@@ -819,7 +832,7 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     while (i >= 0 && j >= 0) {
         const int rr = i + j;
         int force_state = -1, tmp;
-        if (rowmajor) tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i];
+        if (rowmajor) { tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i]; tmp = (tmp & ~7) | (4 - (tmp & 7)); }  // (the strip kernel stores the winner's rank)
         else if (byslot) {
             int st = 0, en = jb.tlen - 1;
             if (st < rr - jb.qlen + 1) st = rr - jb.qlen + 1;
