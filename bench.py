@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--genomes', type=int, default=5000)
     ap.add_argument('--genome-len', type=int, default=4000000)
     ap.add_argument('--strain-pairs', type=int, default=10)
-    ap.add_argument('--reads-per-step', type=int, default=131072)
+    ap.add_argument('--reads-per-step', type=int, default=262144)
     ap.add_argument('--mean-len', type=int, default=8000)
     ap.add_argument('--distinct-batches', type=int, default=3)
     ap.add_argument('--pcie-steps', type=int, default=2, help='extra untimed-for-value steps fed from host buffers (PCIe-inclusive rate)')

@@ -1562,21 +1562,30 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     int n_threads = default_host_threads(opt);
     *n_threads_out = n_threads;
     g_pool.ensure(n_threads);
-    // sub-batches of ~24 Mbp run through a small pool of workers (8 by default), each with its own HIP streams and
+    // sub-batches of ~32 Mbp run through a small pool of workers (12 by default), each with its own HIP streams and
     // device arena, so that the host phases of one sub-batch overlap the GPU phases of the others and the
     // latency-bound kernels (chain DP, long extensions) of one overlap the throughput-bound ones of another
     int n_workers = 12;
     if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(16, atoi(e)));
     std::vector<int> cut{0};
     {
-        int64_t target = 24000000;
+        int64_t target = 32000000;
         if (const char *e = getenv("MPN_SUB_BATCH_BP")) target = std::max<int64_t>(1000, atoll(e));
         // equal-sized sub-batches, their count a multiple of the worker count so that no worker idles in the last round
         const int W = n_workers;
         std::vector<int64_t> sizes;
         int64_t n_cut = std::max<int64_t>(1, (bases + target - 1) / target);
         if (n_cut > W) n_cut = (n_cut + W - 1) / W * W;
-        for (int64_t i = 0; i < n_cut; ++i) sizes.push_back(std::max<int64_t>(1, (bases + n_cut - 1) / n_cut));
+        const int64_t full = std::max<int64_t>(1, (bases + n_cut - 1) / n_cut);
+        if (n_cut >= 2 * W && !getenv("MPN_NO_TAPER")) {
+            // the last round tapers (1/2, 1/4, 1/8, 1/8 of a sub-batch per worker): when the call drains, the GPU idles for a
+            // fraction of a small sub-batch instead of a fraction of a full one
+            for (int64_t i = 0; i < n_cut - W; ++i) sizes.push_back(full);
+            for (int part = 2; part <= 8; part *= 2)
+                for (int rep = 0; rep < (part == 8 ? 2 : 1) * W; ++rep) sizes.push_back(std::max<int64_t>(1, full / part));
+        } else {
+            for (int64_t i = 0; i < n_cut; ++i) sizes.push_back(full);
+        }
         size_t si = 0;
         int64_t acc = 0;
         for (int i = 0; i < n; ++i) {
