@@ -1576,16 +1576,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         std::vector<int64_t> sizes;
         int64_t n_cut = std::max<int64_t>(1, (bases + target - 1) / target);
         if (n_cut > W) n_cut = (n_cut + W - 1) / W * W;
-        const int64_t full = std::max<int64_t>(1, (bases + n_cut - 1) / n_cut);
-        if (n_cut >= 2 * W && !getenv("MPN_NO_TAPER")) {
-            // the last round tapers (1/2, 1/4, 1/8, 1/8 of a sub-batch per worker): when the call drains, the GPU idles for a
-            // fraction of a small sub-batch instead of a fraction of a full one
-            for (int64_t i = 0; i < n_cut - W; ++i) sizes.push_back(full);
-            for (int part = 2; part <= 8; part *= 2)
-                for (int rep = 0; rep < (part == 8 ? 2 : 1) * W; ++rep) sizes.push_back(std::max<int64_t>(1, full / part));
-        } else {
-            for (int64_t i = 0; i < n_cut; ++i) sizes.push_back(full);
-        }
+        for (int64_t i = 0; i < n_cut; ++i) sizes.push_back(std::max<int64_t>(1, (bases + n_cut - 1) / n_cut));
         size_t si = 0;
         int64_t acc = 0;
         for (int i = 0; i < n; ++i) {
