@@ -10,7 +10,7 @@ from megapath_nano_amd import _ffi, realigner
 from oracle import realign_oracle as ro
 from realign_cases import make_window
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('libmpn', 'oracle_built')]
 GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'realign_golden.json')
 KEYS = ('seqs', 'positions', 'cigars', 'reference', 'haplotypes', 'ref_start', 'ref_prefix', 'ref_suffix')
 

@@ -10,6 +10,7 @@ from oracle import realign_oracle as ro
 from oracle.realign_bindings import have_ref, ref_realign
 from realign_cases import make_window
 
+pytestmark = pytest.mark.usefixtures('oracle_built')
 GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'realign_golden.json')
 KEYS = ('seqs', 'positions', 'cigars', 'reference', 'haplotypes', 'ref_start', 'ref_prefix', 'ref_suffix')
 
