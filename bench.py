@@ -27,7 +27,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')  # before the HIP runtime starts: see megapath_nano_amd/__init__.py
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '20')  # before the HIP runtime starts: see megapath_nano_amd/__init__.py
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

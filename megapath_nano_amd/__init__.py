@@ -11,4 +11,4 @@ import os as _os
 
 # 8 pipeline workers x 2 HIP streams need more than ROCm's default 4 hardware queues (streams sharing a queue serialise);
 # the HIP runtime reads this when it initialises, so import this package before the first GPU call (see csrc/mpn_runtime.hip)
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '20')
