@@ -317,8 +317,8 @@ __global__ __launch_bounds__(1024) void scan_i64_kernel(const int64_t *__restric
 
 // ---------------------------------------------------------------------------------------------------------
 // seeds: one lane per read minimizer.  A bucket table over the top bits of the hash (bucket_start[b] = first key of bucket
-// b, 2^bucket_bits + 1 entries) narrows the binary search in the sorted key array to the dozen keys of one bucket:
-// two or three sectors per lookup instead of ~18 uncached probes over the whole array.
+// b, 2^bucket_bits + 1 entries, ~4 keys per bucket) narrows the binary search to one cache line of (key, first position)
+// pairs, which also holds the answer: two or three lines per lookup instead of ~18 uncached probes over the whole array.
 __global__ __launch_bounds__(256) void idx_bucket_table_kernel(const uint64_t *__restrict__ keys, int64_t n_keys, int shift, int64_t n_buckets,
                                                                int64_t *__restrict__ bucket_start) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_keys; i += (int64_t)gridDim.x * blockDim.x) {
@@ -329,7 +329,13 @@ __global__ __launch_bounds__(256) void idx_bucket_table_kernel(const uint64_t *_
     }
 }
 
-__global__ __launch_bounds__(256) void seed_lookup_kernel(const uint64_t *__restrict__ keys, const int64_t *__restrict__ key_off,
+__global__ __launch_bounds__(256) void idx_kv_kernel(const uint64_t *__restrict__ keys, const int64_t *__restrict__ key_off, int64_t n_keys,
+                                                     u128 *__restrict__ kv) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_keys; i += (int64_t)gridDim.x * blockDim.x)
+        kv[i] = u128{i < n_keys ? keys[i] : ~0ULL, (uint64_t)key_off[i]};
+}
+
+__global__ __launch_bounds__(256) void seed_lookup_kernel(const u128 *__restrict__ kv,
                                                           int64_t n_keys, const int64_t *__restrict__ bucket_start, int bucket_shift,
                                                           const u128 *__restrict__ mz, int64_t n_mz,
                                                           int32_t max_occ, int32_t *__restrict__ occ,
@@ -340,11 +346,14 @@ __global__ __launch_bounds__(256) void seed_lookup_kernel(const uint64_t *__rest
         int64_t lo = bucket_start[b], hi = bucket_start[b + 1];
         while (lo < hi) {
             int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+            if (kv[mid].x < key) lo = mid + 1; else hi = mid;
         }
         int32_t t = 0;
         int64_t st = 0;
-        if (lo < n_keys && keys[lo] == key) { st = key_off[lo]; t = (int32_t)min<int64_t>(key_off[lo + 1] - st, 0x7fffffff); }
+        if (lo < n_keys) {
+            const u128 e = kv[lo];
+            if (e.x == key) { st = (int64_t)e.y; t = (int32_t)min<int64_t>((int64_t)kv[lo + 1].y - st, 0x7fffffff); }
+        }
         occ[m] = t >= max_occ ? -1 : t;  // -1: repetitive, skipped (counts into rep_len)
         pos_start[m] = st;
     }

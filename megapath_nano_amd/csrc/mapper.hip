@@ -193,7 +193,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         n_blk.alloc((size_t)n + 1) || blk_base.alloc((size_t)n + 1) || span_sum.alloc(n) || o.rep_len.alloc(n) || o.anchor_off.alloc((size_t)n + 1))
         return -1;
     if (n_mz > 0) {
-        hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p,
+        hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, (const u128 *)idx->kv.p,
                            idx->n_keys, (const int64_t *)idx->bucket_start.p, idx->bucket_shift, mz.p, n_mz, mid_occ, occ.p, pos_start.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(11, 35);
@@ -608,13 +608,19 @@ mpn_index *mpn_index_build_device(int32_t n_seq, const char *const *names, const
 }
 
 // bucket table over the sorted keys (see seed_lookup_kernel); rebuilt from the keys, so it is not part of the file format
+// and the lookup's own copy of the keys: (key, first position) pairs in one array, so that the binary search inside a bucket
+// and the hit range it ends on share a cache line.  Buckets are sized for ~4 keys (one 64-byte line): a lookup touches the
+// bucket table and one or two lines of pairs instead of three dependent arrays.
 static int build_bucket_table(mpn_index *idx, hipStream_t st) {
-    const int hbits = 2 * idx->k, bbits = std::min(24, hbits);
+    int want = 8;
+    while (want < 26 && ((int64_t)1 << (want + 2)) < idx->n_keys) ++want;
+    const int hbits = 2 * idx->k, bbits = std::min(want, hbits);
     idx->bucket_shift = hbits - bbits;
     const int64_t nb = (int64_t)1 << bbits;
-    if (idx->bucket_start.alloc((size_t)nb + 1)) return -1;
+    if (idx->bucket_start.alloc((size_t)nb + 1) || idx->kv.alloc((size_t)idx->n_keys + 1)) return -1;
     hipLaunchKernelGGL(idx_bucket_table_kernel, dim3(grid_1d(idx->n_keys + 1, 256)), dim3(256), 0, st, idx->keys.p, idx->n_keys,
                        idx->bucket_shift, nb, idx->bucket_start.p);
+    hipLaunchKernelGGL(idx_kv_kernel, dim3(grid_1d(idx->n_keys + 1, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p, idx->n_keys, idx->kv.p);
     MPN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -48,6 +48,7 @@ struct mpn_index {
     mpn::DevBuf<uint64_t> keys, pos;
     mpn::DevBuf<int64_t> key_off;
     mpn::DevBuf<int64_t> bucket_start;  // first key of every hash bucket (top bucket_bits of the 2k-bit hash), + end sentinel
+    mpn::DevBuf<mpn::u128> kv;          // (key, key_off) pairs + end sentinel: what seed_lookup_kernel reads
     int bucket_shift = 0;
     mpn::DevBuf<uint32_t> d_seq2;     // device: targets packed 2 bits per base
     mpn::DevBuf<int64_t> d_seq_off, d_nrun_s, d_nrun_e;  // + ambiguous-base runs (concatenated coordinates)
