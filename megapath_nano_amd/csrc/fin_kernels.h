@@ -54,9 +54,65 @@ __global__ __launch_bounds__(64) void aln_finish_wave_kernel(const FinJob *__res
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];
         const int64_t g0 = rv.seq_off[jb.rid] + jb.rs1;
-        if constexpr (IN_LDS) for (int i = lane; i < n; i += 64) c_l[i] = cg[i];
-        for (int x = lane; x < jb.qspan; x += 64) q_l[x] = ext_qbase(reads, roff, rlen, jb.rev, jb.qs1 + x);
-        for (int x = lane; x < jb.tspan; x += 64) t_l[x] = (uint8_t)ref_code(rv, g0 + x);
+        // Staging is a chain of global-load latencies for a single wave, so the loads are batched: eight per lane in flight
+        // for the CIGAR and the query bytes, and the target comes as whole 2-bit words (16 bases per load).
+        if constexpr (IN_LDS) {
+            for (int i0 = 0; i0 < n; i0 += 512) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; v[u] = i < n ? cg[i] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; if (i < n) c_l[i] = v[u]; }
+            }
+        }
+        for (int x0 = 0; x0 < jb.qspan; x0 += 512) {
+            uint8_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = x0 + u * 64 + lane;
+                v[u] = x < jb.qspan ? reads[roff + (jb.rev ? rlen - 1 - (jb.qs1 + x) : jb.qs1 + x)] : (uint8_t)'N';
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = x0 + u * 64 + lane;
+                if (x < jb.qspan) { const int c = nt4_code(v[u]); q_l[x] = (uint8_t)(jb.rev ? (c < 4 ? 3 - c : 4) : c); }
+            }
+        }
+        {
+            // lane i of a round unpacks target bases [16 i, 16 i + 16) of the interval from the two words that hold them
+            const int n16 = (jb.tspan + 15) >> 4;
+            const int sh = 2 * (int)(g0 & 15);
+            const int64_t w0 = g0 >> 4, w_last = (g0 + (jb.tspan > 0 ? jb.tspan - 1 : 0)) >> 4;
+            for (int i0 = 0; i0 < n16; i0 += 128) {
+                unsigned long long w[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    w[u] = 0;
+                    if (i < n16) {  // (the second word only where the interval reaches into it: it may lie past the array)
+                        const unsigned long long lo = rv.seq2[w0 + i], hi = sh && w0 + i + 1 <= w_last ? rv.seq2[w0 + i + 1] : 0u;
+                        w[u] = sh ? (lo >> sh | hi << (32 - sh)) & 0xffffffffULL : lo;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i < n16) {
+                        const int x = i << 4, m = min(16, jb.tspan - x);
+                        for (int b = 0; b < m; ++b) t_l[x + b] = (uint8_t)(w[u] >> (2 * b) & 3);
+                    }
+                }
+            }
+            if (rv.n_runs > 0) {   // ambiguous-base runs that overlap the interval (rare; uniform search)
+                sync();
+                int lo = 0, hi = rv.n_runs;  // first run that ends after g0
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (rv.nrun_e[mid] <= g0) lo = mid + 1; else hi = mid; }
+                for (; lo < rv.n_runs && rv.nrun_s[lo] < g0 + jb.tspan; ++lo) {
+                    const int64_t a = rv.nrun_s[lo] > g0 ? rv.nrun_s[lo] - g0 : 0, b = (rv.nrun_e[lo] < g0 + jb.tspan ? rv.nrun_e[lo] : g0 + jb.tspan) - g0;
+                    for (int64_t x = a + lane; x < b; x += 64) t_l[x] = 4;
+                }
+            }
+        }
         sync();
         int qshift = 0, tshift = 0;
         if (n > 1) {
