@@ -1291,14 +1291,17 @@ static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadS
         }
     }, 9);
     // launch lists by LDS need (CIGAR, shift table, both code arrays): three LDS classes, the rest works in global scratch
-    static const size_t kLds[3] = {(size_t)16 << 10, (size_t)32 << 10, (size_t)64 << 10};
-    std::vector<int32_t> lists[4];
+    // (a fourth class of 152 KB for the longest alignments runs them faster but blocks whole CUs: -2 % under the full pipeline)
+    constexpr int NC = 3;  // LDS classes; list NC works in global scratch
+    static const size_t kLds[NC] = {(size_t)16 << 10, (size_t)32 << 10, (size_t)64 << 10};
+    std::vector<int32_t> lists[NC + 1];
     int64_t code_bytes = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const size_t codes = (size_t)((h_jobs[j].qspan + 3) & ~3) + (size_t)((h_jobs[j].tspan + 3) & ~3);
         const size_t need = (size_t)h_jobs[j].n_cigar * 8 + codes + 16;
-        const int c = need <= kLds[0] ? 0 : need <= kLds[1] ? 1 : need <= kLds[2] ? 2 : 3;
-        if (c == 3) { h_jobs[j].code_off = code_bytes; code_bytes += (int64_t)codes; }
+        int c = 0;
+        while (c < NC && need > kLds[c]) ++c;
+        if (c == NC) { h_jobs[j].code_off = code_bytes; code_bytes += (int64_t)codes; }
         lists[c].push_back(j);
     }
     DevBuf<uint32_t> d_cig, d_aux;
@@ -1306,7 +1309,7 @@ static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     DevBuf<FinJob> d_jobs;
     DevBuf<FinOut> d_out;
     if (d_cig.alloc((size_t)n_ops) || d_jobs.alloc((size_t)n_jobs) || d_out.alloc((size_t)n_jobs)) return -1;
-    if (!lists[3].empty() && (d_aux.alloc((size_t)n_ops) || d_codes.alloc((size_t)code_bytes + 16))) return -1;
+    if (!lists[NC].empty() && (d_aux.alloc((size_t)n_ops) || d_codes.alloc((size_t)code_bytes + 16))) return -1;
     MPN_HIP_CHECK(hipMemcpyAsync(d_cig.p, h_cig, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
     MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, h_jobs, (size_t)n_jobs * sizeof(FinJob), hipMemcpyHostToDevice, st));
     FinParams prm;
@@ -1314,21 +1317,21 @@ static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     for (int i = 0; i < 5; ++i) prm.mat[20 + i] = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e;
     std::vector<int32_t> order;
-    int base[4];
-    for (int c = 0; c < 4; ++c) { base[c] = (int)order.size(); order.insert(order.end(), lists[c].begin(), lists[c].end()); }
+    int base[NC + 1];
+    for (int c = 0; c <= NC; ++c) { base[c] = (int)order.size(); order.insert(order.end(), lists[c].begin(), lists[c].end()); }
     DevBuf<int32_t> d_list;
     if (d_list.upload(order.data(), order.size(), st)) return -1;
     const RefView rvw{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
     EvTimer ev(st);
     static std::once_flag fin_attr;
-    std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[2]); });
-    for (int c = 0; c < 3; ++c)
+    std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[NC - 1]); });
+    for (int c = 0; c < NC; ++c)
         if (!lists[c].empty())
             hipLaunchKernelGGL(aln_finish_wave_kernel<true>, dim3((unsigned)std::min<size_t>(lists[c].size(), 256 * 64)), dim3(64), kLds[c], st, (const FinJob *)d_jobs.p,
                                (const int32_t *)d_list.p + base[c], (int)lists[c].size(), d_cig.p, (uint32_t *)nullptr, (uint8_t *)nullptr, d_seqs, d_off, d_len, rvw, prm, d_out.p);
-    if (!lists[3].empty())
-        hipLaunchKernelGGL(aln_finish_wave_kernel<false>, dim3((unsigned)std::min<size_t>(lists[3].size(), 256 * 64)), dim3(64), 0, st, (const FinJob *)d_jobs.p,
-                           (const int32_t *)d_list.p + base[3], (int)lists[3].size(), d_cig.p, d_aux.p, d_codes.p, d_seqs, d_off, d_len, rvw, prm, d_out.p);
+    if (!lists[NC].empty())
+        hipLaunchKernelGGL(aln_finish_wave_kernel<false>, dim3((unsigned)std::min<size_t>(lists[NC].size(), 256 * 64)), dim3(64), 0, st, (const FinJob *)d_jobs.p,
+                           (const int32_t *)d_list.p + base[NC], (int)lists[NC].size(), d_cig.p, d_aux.p, d_codes.p, d_seqs, d_off, d_len, rvw, prm, d_out.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(52);
     MPN_HIP_CHECK(hipMemcpyAsync(h_out, d_out.p, (size_t)n_jobs * sizeof(FinOut), hipMemcpyDeviceToHost, st));

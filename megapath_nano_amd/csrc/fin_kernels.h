@@ -65,17 +65,33 @@ __global__ __launch_bounds__(64) void aln_finish_wave_kernel(const FinJob *__res
                 for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; if (i < n) c_l[i] = v[u]; }
             }
         }
-        for (int x0 = 0; x0 < jb.qspan; x0 += 512) {
-            uint8_t v[8];
+        for (int x0 = 0; x0 < jb.qspan; x0 += 4 * 64 * 4) {   // four loads in flight per lane, four bases (one word) per load
+            uint32_t v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int x = x0 + u * 64 + lane;
-                v[u] = x < jb.qspan ? reads[roff + (jb.rev ? rlen - 1 - (jb.qs1 + x) : jb.qs1 + x)] : (uint8_t)'N';
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + 4 * (u * 64 + lane);
+                v[u] = 0x4e4e4e4eu;   // "NNNN"
+                if (x < jb.qspan) {
+                    // the four bases x .. x+3 on the hit's strand: ascending addresses, or (reverse strand) descending from
+                    // rlen-1-(qs1+x); the reads buffer is padded, so the word may reach a few bytes past the read
+                    const int64_t a = roff + (jb.rev ? rlen - 1 - (jb.qs1 + x) - 3 : jb.qs1 + x);
+                    if (a >= 0) __builtin_memcpy(&v[u], reads + a, 4);
+                    else for (int j = 0; j < 4; ++j) if (a + j >= 0) reinterpret_cast<uint8_t *>(&v[u])[j] = reads[a + j];
+                    if (jb.rev) v[u] = __builtin_bswap32(v[u]);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int x = x0 + u * 64 + lane;
-                if (x < jb.qspan) { const int c = nt4_code(v[u]); q_l[x] = (uint8_t)(jb.rev ? (c < 4 ? 3 - c : 4) : c); }
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + 4 * (u * 64 + lane);
+                if (x < jb.qspan) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = nt4_code((uint8_t)(v[u] >> (8 * j)));
+                        packed |= (uint32_t)(jb.rev ? (c < 4 ? 3 - c : 4) : c) << (8 * j);
+                    }
+                    *reinterpret_cast<uint32_t *>(q_l + x) = packed;   // (q_l and x are 4-aligned; the array is padded to a multiple of 4)
+                }
             }
         }
         {
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(64) void aln_finish_wave_kernel(const FinJob *__res
             for (int k = k_lo; k < k_hi; ++k) { const uint32_t op = c_l[k] & 0xf, len = c_l[k] >> 4; qa += op != 2 ? len : 0; ta += op != 1 ? len : 0; }
             int qoff = qshift + excl_scan(qa), toff = tshift + excl_scan(ta);
             int32_t blen = 0, mlen = 0, n_ambi_all = 0;
+            const int sc_mch = prm.mat[0], sc_mis = prm.mat[1], sc_amb = prm.mat[4];
             // the lane's columns as one map: D total, P running prefix, mn its minimum, PM its maximum, CM the largest P - min so far
             int32_t P = 0, mn = 0, PM = NEG_INF, CM = 0;
             bool first = true;
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(64) void aln_finish_wave_kernel(const FinJob *__res
                         const int cq = q_l[qoff + (int)l], ct = t_l[toff + (int)l];
                         if (ct > 3 || cq > 3) ++n_ambi;
                         else if (ct != cq) ++n_diff;
-                        step(prm.mat[ct * 5 + cq]);
+                        step(ct > 3 || cq > 3 ? sc_amb : ct == cq ? sc_mch : sc_mis);   // (not a table in the kernel arguments: that is a global load per column)
                     }
                     blen += len - n_ambi; mlen += len - (n_ambi + n_diff); n_ambi_all += n_ambi;
                     toff += len; qoff += len;
