@@ -456,7 +456,8 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                                                                   const int64_t *__restrict__ full_off, const int64_t *__restrict__ blk_base,
                                                                   const int32_t *__restrict__ order, FilterParams fp,
                                                                   unsigned long long *__restrict__ keep,
-                                                                  int64_t *__restrict__ blk_kept, int32_t *__restrict__ blk_read) {
+                                                                  int64_t *__restrict__ blk_kept, int32_t *__restrict__ blk_read,
+                                                                  unsigned int *__restrict__ next_read) {
     extern __shared__ uint32_t flt_lds[];
     uint32_t *bm = flt_lds;                                            // [table A1, A2, B1, B2][level][FLT_WORDS]
     // per wave: the block's minimizers that have hits, compacted -- index position of the first hit | parity << 62,
@@ -464,12 +465,20 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
     unsigned long long *ps_all = (unsigned long long *)(flt_lds + 12 * FLT_WORDS);
     unsigned long long *sb_all = ps_all + FLT_WAVES * 64;
     uint32_t *g_all = (uint32_t *)(sb_all + FLT_WAVES * (FLT_CHUNK / 64));
-    uint32_t *next_blk = g_all + FLT_WAVES * 64;                       // [2]: the block queue of each pass
+    uint32_t *next_blk = g_all + FLT_WAVES * 64;                       // [2]: the block queue of each pass; [2]: the read taken
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned long long *ps = ps_all + wv * 64, *sb = sb_all + wv * (FLT_CHUNK / 64);
     uint32_t *g = g_all + wv * 64;
     const unsigned long long lane_le = lane == 63 ? ~0ULL : (2ULL << lane) - 1;
-    for (int ri = blockIdx.x; ri < n_reads; ri += gridDim.x) {
+    // Persistent workgroups (one per CU) take reads from a counter: a grid of one workgroup per read would keep its hardware
+    // queue's dispatcher busy for the whole kernel (each workgroup needs a whole CU), and every kernel behind it on that
+    // pipe -- of any worker -- waits to be dispatched.
+    for (;;) {
+        if (tid == 0) next_blk[2] = atomicAdd(next_read, 1u);
+        __syncthreads();
+        const int ri = (int)next_blk[2];
+        __syncthreads();
+        if (ri >= n_reads) break;
         const int read = order[ri];                                    // reads with many hits first (the grid's long pole)
         const int64_t m0 = mz_off[read], m1 = mz_off[read + 1];
         const int64_t v0 = full_off[read];

@@ -189,8 +189,16 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<int32_t> occ;
     DevBuf<int64_t> pos_start, rel_off, full_off, n_blk, blk_base;
     DevBuf<unsigned long long> span_sum;
-    if (occ.alloc(n_mz) || pos_start.alloc(n_mz) || rel_off.alloc(n_mz) || o.n_anchor.alloc((size_t)n + 1) || full_off.alloc((size_t)n + 1) ||
-        n_blk.alloc((size_t)n + 1) || blk_base.alloc((size_t)n + 1) || span_sum.alloc(n) || o.rep_len.alloc(n) || o.anchor_off.alloc((size_t)n + 1))
+    {   // layout of the read-back block (download_chains copies it in one piece): five int64[N] tables, two int32[N], the counters
+        const size_t N = (size_t)n, o1 = (N + 1) * 8, o2 = o1 + N * 8, o3 = o2 + N * 8, o4 = o3 + N * 8, o5 = o4 + N * 4, o6 = (o5 + N * 4 + 7) & ~(size_t)7;
+        o.tables_bytes = o6 + (size_t)(2 + WORK_SLOTS) * 8;
+        if (o.tables.alloc(o.tables_bytes)) return -1;
+        auto view = [&](auto &buf, size_t off, size_t count) { buf.release(); buf.p = reinterpret_cast<decltype(buf.p)>(o.tables.p + off); buf.n = count; buf.owned = false; };
+        view(o.n_anchor, 0, N + 1); view(o.n_chained, o1, N); view(o.u_pos, o2, N); view(o.b_pos, o3, N);
+        view(o.n_chain, o4, N); view(o.rep_len, o5, N); view(o.used, o6, 2 + WORK_SLOTS);
+    }
+    if (occ.alloc(n_mz) || pos_start.alloc(n_mz) || rel_off.alloc(n_mz) || full_off.alloc((size_t)n + 1) ||
+        n_blk.alloc((size_t)n + 1) || blk_base.alloc((size_t)n + 1) || span_sum.alloc(n) || o.anchor_off.alloc((size_t)n + 1))
         return -1;
     if (n_mz > 0) {
         hipLaunchKernelGGL(seed_lookup_kernel, dim3(grid_1d(n_mz, 256)), dim3(256), 0, st, (const u128 *)idx->kv.p,
@@ -212,7 +220,8 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<unsigned long long> keep;
     DevBuf<int64_t> blk_kept, blk_off;
     DevBuf<int32_t> blk_read, order;
-    if (order.alloc(n) || keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
+    DevBuf<unsigned int> next_read;
+    if (next_read.alloc(4) || next_read.zero(st) || order.alloc(n) || keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
         blk_read.alloc((size_t)nb_cap + 1) || blk_kept.zero(st))
         return -1;
     if (nb_cap > 0x7fffffff) { set_error("sub-batch too large for the seed filter"); return -1; }
@@ -231,9 +240,9 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             (void)hipFuncSetAttribute((const void *)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLT_LDS_BYTES);
         });
         hipLaunchKernelGGL(seed_order_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)o.n_anchor.p, n, order.p);
-        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, 1 << 20))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
+        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, 256))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
                            pos_start.p, rel_off.p, idx->pos.p, (const int64_t *)full_off.p, (const int64_t *)blk_base.p, (const int32_t *)order.p,
-                           fp, keep.p, blk_kept.p, blk_read.p);
+                           fp, keep.p, blk_kept.p, blk_read.p, next_read.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(11, 50);
     }
@@ -246,9 +255,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     o.n_anchors = n_a;
     g_stats[51] += n_a;
     DevBuf<u128> tmp;
-    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n) || o.n_chain.alloc(n) || o.n_chained.alloc(n) ||
-        o.u_pos.alloc(n) || o.b_pos.alloc(n) || o.used.alloc(2 + WORK_SLOTS) || o.used.zero(st))
-        return -1;
+    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n) || o.used.zero(st)) return -1;
     ev.mark(11);
     if (n_a > 0) {
         // kept hits in (minimizer, hit) order -> tmp; partition per read on the top key bits -> o.anchors; small buckets are
@@ -375,19 +382,14 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolB
     h.n_anchor.resize((size_t)n);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
     unsigned long long used[2 + WORK_SLOTS] = {0};
-    {   // the per-read tables: one pinned staging block, one wait
+    {   // the per-read tables: one device block, one pinned staging block, one copy, one wait
         const size_t N = (size_t)n;
-        const size_t o0 = 0, o1 = o0 + (N + 1) * 8, o2 = o1 + N * 8, o3 = o2 + N * 8, o4 = o3 + N * 8, o5 = o4 + N * 4, o6 = o5 + N * 4,
-                     tot = o6 + sizeof(used);
-        char *pn = (char *)tl_pin.get(tot + 64);
+        const size_t o1 = (N + 1) * 8, o2 = o1 + N * 8, o3 = o2 + N * 8, o4 = o3 + N * 8, o5 = o4 + N * 4, o6 = (o5 + N * 4 + 7) & ~(size_t)7;
+        char *pn = (char *)tl_pin.get(o.tables_bytes + 64);
         if (!pn) { set_error("pinned scratch allocation failed"); return -1; }
-        if (o.n_anchor.download((int64_t *)(pn + o0), N, st) || o.n_chained.download((int64_t *)(pn + o1), N, st) ||
-            o.u_pos.download((int64_t *)(pn + o2), N, st) || o.b_pos.download((int64_t *)(pn + o3), N, st) ||
-            o.n_chain.download((int32_t *)(pn + o4), N, st) || o.rep_len.download((int32_t *)(pn + o5), N, st) ||
-            o.used.download((unsigned long long *)(pn + o6), 2 + WORK_SLOTS, st))
-            return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(pn, o.tables.p, o.tables_bytes, hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(stream_sync(st));
-        memcpy(h.n_anchor.data(), pn + o0, N * 8); memcpy(h.n_chained.data(), pn + o1, N * 8);
+        memcpy(h.n_anchor.data(), pn, N * 8); memcpy(h.n_chained.data(), pn + o1, N * 8);
         memcpy(h.u_pos.data(), pn + o2, N * 8); memcpy(h.b_pos.data(), pn + o3, N * 8);
         memcpy(h.n_chain.data(), pn + o4, N * 4); memcpy(h.rep_len.data(), pn + o5, N * 4);
         memcpy(used, pn + o6, sizeof(used));

@@ -64,6 +64,10 @@ struct u128;
 
 struct SeedChainOut {
     int64_t n_anchors = 0;
+    // the per-read tables the host reads back (n_anchor, n_chained, u_pos, b_pos, n_chain, rep_len, used) are slices of ONE
+    // block: a single device-to-host copy instead of seven (a copy is a queue round trip, and queues are shared)
+    DevBuf<unsigned char> tables;
+    size_t tables_bytes = 0;
     DevBuf<int64_t> n_anchor;                                    // per read: index hits of its minimizers (what minimap2 calls n_a)
     DevBuf<int64_t> anchor_off, c_off, n_chained, u_pos, b_pos;  // anchor_off: CSR of the hits that passed the stray-hit filter; c_off: of those kept for chaining
     DevBuf<int32_t> rep_len, n_ends, n_chain;
