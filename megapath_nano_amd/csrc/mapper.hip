@@ -478,10 +478,9 @@ static int pack_targets_device(mpn_index *idx, const uint8_t *d_seqs, int64_t to
     std::sort(ns.begin(), ns.end());
     std::sort(ne.begin(), ne.end());
     idx->n_nruns = (int32_t)ns.size();
-    idx->h_seq2.resize((size_t)n_words);
-    if (idx->d_seq2.download(idx->h_seq2.data(), (size_t)n_words, st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
-        idx->d_nrun_e.upload(ne.data(), ne.size(), st))
-        return -1;
+    // (no host copy of the packed targets: since the CIGAR fix-up moved to the GPU nothing on the host reads target bases;
+    // mpn_index_save fetches the words when it needs them)
+    if (idx->d_nrun_s.upload(ns.data(), ns.size(), st) || idx->d_nrun_e.upload(ne.data(), ne.size(), st)) return -1;
     MPN_HIP_CHECK(stream_sync(st));
     idx->h_nrun_s.swap(ns); idx->h_nrun_e.swap(ne);
     return 0;
@@ -636,12 +635,12 @@ int mpn_index_save(const mpn_index *idx, const char *path) {
     if (!idx || !path) { set_error("mpn_index_save: null argument"); return -1; }
     hipStream_t st = 0;
     const int64_t total = idx->seq_off.empty() ? 0 : idx->seq_off.back();
-    const std::vector<uint32_t> &words = idx->h_seq2;
+    std::vector<uint32_t> words(idx->d_seq2.n);
     const std::vector<int64_t> &ns = idx->h_nrun_s, &ne = idx->h_nrun_e;
     std::vector<uint64_t> keys((size_t)idx->n_keys), pos((size_t)idx->n_mz);
     std::vector<int64_t> h_key_off((size_t)idx->n_keys + 1);
     if (idx->keys.download(keys.data(), keys.size(), st) || idx->pos.download(pos.data(), pos.size(), st) ||
-        idx->key_off.download(h_key_off.data(), h_key_off.size(), st))
+        idx->key_off.download(h_key_off.data(), h_key_off.size(), st) || idx->d_seq2.download(words.data(), words.size(), st))
         return -1;
     MPN_HIP_CHECK(stream_sync(st));
     FILE *f = fopen(path, "wb");
@@ -736,6 +735,7 @@ mpn_index *mpn_index_load(const char *path) {
         return nullptr;
     }
     idx->h_nrun_s.swap(ns); idx->h_nrun_e.swap(ne);
+    std::vector<uint32_t>().swap(idx->h_seq2);   // (only the staging of the load)
     return idx;
 }
 

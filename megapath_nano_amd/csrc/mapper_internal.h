@@ -23,27 +23,8 @@ struct mpn_index {
     std::vector<std::string> names;
     std::vector<int32_t> lens;
     std::vector<int64_t> seq_off;     // host: offset of each target in concatenated coordinates
-    // host copy of the packed targets (the CIGAR fix-up of the hit bookkeeping reads target slices): 2 bits per base +
-    // the ambiguous-base runs, i.e. 0.25 byte per target base instead of a byte
-    std::vector<uint32_t> h_seq2;
-    std::vector<int64_t> h_nrun_s, h_nrun_e;
-    // codes (0..4) of concatenated positions [g, g + len) into out
-    void fetch_codes(int64_t g, int64_t len, uint8_t *out) const {
-        static const struct Unpack4 {  // the four codes of a packed byte, one per output byte
-            uint32_t t[256];
-            Unpack4() { for (uint32_t b = 0; b < 256; ++b) t[b] = (b & 3) | (b >> 2 & 3) << 8 | (b >> 4 & 3) << 16 | (b >> 6 & 3) << 24; }
-        } u4;
-        const uint8_t *bytes = (const uint8_t *)h_seq2.data();  // base j: byte j >> 2, bits 2 (j & 3) (little-endian words)
-        int64_t i = 0;
-        for (; i < len && ((g + i) & 3); ++i) out[i] = (uint8_t)(bytes[(g + i) >> 2] >> (2 * ((g + i) & 3)) & 3);
-        for (; i + 4 <= len; i += 4) memcpy(out + i, &u4.t[bytes[(g + i) >> 2]], 4);
-        for (; i < len; ++i) out[i] = (uint8_t)(bytes[(g + i) >> 2] >> (2 * ((g + i) & 3)) & 3);
-        if (h_nrun_s.empty() || len <= 0) return;
-        size_t lo = 0, hi = h_nrun_s.size();  // first run that ends after g
-        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (h_nrun_e[mid] <= g) lo = mid + 1; else hi = mid; }
-        for (; lo < h_nrun_s.size() && h_nrun_s[lo] < g + len; ++lo)
-            for (int64_t i = h_nrun_s[lo] > g ? h_nrun_s[lo] : g; i < h_nrun_e[lo] && i < g + len; ++i) out[i - g] = 4;
-    }
+    std::vector<uint32_t> h_seq2;               // staging of mpn_index_load only (the packed targets live in d_seq2)
+    std::vector<int64_t> h_nrun_s, h_nrun_e;    // ambiguous-base runs (concatenated coordinates), kept for mpn_index_save
     int64_t n_keys = 0, n_mz = 0;
     mpn::DevBuf<uint64_t> keys, pos;
     mpn::DevBuf<int64_t> key_off;
