@@ -1,4 +1,4 @@
-# run on the GPU box: kernel trace (no stats) of the default 8-worker bench; analysis of the timed steps
+# run on the GPU box: kernel trace (no stats) of the default bench; analysis of the timed steps
 set -e
 export TMPDIR=/tmp
 O=gpurun_out/prof_tr
