@@ -84,6 +84,10 @@ int64_t mpn_index_n_minimizers(const mpn_index *idx);
 int64_t mpn_index_n_keys(const mpn_index *idx);
 /* occurrence cut-off for a given -f (minimap2: mm_idx_cal_max_occ) */
 int32_t mpn_index_mid_occ(const mpn_index *idx, float frac);
+/* bases [start, start+len) of target i as upper-case ASCII (ambiguous bases come back as 'N'), decoded from the 2-bit
+ * targets resident in HBM: what a checker of PAF lines needs when the target set is too large to keep on the host
+ * (bench.py's correctness block).  Returns len, or a negative error (range outside the target). */
+int64_t mpn_index_fetch_seq(const mpn_index *idx, int32_t i, int64_t start, int64_t len, char *out);
 /* copies of index arrays for the parity tests: keys[n_keys], key_off[n_keys+1], pos[n_minimizers] */
 int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uint64_t *pos);
 

@@ -1537,6 +1537,11 @@ static int default_host_threads(const mpn_map_opt *opt) {
         // step is short enough that a burst waiting for a free pool thread costs more than the quota's throttling (measured
         // on a 16-CPU quota: 16 threads 84.7, 24: 86.4, 32: 88.2, 48: 84.1 Gbp/min)
         if (quota > 0 && period > 0) n = std::min(n, 2 * std::max(1, (int)((quota + period - 1) / period)));
+        // one process per GPU: the ranks of a node share its cores (bench.py / the launcher export the rank count)
+        int ranks = 1;
+        if (const char *e = getenv("MPN_RANKS_ON_NODE")) ranks = std::max(1, atoi(e));
+        else if (const char *e2 = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e2));
+        n = std::max(2, n / ranks);
         return n;
     }();
     return detected;

@@ -793,6 +793,28 @@ int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
     return (int32_t)(v + 1);
 }
 
+__global__ void idx_decode_kernel(RefView rv, int64_t g0, int64_t len, char *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) out[i] = "ACGTN"[ref_code(rv, g0 + i)];
+}
+
+int64_t mpn_index_fetch_seq(const mpn_index *idx, int32_t i, int64_t start, int64_t len, char *out) {
+    if (!idx || !out || i < 0 || i >= idx->n_seq || start < 0 || len < 0 || start + len > idx->lens[(size_t)i]) {
+        set_error("mpn_index_fetch_seq: range outside the target");
+        return -2;
+    }
+    if (len == 0) return 0;
+    hipStream_t st = 0;
+    DevBuf<char> d;
+    if (d.alloc((size_t)len)) return -1;
+    const RefView rv{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
+    hipLaunchKernelGGL(idx_decode_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, rv, idx->seq_off[(size_t)i] + start, len, d.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    if (d.download(out, (size_t)len, st)) return -1;
+    MPN_HIP_CHECK(stream_sync(st));
+    return len;
+}
+
 int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uint64_t *pos) {
     hipStream_t st = 0;
     if (idx->keys.download(keys, (size_t)idx->n_keys, st) || idx->key_off.download(key_off, (size_t)idx->n_keys + 1, st) ||

@@ -49,6 +49,8 @@ def _bind():
         lib.mpn_index_n_keys.restype = ct.c_int64
         lib.mpn_index_mid_occ.argtypes = [P, ct.c_float]
         lib.mpn_index_mid_occ.restype = ct.c_int32
+        lib.mpn_index_fetch_seq.argtypes = [P, ct.c_int32, ct.c_int64, ct.c_int64, ct.c_char_p]
+        lib.mpn_index_fetch_seq.restype = ct.c_int64
         lib.mpn_index_export.argtypes = [P, P, P, P]
         lib.mpn_index_export.restype = ct.c_int
         lib.mpn_sam_header.argtypes = [P, ct.c_char_p, ct.c_char_p, ct.c_int64]
@@ -217,6 +219,14 @@ class Index:
 
     def mid_occ(self, f=2e-4):
         return _bind().mpn_index_mid_occ(self.h, f)
+
+    def fetch_seq(self, i, start, length):
+        """bases [start, start+length) of target i as bytes, decoded from the packed targets in HBM"""
+        buf = ct.create_string_buffer(int(length) + 1)
+        r = _bind().mpn_index_fetch_seq(self.h, int(i), int(start), int(length), buf)
+        if r < 0:
+            raise _ffi.MpnError(f'mpn_index_fetch_seq rc={r}: {_ffi.last_error()}')
+        return buf.raw[:r]
 
     def export(self):
         keys = np.zeros(self.n_keys, dtype=np.uint64)

@@ -138,15 +138,18 @@ def make_genomes_device(seed, n_genomes, length, strain_pairs, device, repeats=T
 
 
 def make_reads_device(seed, genomes_flat, genome_len, n_reads, weights, device, mean_len=8000, min_len=200,
-                      sub=0.04, ins=0.03, dele=0.05, chunk_reads=8192):
+                      sub=0.04, ins=0.03, dele=0.05, chunk_reads=8192, return_truth=False):
     """ONT-like reads sampled from device-resident genomes.
-    -> (uint8 tensor of the concatenated reads (padded by 16 bytes), int64 offsets, int32 lengths) on `device`."""
+    -> (uint8 tensor of the concatenated reads (padded by 16 bytes), int64 offsets, int32 lengths) on `device`;
+    with return_truth also the origin of every read as host arrays: dict(genome, start, end, rev)."""
     import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
     w = torch.as_tensor(np.asarray(weights, dtype=np.float64) / float(np.sum(weights)), device=device, dtype=torch.float32)
     gamma = torch.distributions.Gamma(torch.tensor(1.6, device=device), torch.tensor(1.6 / mean_len, device=device))
-    torch.manual_seed(int(seed))  # torch.distributions draws from the default generator
+    # torch.distributions draws from the default generator; a seed of its own, or the lengths correlate with the genome
+    # choice below (identical Philox streams: the shortest reads would all come from the first community member)
+    torch.manual_seed(int(seed) * 2654435761 % (1 << 31) + 17)
     L = gamma.sample((n_reads,)).clamp_(min=min_len, max=genome_len).long()
     gi = torch.multinomial(w, n_reads, replacement=True, generator=gen)
     start = (torch.rand(n_reads, generator=gen, device=device, dtype=torch.float64) * (genome_len - L + 1).double()).long()
@@ -197,4 +200,7 @@ def make_reads_device(seed, genomes_flat, genome_len, n_reads, weights, device, 
     lens = torch.cat(out_lens)
     buf = torch.cat(pieces + [torch.full((16,), ord('A'), dtype=torch.uint8, device=device)])
     offs = torch.cumsum(lens, 0) - lens
+    if return_truth:
+        truth = dict(genome=gi.cpu().numpy(), start=start.cpu().numpy(), end=(start + L).cpu().numpy(), rev=rev.cpu().numpy())
+        return buf, offs.contiguous(), lens.to(torch.int32).contiguous(), truth
     return buf, offs.contiguous(), lens.to(torch.int32).contiguous()

@@ -131,12 +131,40 @@ int64_t mmo_sketch(const char *seq, int32_t len, int w, int k, uint32_t rid, mm1
 }
 
 /* ---------------------------------------------------------------- index */
+/* Sort by (x, y): the records are first partitioned on the top bits of x (a counting pass), then every bucket is sorted on
+ * its own; (x, y) is a total order (y is unique), so the result is the one a single qsort gives.  Buckets and the
+ * per-sequence sketches run on OpenMP threads: the tests build indexes of a gigabase on the GPU box's host. */
+static void sort_128xy(mm128 *a, int64_t n, int key_bits)
+{
+    const int bb = key_bits < 12 ? key_bits : 12, shift = key_bits - bb;
+    const int64_t nb = (int64_t)1 << bb;
+    int64_t *cnt, i, b;
+    mm128 *t;
+    if (n < (1 << 16)) { qsort(a, n, 16, cmp_128xy); return; }
+    cnt = (int64_t *)calloc((size_t)nb + 1, 8);
+    t = (mm128 *)malloc((size_t)n * 16);
+    for (i = 0; i < n; ++i) ++cnt[(a[i].x >> shift) + 1];
+    for (b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+    {
+        int64_t *cur = (int64_t *)malloc((size_t)nb * 8);
+        memcpy(cur, cnt, (size_t)nb * 8);
+        for (i = 0; i < n; ++i) t[cur[a[i].x >> shift]++] = a[i];
+        free(cur);
+    }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (b = 0; b < nb; ++b)
+        if (cnt[b + 1] - cnt[b] > 1) qsort(t + cnt[b], (size_t)(cnt[b + 1] - cnt[b]), 16, cmp_128xy);
+    memcpy(a, t, (size_t)n * 16);
+    free(t); free(cnt);
+}
+
 mmo_idx *mmo_idx_build(int32_t n_seq, const char **names, const char **seqs, const int32_t *lens, int k, int w)
 {
     mmo_idx *mi = (mmo_idx *)calloc(1, sizeof(mmo_idx));
-    int64_t tot = 0, i, n = 0, m = 0;
+    int64_t tot = 0, i, n = 0;
     int32_t s;
-    mm128 *all = 0;
+    mm128 *all = 0, **sv;
+    int64_t *sn;
     mi->k = k, mi->w = w, mi->n_seq = n_seq;
     mi->name = (char **)calloc(n_seq, sizeof(char *));
     mi->len = (int32_t *)calloc(n_seq, 4);
@@ -144,18 +172,24 @@ mmo_idx *mmo_idx_build(int32_t n_seq, const char **names, const char **seqs, con
     for (s = 0; s < n_seq; ++s) mi->off[s] = tot, tot += lens[s], mi->len[s] = lens[s], mi->name[s] = strdup(names[s]);
     mi->off[n_seq] = tot;
     mi->seq4 = (uint8_t *)malloc(tot > 0 ? tot : 1);
+    sv = (mm128 **)calloc(n_seq > 0 ? n_seq : 1, sizeof(mm128 *));
+    sn = (int64_t *)calloc((size_t)n_seq + 1, 8);
+#pragma omp parallel for schedule(dynamic, 1)
     for (s = 0; s < n_seq; ++s) {
-        mm128 *v;
-        int64_t nv, j;
+        int64_t j;
         for (j = 0; j < lens[s]; ++j) mi->seq4[mi->off[s] + j] = nt4((unsigned char)seqs[s][j]);
-        nv = mmo_sketch(seqs[s], lens[s], w, k, (uint32_t)s, &v);
-        if (n + nv > m) { m = (n + nv) * 2; all = (mm128 *)realloc(all, (size_t)m * 16); }
-        memcpy(all + n, v, (size_t)nv * 16);
-        n += nv;
-        free(v);
+        sn[s] = mmo_sketch(seqs[s], lens[s], w, k, (uint32_t)s, &sv[s]);
     }
+    for (s = 0; s < n_seq; ++s) n += sn[s];
+    all = (mm128 *)malloc((size_t)(n > 0 ? n : 1) * 16);
+    for (s = 0, i = 0; s < n_seq; ++s) {
+        if (sn[s]) memcpy(all + i, sv[s], (size_t)sn[s] * 16);
+        i += sn[s];
+        free(sv[s]);
+    }
+    free(sv); free(sn);
     for (i = 0; i < n; ++i) all[i].x >>= 8; /* drop the span: key = hash only */
-    qsort(all, n, 16, cmp_128xy);
+    sort_128xy(all, n, 2 * k);
     mi->keys = (uint64_t *)malloc((size_t)(n + 1) * 8);
     mi->key_off = (int64_t *)malloc((size_t)(n + 2) * 8);
     mi->pos = (uint64_t *)malloc((size_t)(n + 1) * 8);

@@ -76,6 +76,68 @@ def walk(cigar, qseq, tseq, sc):
     return dict(n_match=n_match, n_mismatch=n_mis, n_ambi=n_ambi, n_ins=n_ins, n_del=n_del, n_gapo=n_gapo, n_col=n_col, score=score, ms=best)
 
 
+_CODE = None
+
+
+def _codes(seq):
+    """ASCII (str / bytes) -> numpy codes 0..3, 4 for anything else (U counts as T)"""
+    import numpy as np
+    global _CODE
+    if _CODE is None:
+        _CODE = np.full(256, 4, dtype=np.int8)
+        for k, ch in enumerate('ACGT'):
+            _CODE[ord(ch)] = _CODE[ord(ch.lower())] = k
+        _CODE[ord('U')] = _CODE[ord('u')] = 3
+    b = seq.encode() if isinstance(seq, str) else bytes(seq)
+    return _CODE[np.frombuffer(b, dtype=np.uint8)]
+
+
+def walk_np(cigar, qseq, tseq, sc):
+    """walk() with numpy: the same numbers from the same definitions, for the checks that run over thousands of
+    multi-kilobase alignments (bench.py's correctness block).  The running local score `run = max(0, run + s)` is the
+    Lindley recursion: run_t = S_t - min(0, min_{u <= t} S_u) over the prefix sums S of the per-event scores."""
+    import numpy as np
+    cq_all, ct_all = _codes(qseq), _codes(tseq)
+    n_ops = len(cigar)
+    lens = np.fromiter((n for n, _ in cigar), dtype=np.int64, count=n_ops)
+    ops = np.fromiter((('MID'.index(op) if op in 'MID' else 9) for _, op in cigar), dtype=np.int8, count=n_ops)
+    if (ops == 9).any():
+        raise AssertionError('unexpected CIGAR operation inside an alignment')
+    qadv = np.where(ops != 2, lens, 0)
+    tadv = np.where(ops != 1, lens, 0)
+    assert int(qadv.sum()) == len(cq_all) and int(tadv.sum()) == len(ct_all), 'CIGAR does not span the aligned intervals'
+    qstart, tstart = np.cumsum(qadv) - qadv, np.cumsum(tadv) - tadv
+    # events in alignment order: one per M column, one per gap
+    n_ev = np.where(ops == 0, lens, 1)
+    ev_start = np.cumsum(n_ev) - n_ev
+    total = int(n_ev.sum())
+    ev_score = np.zeros(total, dtype=np.int64)
+    m = ops == 0
+    rep = np.repeat(np.arange(n_ops)[m], lens[m])
+    within = np.arange(int(lens[m].sum())) - np.repeat(np.cumsum(lens[m]) - lens[m], lens[m])
+    cq, ct = cq_all[qstart[rep] + within], ct_all[tstart[rep] + within]
+    amb = (cq > 3) | (ct > 3)
+    eq = (cq == ct) & ~amb
+    s_m = np.where(amb, -sc.sc_ambi, np.where(eq, sc.a, -sc.b)).astype(np.int64)
+    ev_score[ev_start[rep] + within] = s_m
+    g = ~m
+    glen = lens[g]
+    gap_cost = np.minimum(sc.q + sc.e * glen, sc.q2 + sc.e2 * glen)
+    score = int(s_m.sum()) - int(gap_cost.sum())
+    ev_score[ev_start[g]] = -(sc.q + sc.e * glen)
+    S = np.cumsum(ev_score)
+    floor = np.minimum.accumulate(np.minimum(S, 0))
+    best = int((S - floor).max()) if total else 0
+    # ambiguous bases inside gaps
+    qa, ta = np.concatenate([[0], np.cumsum(cq_all > 3)]), np.concatenate([[0], np.cumsum(ct_all > 3)])
+    ins, dele = ops == 1, ops == 2
+    amb_ins = (qa[qstart[ins] + lens[ins]] - qa[qstart[ins]]).sum() if ins.any() else 0
+    amb_del = (ta[tstart[dele] + lens[dele]] - ta[tstart[dele]]).sum() if dele.any() else 0
+    return dict(n_match=int(eq.sum()), n_mismatch=int((~eq & ~amb).sum()), n_ambi=int(amb.sum() + amb_ins + amb_del),
+                n_ins=int(lens[ins].sum() - amb_ins), n_del=int(lens[dele].sum() - amb_del), n_gapo=int(g.sum()),
+                n_col=int(lens[m].sum()), score=score, ms=best)
+
+
 def tags_of(fields):
     out = {}
     for f in fields:
@@ -84,9 +146,11 @@ def tags_of(fields):
     return out
 
 
-def check_paf(paf_text, reads, genomes, best_n=5, with_cigar=True, sc=None, stats=None):
-    """reads: dict name -> sequence (str); genomes: dict name -> sequence (str).  Raises AssertionError on any violation.
-    stats (optional dict) receives counters: lines, as_equal (AS equals the CIGAR's dual-affine score), primaries."""
+def check_paf(paf_text, reads, genomes, best_n=5, with_cigar=True, sc=None, stats=None, fast=False):
+    """reads: dict name -> sequence (str); genomes: dict name -> sequence (str), or any mapping whose values support len()
+    and slicing (bench.py hands over slices fetched from the index in HBM).  Raises AssertionError on any violation.
+    stats (optional dict) receives counters: lines, as_equal (AS equals the CIGAR's dual-affine score), primaries.
+    fast: recompute with walk_np (numpy) instead of the per-base Python loop."""
     sc = sc or Scoring()
     stats = stats if stats is not None else {}
     per_read = {}
@@ -107,7 +171,7 @@ def check_paf(paf_text, reads, genomes, best_n=5, with_cigar=True, sc=None, stat
             assert all(op in 'MID' for _, op in cig) and cig[0][1] == 'M' and cig[-1][1] == 'M', t['cg'][:60]
             assert all(cig[i][1] != cig[i + 1][1] for i in range(len(cig) - 1)), 'adjacent operations of the same kind'
             q = reads[name][qs:qe] if strand == '+' else revcomp(reads[name])[qlen - qe:qlen - qs]
-            w = walk(cig, q, genomes[tname][ts:te], sc)
+            w = (walk_np if fast else walk)(cig, q, genomes[tname][ts:te], sc)
             assert mlen == w['n_match'], (line[:80], mlen, w)
             assert blen == w['n_match'] + w['n_mismatch'] + w['n_ins'] + w['n_del'], (line[:80], blen, w)
             assert t['nn'] == w['n_ambi'] and t['NM'] == w['n_mismatch'] + w['n_ins'] + w['n_del'] + w['n_ambi'], (line[:80], t['NM'], w)
