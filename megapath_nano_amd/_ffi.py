@@ -28,6 +28,16 @@ def last_error():
     return lib().mpn_last_error().decode()
 
 
+def hint(msg):
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  A process that uses both must import torch (and touch the GPU
+    with it) BEFORE libmpn.so is loaded, as bench.py does: then both HIP runtimes sit on one HSA runtime.  The other order
+    leaves two HSA runtimes in the process and the second one finds no device."""
+    import sys
+    if 'no ROCm-capable device' in msg and 'torch' in sys.modules:
+        msg += ' [libmpn.so was loaded before PyTorch initialised the GPU: import torch and call torch.cuda.init() first]'
+    return msg
+
+
 def check(rc, what):
     if rc != 0:
-        raise MpnError(f'{what} failed (rc={rc}): {last_error()}')
+        raise MpnError(f'{what} failed (rc={rc}): {hint(last_error())}')

@@ -151,7 +151,7 @@ class Index:
         self.k, self.w = k, w
         self.h = lib.mpn_index_build(n, names, seqs, self.lens.ctypes.data, k, w)
         if not self.h:
-            raise _ffi.MpnError('mpn_index_build failed: ' + _ffi.last_error())
+            raise _ffi.MpnError('mpn_index_build failed: ' + _ffi.hint(_ffi.last_error()))
 
     @classmethod
     def from_device(cls, names, d_seqs_ptr, lens, k=15, w=10):
@@ -167,7 +167,7 @@ class Index:
         self.k, self.w = k, w
         self.h = lib.mpn_index_build_device(n, cn, d_seqs_ptr, off.ctypes.data, self.lens.ctypes.data, k, w)
         if not self.h:
-            raise _ffi.MpnError('mpn_index_build_device failed: ' + _ffi.last_error())
+            raise _ffi.MpnError('mpn_index_build_device failed: ' + _ffi.hint(_ffi.last_error()))
         return self
 
     def sam_header(self, cmdline=None):

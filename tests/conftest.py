@@ -22,6 +22,14 @@ def oracle_built():
 
 @pytest.fixture(scope='session')
 def libmpn():
+    # On a GPU box the tests run on the runtime stack bench.py runs on: PyTorch-ROCm initialises the GPU first, libmpn.so is
+    # loaded afterwards (megapath_nano_amd/_ffi.py hint(): the other order leaves two HSA runtimes in the process)
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except ImportError:
+        pass
     from megapath_nano_amd import build, _ffi
     build.build()
     return _ffi.lib()

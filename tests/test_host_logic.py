@@ -249,3 +249,31 @@ def test_index_file_magic_detection(tmp_path):
     idx = tmp_path / 't.mpi'
     idx.write_bytes(Index.MAGIC + b'\0' * 64)
     assert not Index.is_index_file(str(fa)) and Index.is_index_file(str(idx)) and not Index.is_index_file(str(tmp_path / 'missing'))
+
+
+def test_paf_check_numpy_walk_equals_the_plain_walk():
+    """bench.py's correctness block uses paf_check.walk_np; it must give what the per-base loop gives."""
+    import paf_check as pc
+    rng = np.random.default_rng(11)
+    sc = pc.Scoring()
+    for _ in range(200):
+        n = int(rng.integers(1, 40))
+        cig = [(int(rng.integers(1, 30 if k % 2 == 0 else 60)), 'M' if k % 2 == 0 else 'ID'[int(rng.integers(0, 2))]) for k in range(n)]
+        ql, tl = sum(l for l, o in cig if o != 'D'), sum(l for l, o in cig if o != 'I')
+        q = ''.join(rng.choice(list('ACGTN'), p=[.24, .24, .24, .24, .04], size=ql))
+        t = ''.join(rng.choice(list('ACGTN'), p=[.24, .24, .24, .24, .04], size=tl))
+        assert pc.walk(cig, q, t, sc) == pc.walk_np(cig, q, t, sc)
+    with pytest.raises(AssertionError):
+        pc.walk_np([(3, 'M')], 'ACG', 'ACGT', sc)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` without a launcher starts N ranks itself or exits non-zero: never a silent one-rank run
+    (VERDICT r2).  Here no GPU is visible, so --gpus 2 must fail before anything is launched."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MPN_SINGLE_DEVICE')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and 'GPU(s) are visible' in out.stderr and not out.stdout.strip()
+    env['WORLD_SIZE'] = '4'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and 'WORLD_SIZE=4' in out.stderr
