@@ -130,10 +130,11 @@ def iter_target_parts(records, batch_bases):
     (whole sequences); a part is closed after the first mini-batch that brings it OVER batch_bases.  Yields lists of
     (name, sequence)."""
     part, part_bases, mini = [], 0, 0
+    mini_batch = min(IDX_MINI_BATCH, max(1, batch_bases))   # mm_idx_gen reads min(mini_batch_size, batch_size) at a time
     for name, seq in records:
         part.append((name, seq))
         mini += len(seq)
-        if mini >= IDX_MINI_BATCH:
+        if mini >= mini_batch:
             part_bases += mini
             mini = 0
             if part_bases > batch_bases:
@@ -209,9 +210,31 @@ class MappedBatch:
         self.target_names, self.target_lens = target_names, target_lens
 
 
+class _Results(list):
+    """The MappedBatch list of map_files.  With a sink every batch is handed over as soon as it is final and its text is
+    dropped (a run of configs[2]'s size has tens of GB of SAM text); the integer columns stay."""
+
+    def __init__(self, on_batch=None, on_header=None):
+        super().__init__()
+        self.on_batch, self.on_header, self.header_sent = on_batch, on_header, False
+
+    def header(self, text):
+        if self.on_header and not self.header_sent and text is not None:
+            self.on_header(text)
+            self.header_sent = True
+
+    def append(self, b):
+        if self.on_batch:
+            self.on_batch(b)
+            b.paf = b.sam = None
+        super().append(b)
+
+
 def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False, want_cols=True, read_batch_bases=200_000_000,
-              save_index=None, cache_key=None):
+              save_index=None, cache_key=None, on_batch=None, on_header=None):
     """Map the reads of query_paths against the targets.  -> (list of MappedBatch, SAM header text or None).
+    on_header(text) / on_batch(MappedBatch): called with the SAM header before the first batch and with every batch as
+    soon as its text is final; the text is then not kept.
 
     Without `--split-prefix` and with more than one index part minimap2 reports every part on its own; the batches are
     then returned part by part, in that order."""
@@ -220,12 +243,13 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
     out_opt.out_sam = (2 if want_paf else 1) if want_sam else 0
     text_wanted = want_paf or want_sam
     batches = list(iter_read_batches(query_paths, read_batch_bases))
-    results, header = [], None
+    results, header = _Results(on_batch, on_header), None
 
     def single(idx):
         nonlocal header
         if want_sam:
             header = idx.sam_header()
+            results.header(header)
         names, lens = np.array(idx.names, dtype=object), idx.lens
         for b in batches:
             text, sam, cols = mapper.map_batch_full(idx, out_opt, b, want_paf=text_wanted, want_cols=want_cols)
@@ -243,8 +267,9 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
             hits = [mapper.Hits(b) for b in batches]
             for h in hits:
                 h.add_part(idx, opt)
-            _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
             header = hits[0].sam_header() if (want_sam and hits) else (idx.sam_header() if want_sam else None)
+            results.header(header)
+            _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
             for h in hits:
                 h.close()
         else:
@@ -273,8 +298,13 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
             idx = mapper.Index(part, k=options.k, w=options.w)
             del part
             n_parts += 1
-            if save_index and n_parts == 1:
-                idx.save(save_index)  # minimap2 -d FILE
+            if save_index:
+                # minimap2 -d FILE dumps every part into the one file; the .mpi format holds one index, so a target set that
+                # needs several parts is refused loudly instead of being saved truncated
+                if n_parts > 1:
+                    raise ValueError(f'-d {save_index}: the target set needs more than one index part at -I {options.batch_bases}; '
+                                     'raise -I (the index is built on the GPU: one part holds ~36 Gbp)')
+                idx.save(save_index)
             use(idx)
             prev = idx
         if prev is not None:
@@ -285,6 +315,7 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
     if hits is not None:
         if want_sam:
             header = hits[0].sam_header() if hits else ''
+            results.header(header)
         _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
         for h in hits:
             h.close()
@@ -353,6 +384,24 @@ def _resolve_queries(assembly_metadata, global_options, query_filename_list, que
     return paths
 
 
+def _run_amr(global_options, bam_filename, amr_output_folder, log_file):
+    """aligner.py:250-256 starts the AMR module (megapath_nano_amr.py, outside this path: SURVEY section 8 scope) on the BAM.
+    A caller may hand over its own hook (global_options['amr_hook'](bam, folder)); otherwise the reference's script is run
+    when the deployment has it (global_options['nano_bin_dir']), and its absence is reported instead of hidden."""
+    hook = global_options.get('amr_hook')
+    if callable(hook):
+        hook(bam_filename, amr_output_folder)
+        return
+    import subprocess
+    script = os.path.join(global_options.get('nano_bin_dir', ''), 'megapath_nano_amr.py')
+    if os.path.isfile(script):
+        subprocess.Popen(['python', script, '--query_bam', bam_filename, '--output_folder', str(amr_output_folder), '--threads',
+                          str(global_options.get('AMRThreadOption', 1))], stderr=log_file if hasattr(log_file, 'fileno') else None).wait()
+    else:
+        print(f'AMR module not started: {script or "megapath_nano_amr.py"} not found (give global_options[\'nano_bin_dir\'] or amr_hook)',
+              file=os.sys.stderr)
+
+
 def _frame_of(batch):
     c = batch.cols
     i64 = lambda a: a.astype(np.int64)  # noqa: E731
@@ -390,24 +439,32 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
     # the tiebreaker stream: Python's generator seeded with the md5 of the query basenames (aligner.py:160-168)
     random.seed(hashlib.md5(''.join(os.path.split(q)[1] for q in query_paths).encode()).hexdigest())
 
-    options = AlignerOptions(aligner_options, mapping_only)
     output_paf = not (paf_path_and_prefix is None or paf_path_and_prefix == '')
-    want_sam = output_paf and not mapping_only
+    # the reference adds -a whenever a PAF prefix is given (aligner.py:190-191), and minimap2's -a implies base-level
+    # alignment: with a prefix the CIGARs are computed even for mapping_only
+    options = AlignerOptions(aligner_options, mapping_only and not output_paf)
+    want_sam = output_paf
     regular = all(os.path.isfile(p) for p in target_paths)
     cache_key = (tuple(target_paths), options.k, options.w, options.batch_bases) if regular else None
-    batches, header = map_files(target_paths, query_paths, options, want_paf=output_paf, want_sam=want_sam, want_cols=True,
-                                read_batch_bases=batch_bases, cache_key=cache_key)
     if output_paf:
-        with open(f'{paf_path_and_prefix}.paf', 'w') as f:
-            for b in batches:
-                f.write(b.paf)
-    if want_sam:
-        with open(f'{paf_path_and_prefix}.sam', 'w') as f:
-            f.write(header or '')
-            for b in batches:
-                f.write(b.sam)
-        from . import bam  # samtools view -F1796 -b | samtools sort; samtools index (aligner.py:246-252)
-        bam.sam_to_sorted_bam(f'{paf_path_and_prefix}.sam', f'{paf_path_and_prefix}.bam', exclude_flags=1796)
+        # PAF and SAM go to disk batch by batch: nothing but the integer columns of a batch is kept in memory
+        with open(f'{paf_path_and_prefix}.paf', 'w') as paf_f, open(f'{paf_path_and_prefix}.sam', 'w') as sam_f:
+            batches, header = map_files(target_paths, query_paths, options, want_paf=True, want_sam=True, want_cols=True,
+                                        read_batch_bases=batch_bases, cache_key=cache_key, on_header=sam_f.write,
+                                        on_batch=lambda b: (paf_f.write(b.paf), sam_f.write(b.sam)))
+        print('Finished species alignment step.')                                                        # aligner.py:244
+        from . import bam
+        # samtools view -F<flags> -b | samtools sort; samtools index (aligner.py:245-252): 1796 = unmapped | secondary | QC fail |
+        # duplicate; the amplicon filter keeps everything that is mapped
+        exclude = 4 if module_option == 'amplicon_filter_module' else 1796
+        bam.sam_to_sorted_bam(f'{paf_path_and_prefix}.sam', f'{paf_path_and_prefix}.bam', exclude_flags=exclude)
+        if module_option in ('taxon_and_AMR_module', 'AMR_module_only'):                                # aligner.py:250-256
+            _run_amr(global_options, f'{paf_path_and_prefix}.bam', AMR_output_folder, log_file)
+        if module_option in ('AMR_module_only', 'amplicon_filter_module'):                               # aligner.py:257-259
+            os.sys.exit()
+    else:
+        batches, header = map_files(target_paths, query_paths, options, want_paf=False, want_sam=False, want_cols=True,
+                                    read_batch_bases=batch_bases, cache_key=cache_key)
 
     frames = [_frame_of(b) for b in batches if len(b.cols['read_idx'])]
     if frames:

@@ -34,31 +34,63 @@ def reg2bin(beg, end):
     return 0
 
 
-class BgzfWriter:
-    """BGZF stream: tell() is the virtual offset the next byte will get."""
+def _bgzf_block(payload, level):
+    if level == 0:   # htslib writes level 0 as one stored deflate block
+        body = b'\x01' + struct.pack('<HH', len(payload), len(payload) ^ 0xffff) + payload
+    else:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(payload) + c.flush()
+    return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(body) + 25) + body +
+            struct.pack('<II', zlib.crc32(payload) & 0xffffffff, len(payload)))
 
-    def __init__(self, fileobj, level=-1):
+
+class BgzfWriter:
+    """BGZF stream.  Blocks are compressed by a thread pool (zlib releases the GIL), PENDING blocks at a time, so the file
+    address of a block is not known when it is closed: tell() returns a provisional virtual offset (block NUMBER << 16 |
+    offset in the block) and resolve() turns it into the real one (block ADDRESS << 16 | offset) once the blocks before it
+    have been written (after drain())."""
+    PENDING = 256
+
+    def __init__(self, fileobj, level=-1, threads=None):
+        import os
         self.f, self.level = fileobj, level
         self.buf = bytearray()
-        self.block_address = 0
+        self.pending = []            # closed blocks that are not compressed yet
+        self.addr = [0]              # addr[i] = file address of block i, for every block whose predecessors are written
+        self.block_no = 0            # number of the block being filled
+        self.threads = threads if threads is not None else max(1, min(16, os.cpu_count() or 1))
+        self.pool = None
 
     def tell(self):
-        return self.block_address << 16 | len(self.buf)
+        return self.block_no << 16 | len(self.buf)
 
-    def _emit(self, payload):
-        if self.level == 0:   # htslib writes level 0 as one stored deflate block
-            body = b'\x01' + struct.pack('<HH', len(payload), len(payload) ^ 0xffff) + bytes(payload)
+    def resolve(self, voff):
+        return self.addr[voff >> 16] << 16 | (voff & 0xffff)
+
+    def _close_block(self, payload):
+        self.pending.append(bytes(payload))
+        self.block_no += 1
+        if len(self.pending) >= self.PENDING:
+            self.drain()
+
+    def drain(self):
+        if not self.pending:
+            return
+        if self.threads > 1 and len(self.pending) > 4 and self.level != 0:
+            if self.pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self.pool = ThreadPoolExecutor(self.threads)
+            blocks = self.pool.map(lambda p: _bgzf_block(p, self.level), self.pending)
         else:
-            c = zlib.compressobj(self.level, zlib.DEFLATED, -15)
-            body = c.compress(bytes(payload)) + c.flush()
-        block = (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(body) + 25) + body +
-                 struct.pack('<II', zlib.crc32(bytes(payload)) & 0xffffffff, len(payload)))
-        self.f.write(block)
-        self.block_address += len(block)
+            blocks = (_bgzf_block(p, self.level) for p in self.pending)
+        for b in blocks:
+            self.f.write(b)
+            self.addr.append(self.addr[-1] + len(b))
+        self.pending = []
 
     def flush(self):
         while self.buf:
-            self._emit(self.buf[:BGZF_BLOCK])
+            self._close_block(self.buf[:BGZF_BLOCK])
             del self.buf[:BGZF_BLOCK]
 
     def flush_try(self, size):
@@ -69,12 +101,15 @@ class BgzfWriter:
     def write(self, data):
         self.buf += data
         while len(self.buf) >= BGZF_BLOCK:
-            self._emit(self.buf[:BGZF_BLOCK])
+            self._close_block(self.buf[:BGZF_BLOCK])
             del self.buf[:BGZF_BLOCK]
 
     def close(self):
         self.flush()
+        self.drain()
         self.f.write(BGZF_EOF)
+        if self.pool is not None:
+            self.pool.shutdown()
 
 
 def _aux_bytes(field):
@@ -114,6 +149,20 @@ def parse_cigar(text):
     return ops
 
 
+_SEQ_TABLE = bytes(_SEQ_CODE.get(chr(c).upper(), 15) for c in range(256))
+_QUAL_TABLE = bytes((c - 33) & 0xff for c in range(256))
+MAX_CIGAR_OPS = 65535          # n_cigar_op is 16 bits wide in a BAM record
+
+
+def pack_seq(seq):
+    """SEQ text -> 4-bit codes, two bases per byte, high nibble first (SAMv1 4.2); bytes.translate + numpy, no per-base loop."""
+    import numpy as np
+    codes = np.frombuffer(seq.encode().translate(_SEQ_TABLE), dtype=np.uint8)
+    if len(codes) & 1:
+        codes = np.concatenate([codes, np.zeros(1, dtype=np.uint8)])
+    return ((codes[0::2] << 4) | codes[1::2]).tobytes()
+
+
 def encode_record(fields, ref_id):
     """One SAM line (already split on tabs) -> (refID, pos0, end0, flag, BAM record bytes without the block_size word)."""
     qname, flag, rname, pos, mapq, cigar_s, rnext, pnext, tlen, seq, qual = fields[:11]
@@ -124,19 +173,22 @@ def encode_record(fields, ref_id):
     ref_len = sum(c >> 4 for c in cigar if (c & 0xf) in _REF_CONSUMING)
     end0 = pos0 + ref_len if (ref_len > 0 and not flag & 4) else pos0 + 1
     l_seq = 0 if seq == '*' else len(seq)
-    packed = bytearray((l_seq + 1) // 2)
-    for i in range(l_seq):
-        packed[i >> 1] |= _SEQ_CODE.get(seq[i].upper(), 15) << (4 if i % 2 == 0 else 0)
+    packed = pack_seq(seq) if l_seq else b''
     if l_seq == 0:
         q = b''
     elif qual == '*':
         q = b'\xff' * l_seq
     else:
-        q = bytes(ord(c) - 33 for c in qual)
+        q = qual.encode().translate(_QUAL_TABLE)
     name = qname.encode() + b'\0'
+    aux = b''.join(_aux_bytes(f) for f in fields[11:])
+    if len(cigar) > MAX_CIGAR_OPS:
+        # htslib (sam.c bam_write1 / SAMv1 4.2.2): a CIGAR that does not fit 16 bits is replaced by <l_seq>S<ref_len>N and
+        # the real one travels in a CG:B,I tag (ultra-long ONT reads have such CIGARs)
+        aux += b'CGBI' + struct.pack('<I', len(cigar)) + struct.pack('<%dI' % len(cigar), *cigar)
+        cigar = [l_seq << 4 | 4, ref_len << 4 | 3]
     rec = (struct.pack('<iiBBHHHiiii', tid, pos0, len(name), mapq, reg2bin(pos0, end0), len(cigar), flag, l_seq, ntid, int(pnext) - 1,
-                       int(tlen)) + name + struct.pack('<%dI' % len(cigar), *cigar) + bytes(packed) + q +
-           b''.join(_aux_bytes(f) for f in fields[11:]))
+                       int(tlen)) + name + struct.pack('<%dI' % len(cigar), *cigar) + packed + q + aux)
     return tid, pos0, end0, flag, rec
 
 
@@ -200,6 +252,20 @@ class BaiBuilder:
         else:
             self.n_unmapped += 1
         self.last_off = offset_after
+
+    def remap(self, fn):
+        """Every virtual offset collected so far through fn (BgzfWriter.resolve: provisional -> real); the count pairs of the
+        pseudo-bins are not offsets and stay."""
+        for bins in self.bins:
+            for b, lst in bins.items():
+                for k, c in enumerate(lst):
+                    if b == META_BIN and k % 2 == 1:
+                        continue
+                    c[0], c[1] = fn(c[0]), fn(c[1])
+        for lin in self.lin:
+            for w in lin:
+                lin[w] = fn(lin[w])
+        self.last_off, self.save_off, self.off_beg = fn(self.last_off), fn(self.save_off), fn(self.off_beg)
 
     def finish(self, final_offset):
         if self.save_tid >= 0:
@@ -273,32 +339,66 @@ def write_bam(path, header_text, ref_names, ref_lens, records, level=-1, index_p
                 bai.push(tid, pos0, end0, w.tell(), not flag & 4)
         if bai:
             w.flush()
-            bai.finish(w.tell())
+            w.drain()
+            bai.remap(w.resolve)
+            bai.finish(w.resolve(w.tell()))
         w.close()
     if bai:
         bai.write(index_path)
 
 
-def sam_to_sorted_bam(sam_path, bam_path, exclude_flags=0, level=-1, index=True):
+def sam_to_sorted_bam(sam_path, bam_path, exclude_flags=0, level=-1, index=True, sort_keys=None):
     """`samtools view -F <exclude_flags> -b | samtools sort; samtools index`: keep the records without any of the flags, order them
-    by (reference, position, strand) with the unplaced ones last -- a stable sort, like samtools' -- and write BAM + .bai."""
-    header, recs = [], []
-    with open(sam_path) as f:
-        for line in f:
-            if line.startswith('@'):
-                header.append(line)
-    names, lens = parse_header(header)
-    ref_id = {n: i for i, n in enumerate(names)}
-    with open(sam_path) as f:
-        for line in f:
-            if line.startswith('@') or not line.strip():
-                continue
-            fields = line.rstrip('\n').split('\t')
-            if int(fields[1]) & exclude_flags:
-                continue
-            recs.append(encode_record(fields, ref_id))
-    recs.sort(key=lambda r: ((r[0] if r[0] >= 0 else 1 << 40), r[1] + 1, (r[3] >> 4) & 1))
+    by (reference, position, strand) with the unplaced ones last -- a stable sort, like samtools' -- and write BAM + .bai.
+
+    The SAM text of a run is tens of GB: only a key (reference, position, strand) and the line's place in the file are kept per
+    record; the lines are read back in sorted order and encoded as they are written.  sort_keys(tid, pos, rev) -> order may
+    replace the host sort (megapath_nano_amd.abundance.device_sort_order runs it on the GPU)."""
+    import numpy as np
+    header = []
+    tids, poss, revs, offs, lens_ = [], [], [], [], []
+    ref_id = None
+    names = lens = None
+    with open(sam_path, 'rb') as f:
+        off = 0
+        for raw in f:
+            n = len(raw)
+            if raw[:1] == b'@':
+                header.append(raw.decode())
+            elif raw.strip():
+                if ref_id is None:
+                    names, lens = parse_header(header)
+                    ref_id = {nm.encode(): i for i, nm in enumerate(names)}
+                # QNAME FLAG RNAME POS: the first four fields are all the key needs
+                f4 = raw.split(b'\t', 4)
+                flag = int(f4[1])
+                if not flag & exclude_flags:
+                    tids.append(ref_id.get(f4[2], -1) if f4[2] != b'*' else -1)
+                    poss.append(int(f4[3]))
+                    revs.append((flag >> 4) & 1)
+                    offs.append(off)
+                    lens_.append(n)
+            off += n
+    if ref_id is None:
+        names, lens = parse_header(header)
+    tid = np.asarray(tids, dtype=np.int64)
+    pos = np.asarray(poss, dtype=np.int64)
+    rev = np.asarray(revs, dtype=np.int64)
+    tid_key = np.where(tid >= 0, tid, np.int64(1) << 40)
+    if sort_keys is not None and len(tid):
+        order = np.asarray(sort_keys(tid_key, pos, rev), dtype=np.int64)
+    else:
+        order = np.lexsort((rev, pos, tid_key))   # stable: equal keys stay in file order
+    ref_str = {n_: i for i, n_ in enumerate(names)}
+    offs_a, lens_a = np.asarray(offs, dtype=np.int64), np.asarray(lens_, dtype=np.int64)
+
+    def records():
+        with open(sam_path, 'rb') as f:
+            for k in order:
+                f.seek(int(offs_a[k]))
+                yield encode_record(f.read(int(lens_a[k])).decode().rstrip('\n').split('\t'), ref_str)
+
     hd = '@HD\tVN:1.6\tSO:coordinate\n'
     body = ''.join(l for l in header if not l.startswith('@HD'))
-    write_bam(bam_path, hd + body, names, lens, recs, level=level, index_path=bam_path + '.bai' if index else None)
-    return len(recs)
+    write_bam(bam_path, hd + body, names, lens, records(), level=level, index_path=bam_path + '.bai' if index else None)
+    return len(order)

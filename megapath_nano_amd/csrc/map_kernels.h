@@ -1644,13 +1644,15 @@ __global__ __launch_bounds__(256) void idx_pack2_kernel(const uint8_t *__restric
 }
 
 // occurrence histogram of the index keys (mm_idx_cal_max_occ needs a quantile of it): bins 0..nbins-1, the last one open-ended
-__global__ __launch_bounds__(256) void idx_occ_hist_kernel(const int64_t *__restrict__ key_off, int64_t n_keys, int nbins,
+// (the key offsets are read from the lookup's (key, first position) pairs: the separate key / offset arrays of the build are
+// released once that table exists)
+__global__ __launch_bounds__(256) void idx_occ_hist_kernel(const u128 *__restrict__ kv, int64_t n_keys, int nbins,
                                                            unsigned long long *__restrict__ hist) {
     __shared__ unsigned int local[1024];
     for (int k = threadIdx.x; k < 1024; k += blockDim.x) local[k] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t occ = key_off[i + 1] - key_off[i];
+        const int64_t occ = (int64_t)(kv[i + 1].y - kv[i].y);
         if (occ < 1024) atomicAdd(&local[(int)occ], 1u);
         else atomicAdd(&hist[occ < nbins - 1 ? occ : nbins - 1], 1ULL);
     }

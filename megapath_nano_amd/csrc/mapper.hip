@@ -185,7 +185,13 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     EvTimer ev(st);
     if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st, &ev)) return -1;
     g_stats[1] += n_mz;
-    const int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
+    int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
+    if (mid_occ > (1 << 25)) {
+        // `-f 0` (no cut-off, valid in minimap2) arrives as INT32_MAX: nothing occurs more often than the index's most frequent
+        // minimizer, so that count + 1 is the same cut-off
+        const int32_t top = mpn_index_mid_occ(idx, 1e-30f);
+        if (top > 0) mid_occ = std::min(mid_occ, top);
+    }
     DevBuf<int32_t> occ;
     DevBuf<int64_t> pos_start, rel_off, full_off, n_blk, blk_base;
     DevBuf<unsigned long long> span_sum;
@@ -623,6 +629,26 @@ static int build_bucket_table(mpn_index *idx, hipStream_t st) {
                        idx->bucket_shift, nb, idx->bucket_start.p);
     hipLaunchKernelGGL(idx_kv_kernel, dim3(grid_1d(idx->n_keys + 1, 256)), dim3(256), 0, st, idx->keys.p, idx->key_off.p, idx->n_keys, idx->kv.p);
     MPN_HIP_CHECK(hipGetLastError());
+    // the pairs now hold both arrays (16 B per key; 4 GB at the 256 M keys of a 20 Gbp target set): save, export and the
+    // occurrence histogram read them from there
+    MPN_HIP_CHECK(stream_sync(st));
+    idx->keys.release(); idx->key_off.release();
+    return 0;
+}
+
+// host copies of the sorted keys and their offsets (n_keys + 1 entries), split out of the lookup's pairs
+static int fetch_keys(const mpn_index *idx, uint64_t *keys, int64_t *key_off, hipStream_t st) {
+    const size_t n = (size_t)idx->n_keys + 1, piece = (size_t)1 << 22;
+    std::vector<u128> buf(std::min(n, piece));
+    for (size_t lo = 0; lo < n; lo += piece) {
+        const size_t m = std::min(piece, n - lo);
+        MPN_HIP_CHECK(hipMemcpyAsync(buf.data(), idx->kv.p + lo, m * sizeof(u128), hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(stream_sync(st));
+        for (size_t i = 0; i < m; ++i) {
+            if (keys && lo + i < (size_t)idx->n_keys) keys[lo + i] = buf[i].x;
+            if (key_off) key_off[lo + i] = (int64_t)buf[i].y;
+        }
+    }
     return 0;
 }
 
@@ -639,8 +665,8 @@ int mpn_index_save(const mpn_index *idx, const char *path) {
     const std::vector<int64_t> &ns = idx->h_nrun_s, &ne = idx->h_nrun_e;
     std::vector<uint64_t> keys((size_t)idx->n_keys), pos((size_t)idx->n_mz);
     std::vector<int64_t> h_key_off((size_t)idx->n_keys + 1);
-    if (idx->keys.download(keys.data(), keys.size(), st) || idx->pos.download(pos.data(), pos.size(), st) ||
-        idx->key_off.download(h_key_off.data(), h_key_off.size(), st) || idx->d_seq2.download(words.data(), words.size(), st))
+    if (fetch_keys(idx, keys.data(), h_key_off.data(), st) || idx->pos.download(pos.data(), pos.size(), st) ||
+        idx->d_seq2.download(words.data(), words.size(), st))
         return -1;
     MPN_HIP_CHECK(stream_sync(st));
     FILE *f = fopen(path, "wb");
@@ -772,7 +798,7 @@ int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
         DevBuf<unsigned long long> hist;
         idx->occ_hist.assign((size_t)nbins, 0);
         if (hist.alloc((size_t)nbins) || hist.zero(st)) return -1;
-        hipLaunchKernelGGL(idx_occ_hist_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, st, (const int64_t *)idx->key_off.p, n, nbins, hist.p);
+        hipLaunchKernelGGL(idx_occ_hist_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, st, (const u128 *)idx->kv.p, n, nbins, hist.p);
         if (hist.download((unsigned long long *)idx->occ_hist.data(), (size_t)nbins, st) || stream_sync(st) != hipSuccess) {
             idx->occ_hist.clear();
             set_error("mpn_index_mid_occ: histogram failed");
@@ -783,7 +809,7 @@ int32_t mpn_index_mid_occ(const mpn_index *idx, float f) {
     for (int b = 0; b < nbins; ++b) { cum += (int64_t)idx->occ_hist[(size_t)b]; if (cum > kk) { v = b; break; } }
     if (v < 0 || v == nbins - 1) {  // open bin: exact selection on the host
         std::vector<int64_t> h_key_off((size_t)n + 1);
-        if (idx->key_off.download(h_key_off.data(), h_key_off.size(), st) || stream_sync(st) != hipSuccess) return -1;
+        if (fetch_keys(idx, nullptr, h_key_off.data(), st)) return -1;
         std::vector<uint32_t> a((size_t)n);
         for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (uint32_t)(h_key_off[(size_t)i + 1] - h_key_off[(size_t)i]);
         std::nth_element(a.begin(), a.begin() + kk, a.end());
@@ -817,9 +843,7 @@ int64_t mpn_index_fetch_seq(const mpn_index *idx, int32_t i, int64_t start, int6
 
 int mpn_index_export(const mpn_index *idx, uint64_t *keys, int64_t *key_off, uint64_t *pos) {
     hipStream_t st = 0;
-    if (idx->keys.download(keys, (size_t)idx->n_keys, st) || idx->key_off.download(key_off, (size_t)idx->n_keys + 1, st) ||
-        idx->pos.download(pos, (size_t)idx->n_mz, st))
-        return -1;
+    if (fetch_keys(idx, keys, key_off, st) || idx->pos.download(pos, (size_t)idx->n_mz, st)) return -1;
     MPN_HIP_CHECK(stream_sync(st));
     return 0;
 }

@@ -140,9 +140,38 @@ def test_aligner_executable_dropin(files):
             f.write(b'>' + name.encode() + b'\n' + bytes(seq) + b'\n')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'mpn-aligner'), '-c', '-t', '8', '-I', '0G', '-x', 'map-ont',
                           str(target), str(fq), '--split-prefix', 'tmp'], check=True, capture_output=True, text=True).stdout
-    oidx = mb.Index(gen)
+    # `-I 0G` is what the reference passes on a host with less than 64 GiB of free memory (megapath_nano.py:4019-4022): minimap2
+    # then reads min(mini-batch, 0) bases at a time, i.e. every target sequence becomes an index part of its own
+    parts = [mb.Index([g]) for g in gen]
     oopt = mb.default_opt()
-    sp = mb.SplitIndex([oidx])
+    sp = mb.SplitIndex(parts)
     assert out == ''.join(sp.map_read(oopt, r['name'], r['seq']) for r in reads)
     sp.close()
-    oidx.close()
+    for p_ in parts:
+        p_.close()
+
+
+def test_align_mirror_amplicon_module_keeps_secondaries_and_exits(files):
+    """aligner.py:246-259: the amplicon filter's BAM is made with -F4 (secondary alignments stay) and Align() exits after it;
+    with a PAF prefix the call carries -a, so the SAM has CIGARs even for mapping_only."""
+    from megapath_nano_amd.aligner import Align
+    from bam_reader import read_bam
+    d, gen, reads, table, fq = files
+    target = d / 'amplicon_ref.fna'
+    with open(target, 'wb') as f:
+        for name, seq in gen:
+            f.write(b'>' + name.encode() + b'\n' + bytes(seq) + b'\n')
+    opts = dict(assembly_folder=str(d), min_alignment_score=0, debug=False, nano_dir=str(d))
+    with pytest.raises(SystemExit) as e:
+        Align(assembly_metadata=FakeMetadata(table), global_options=opts, temp_dir_name=str(d), log_file=None,
+              query_filename_list=pd.DataFrame({'path': [str(fq)]}), target_filename_list=pd.DataFrame({'path': [str(target)]}),
+              aligner_options=['-t', '4', '-N', '50', '-p', '1', '-x', 'map-ont'], paf_path_and_prefix=str(d / 'amp'),
+              mapping_only=True, module_option='amplicon_filter_module', align_concat_fa=True)
+    assert e.value.code is None                                   # os.sys.exit() without a message
+    sam = [l.split('\t') for l in open(d / 'amp.sam') if not l.startswith('@')]
+    mapped = [f for f in sam if not int(f[1]) & 4]
+    assert mapped and all(f[5] != '*' for f in mapped)            # -a implies CIGARs
+    assert any(int(f[1]) & 256 for f in mapped)                   # the world has a 99 % strain pair: secondaries exist
+    b = read_bam(str(d / 'amp.bam'))
+    assert len(b['records']) == len(mapped) and any(r['flag'] & 256 for r in b['records'])
+    assert os.path.exists(d / 'amp.bam.bai')

@@ -88,3 +88,57 @@ def test_sorted_bam_from_sam_filters_flags_and_sorts(tmp_path):
     assert b['records'][3]['aux'].startswith(b'NMC\0ASC\x0adef') and b['records'][3]['aux'].endswith(b'tpAP')
     refs, nc = read_bai(str(tmp_path / 'x.bam.bai'))
     assert len(refs) == 2 and nc == 0 and 4681 in refs[0][0] or 37450 in refs[0][0]
+
+
+def test_threaded_bgzf_index_points_at_record_starts_and_long_cigars_use_cg(tmp_path):
+    """Blocks are compressed by a thread pool, so the index is built from provisional offsets and resolved afterwards: every
+    chunk of the .bai must begin at the first byte of a record of its bin, and the linear index at a record start.  A CIGAR of
+    more than 65535 operations travels as <l_seq>S<ref_len>N + CG:B,I (htslib bam_write1)."""
+    import numpy as np
+    from bam_reader import virtual_offset
+    rng = np.random.default_rng(5)
+    lines = ['@SQ\tSN:t1\tLN:3000000\n', '@SQ\tSN:t2\tLN:2000000\n']
+    for i in range(3000):
+        L = int(rng.integers(2000, 9000))
+        seq = ''.join(rng.choice(list('ACGT'), size=L))
+        qual = ''.join(chr(33 + int(x)) for x in rng.integers(0, 40, size=L))
+        ref, pos = ('t1', int(rng.integers(1, 2900000))) if i % 3 else ('t2', int(rng.integers(1, 1900000)))
+        lines.append(f'r{i}\t{16 * (i % 2)}\t{ref}\t{pos}\t60\t{L}M\t*\t0\t0\t{seq}\t{qual}\tNM:i:{i % 50}\n')
+    n_ops = 70001   # 35001 x 1M + 35000 x 1I: query 70001, reference 35001
+    lines.append('long\t0\tt1\t5\t60\t' + '1M1I' * 35000 + '1M' + '\t*\t0\t0\t' + 'A' * n_ops + '\t*\n')
+    sam = tmp_path / 'big.sam'
+    sam.write_text(''.join(lines))
+    out = str(tmp_path / 'big.bam')
+    assert bam.sam_to_sorted_bam(str(sam), out, exclude_flags=1796) == 3001
+    b = read_bam(out)
+    assert len(b['blocks']) > bam.BgzfWriter.PENDING + 10            # several rounds of the compressor pool
+    keys = [(r['tid'], r['pos'], (r['flag'] >> 4) & 1) for r in b['records']]
+    assert keys == sorted(keys)
+    # a virtual offset may name the end of a block instead of the start of the next one (htslib records the position after
+    # the previous record): compare uncompressed positions
+    ublock = {c: u for c, u in b['blocks']}
+    upos = lambda v: ublock[v >> 16] + (v & 0xffff)  # noqa: E731
+    starts = {upos(v) for v, _ in b['offsets']}
+    refs, nc = read_bai(out + '.bai')
+    n_chunks = 0
+    for tid, (bins, lin) in enumerate(refs):
+        for bn, chunks in bins.items():
+            if bn == bam.META_BIN:
+                continue
+            for beg, end in chunks:
+                assert upos(beg) in starts and beg < end, (tid, bn)
+                n_chunks += 1
+        assert all(upos(v) in starts for v in lin), tid
+    assert n_chunks > 20 and nc == 0
+    # every record is inside a chunk of its bin
+    for r, (v, _) in zip(b['records'], b['offsets']):
+        ref_len = sum(c >> 4 for c in r['cigar'] if (c & 15) in (0, 2, 3, 7, 8))
+        bn = bam.reg2bin(r['pos'], r['pos'] + max(ref_len, 1))
+        bins = refs[r['tid']][0]
+        while bn not in bins:          # htslib folds sparse bins into their parents
+            bn = (bn - 1) >> 3
+        assert any(upos(beg) <= upos(v) < upos(end) for beg, end in bins[bn]), r['name']
+    lr = [r for r in b['records'] if r['name'] == 'long'][0]
+    assert lr['cigar'] == [n_ops << 4 | 4, 35001 << 4 | 3]
+    assert lr['aux'][:8] == b'CGBI' + struct.pack('<I', n_ops) and len(lr['aux']) == 8 + 4 * n_ops
+    assert struct.unpack_from('<3I', lr['aux'], 8) == (1 << 4 | 0, 1 << 4 | 1, 1 << 4 | 0)
