@@ -9,6 +9,7 @@
 #include "map_types.h"
 #include "ext_kernels.h"
 #include "fin_kernels.h"
+#include "stitch_kernels.h"
 #include "mapper_internal.h"
 #include "../../include/mpn_map.h"
 
@@ -49,7 +50,7 @@ struct Reg {
     int32_t has_p = 0, dp_score = 0, dp_max = 0, dp_max2 = 0, n_ambi = 0;
     std::vector<uint32_t> cigar;
     int32_t aligned = 0;  // base-level extension already done (or not needed)
-    int32_t fin_pending = 0, fin_qs1 = 0, fin_rs1 = 0, fin_qspan = 0, fin_tspan = 0;  // stitched this round: CIGAR fix-up and statistics are due
+    int32_t fin_idx = -1;  // >= 0: stitched this round (its index among the round's hits): CIGAR fix-up and statistics are due
 };
 
 static inline uint64_t hash64(uint64_t key) {
@@ -360,6 +361,7 @@ struct Seg { int32_t qs, qe, rs, re, bw, anchor_i, job; };
 struct Plan {
     int32_t as1 = 0, cnt1 = 0, rs = 0, qs = 0, re = 0, qe = 0, rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
     int32_t left_job = -1, right_job = -1;
+    int32_t first_job = 0, n_jobs = 0, rid = 0, rev = 0;   // the hit's jobs in the read's job list: left?, fills (incl. placeholders), right?
     std::vector<Seg> segs;
 };
 
@@ -434,6 +436,11 @@ struct JobSink {
         jobs.push_back(j);
         return (int)jobs.size() - 1;
     }
+    // a window that gets no DP (refused by max_sw_mat, or empty): the placeholder keeps the hit's job list complete for the
+    // stitching kernel, which treats it as z-dropped at its start
+    void add_refused(int read, int rid, int rev, int qs, int ts, int reversed, int flag) {
+        add(read, rid, rev, qs, 0, ts, 0, reversed, 0, 0, 0, flag | EZ_REFUSED);
+    }
 };
 
 static void plan_align(const mpn_map_opt *opt, const mpn_index *mi, int read, int qlen, Reg &r, int n_a, u128 *a, Plan &pl,
@@ -500,9 +507,13 @@ static void plan_align(const mpn_map_opt *opt, const mpn_index *mi, int read, in
     pl.left_job = pl.right_job = -1;
     const int maxsw = opt->max_sw_mat > 0;
     auto too_big = [&](int ql, int tl) { return maxsw && (int64_t)tl * ql > opt->max_sw_mat; };
-    if (qs > 0 && rs > 0 && !too_big(qs - qs0, rs - rs0))
-        pl.left_job = sink.add(read, rid, rev, qs0, qs - qs0, rs0, rs - rs0, 1, bw, r.split_inv ? opt->zdrop_inv : opt->zdrop,
-                               opt->end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR);
+    pl.first_job = (int32_t)sink.jobs.size();
+    if (qs > 0 && rs > 0) {
+        if (!too_big(qs - qs0, rs - rs0))
+            pl.left_job = sink.add(read, rid, rev, qs0, qs - qs0, rs0, rs - rs0, 1, bw, r.split_inv ? opt->zdrop_inv : opt->zdrop,
+                                   opt->end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR);
+        else sink.add_refused(read, rid, rev, qs0, rs0, 1, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR);
+    }
     for (i = 1; i < cnt1; ++i) {
         if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
         re = (int32_t)a[as1 + i].x - kh; qe = (int32_t)a[as1 + i].y - kh;
@@ -513,24 +524,19 @@ static void plan_align(const mpn_map_opt *opt, const mpn_index *mi, int read, in
             s.qs = qs; s.qe = qe; s.rs = rs; s.re = re; s.bw = bw1; s.anchor_i = i; s.job = -1;
             if (!too_big(qe - qs, re - rs) && qe - qs > 0 && re - rs > 0)
                 s.job = sink.add(read, rid, rev, qs, qe - qs, rs, re - rs, 0, bw1, opt->zdrop, -1, EZ_APPROX_MAX);
+            else sink.add_refused(read, rid, rev, qs, rs, 0, EZ_APPROX_MAX);
             pl.segs.push_back(s);
             rs = re; qs = qe;
         }
     }
     pl.re = re; pl.qe = qe;
-    if (qe < qe0 && re < re0 && !too_big(qe0 - qe, re0 - re))
-        pl.right_job = sink.add(read, rid, rev, qe, qe0 - qe, re, re0 - re, 0, bw, opt->zdrop, opt->end_bonus, EZ_EXTZ_ONLY);
-}
-
-struct JobOut { const ExtRes *res; const uint32_t *cig; };
-
-static void append_cigar(Reg &r, int n_cigar, const uint32_t *cigar) {
-    if (n_cigar == 0) return;
-    r.has_p = 1;
-    if (!r.cigar.empty() && (r.cigar.back() & 0xf) == (cigar[0] & 0xf)) {
-        r.cigar.back() += (cigar[0] >> 4) << 4;
-        r.cigar.insert(r.cigar.end(), cigar + 1, cigar + n_cigar);
-    } else r.cigar.insert(r.cigar.end(), cigar, cigar + n_cigar);
+    if (qe < qe0 && re < re0) {
+        if (!too_big(qe0 - qe, re0 - re))
+            pl.right_job = sink.add(read, rid, rev, qe, qe0 - qe, re, re0 - re, 0, bw, opt->zdrop, opt->end_bonus, EZ_EXTZ_ONLY);
+        else sink.add_refused(read, rid, rev, qe, re, 0, EZ_EXTZ_ONLY);
+    }
+    pl.n_jobs = (int32_t)sink.jobs.size() - pl.first_job;
+    pl.rid = rid; pl.rev = rev;
 }
 
 // MPN_DEBUG_CPU: thread CPU time of the sections of a host phase (g_cpu_ns[16 + k])
@@ -541,81 +547,30 @@ struct CpuSect {
     void lap(int k);
 };
 
+// What the stitching kernel found for one hit (stitch_kernels.h) applied to the hit: coordinates, DP score, and -- when a
+// gap fill z-dropped -- the split of the hit at the last anchor before the drop (mm_align1's `dropped` branch).
 // returns true if a split remainder was produced in r2
-static bool stitch_align(const mpn_map_opt *opt, int qlen, Reg &r, Reg &r2,
-                         const u128 *a, const Plan &pl, const ExtRes *res, const ExtJob *jobs,
-                         const uint32_t *cig_pool) {
-    const int32_t rev = a[r.as].x >> 63;
-    auto cig_of = [&](int job, int *n) -> const uint32_t * {
-        const ExtRes &e = res[job];
-        const ExtJob &j = jobs[job];
-        *n = e.n_cigar;
-        (void)j;
-        return cig_pool + e.cig_pos;
-    };
+static bool apply_stitch(const mpn_map_opt *opt, int qlen, Reg &r, Reg &r2, const u128 *a, const Plan &pl, const StitchOut &so, int fin_idx) {
     bool has_r2 = false;
-    CpuSect sect(g_cpu_on);
-    int32_t rs = pl.rs, qs = pl.qs, rs1, qs1, re1, qe1, dropped = 0;
     r2.cnt = 0;
-    if (qs > 0 && rs > 0) {
-        ExtRes ez;
-        memset(&ez, 0, sizeof(ez));
-        ez.max_q = ez.max_t = ez.mqe_t = -1;
-        int nc = 0;
-        const uint32_t *cg = nullptr;
-        if (pl.left_job >= 0) { ez = res[pl.left_job]; cg = cig_of(pl.left_job, &nc); }
-        else ez.zdropped = 1;  // refused by max_sw_mat
-        if (nc > 0) { append_cigar(r, nc, cg); r.dp_score += ez.max; }
-        rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
-        qs1 = qs - (ez.reach_end ? qs - pl.qs0 : ez.max_q + 1);
-    } else { rs1 = rs; qs1 = qs; }
-    re1 = rs; qe1 = qs;
-    for (size_t si = 0; si < pl.segs.size(); ++si) {
-        const Seg &s = pl.segs[si];
-        re1 = s.re; qe1 = s.qe;
-        ExtRes ez;
-        memset(&ez, 0, sizeof(ez));
-        ez.max_q = ez.max_t = -1;
-        int nc = 0;
-        const uint32_t *cg = nullptr;
-        if (s.job >= 0) { ez = res[s.job]; cg = cig_of(s.job, &nc); }
-        else ez.zdropped = 1;
-        if (nc > 0) append_cigar(r, nc, cg);
-        if (ez.zdropped) {
-            r.has_p = 1;
-            int j;
-            for (j = s.anchor_i - 1; j >= 0; --j) if ((int32_t)a[pl.as1 + j].x <= s.rs + ez.max_t) break;
-            dropped = 1;
-            if (j < 0) j = 0;
-            r.dp_score += ez.max;
-            re1 = s.rs + (ez.max_t + 1);
-            qe1 = s.qs + (ez.max_q + 1);
-            if (pl.cnt1 - (j + 1) >= opt->min_cnt) {
-                const int old_cnt = r.cnt;
-                split_reg(r, r2, pl.as1 + j + 1 - r.as, qlen, a);
-                has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
-            }
-            break;
-        } else r.dp_score += ez.score;
+    if (so.has_p) r.has_p = 1;
+    r.dp_score += so.dp_score;
+    if (so.dropped) {
+        const Seg &sg = pl.segs[(size_t)so.drop_fill];
+        int j;
+        for (j = sg.anchor_i - 1; j >= 0; --j) if ((int32_t)a[pl.as1 + j].x <= sg.rs + so.drop_max_t) break;
+        if (j < 0) j = 0;
+        if (pl.cnt1 - (j + 1) >= opt->min_cnt) {
+            const int old_cnt = r.cnt;
+            split_reg(r, r2, pl.as1 + j + 1 - r.as, qlen, a);
+            has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
+        }
     }
-    if (!dropped && pl.qe < pl.qe0 && pl.re < pl.re0) {
-        ExtRes ez;
-        memset(&ez, 0, sizeof(ez));
-        ez.max_q = ez.max_t = ez.mqe_t = -1;
-        int nc = 0;
-        const uint32_t *cg = nullptr;
-        if (pl.right_job >= 0) { ez = res[pl.right_job]; cg = cig_of(pl.right_job, &nc); }
-        else ez.zdropped = 1;
-        if (nc > 0) { append_cigar(r, nc, cg); r.dp_score += ez.max; }
-        re1 = pl.re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
-        qe1 = pl.qe + (ez.reach_end ? pl.qe0 - pl.qe : ez.max_q + 1);
-    }
-    r.rs = rs1; r.re = re1;
-    if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; }
-    else { r.qs = qs1; r.qe = qe1; }
-    sect.lap(0);
-    // the CIGAR fix-up and the alignment statistics (mm_update_extra) are done for the whole round by aln_finish_kernel
-    if (r.has_p) { r.fin_pending = 1; r.fin_qs1 = qs1; r.fin_rs1 = rs1; r.fin_qspan = std::max(0, qe1 - qs1); r.fin_tspan = std::max(0, re1 - rs1); }
+    r.rs = so.rs1; r.re = so.re1;
+    if (pl.rev) { r.qs = qlen - so.qe1; r.qe = qlen - so.qs1; }
+    else { r.qs = so.qs1; r.qe = so.qe1; }
+    // the CIGAR fix-up and the alignment statistics (mm_update_extra) are done for the whole round by aln_finish_wave_kernel
+    r.fin_idx = r.has_p ? fin_idx : -1;
     r.aligned = 1;
     return has_r2;
 }
@@ -859,6 +814,7 @@ struct Slot {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
+    PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
     PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
     PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_jobs{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
@@ -891,13 +847,20 @@ __global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const in
 enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 48, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
 static inline int strip_windows_per_wave(int l) { return 4 >> ((l - L_STRIP) / 16); }
 
+// Device-resident results of a round's DP jobs: the job records, one result record per job, and the pool of compacted CIGAR
+// operations; `used` = [operations in the pool, windows listed for the exact second pass].  They stay in HBM for the stitching
+// kernel (valid until the worker's next round); nothing per window travels to the host.
+struct DevRound {
+    ExtJob *jobs = nullptr;
+    ExtRes *res = nullptr;
+    uint32_t *compact = nullptr;
+    unsigned long long *used = nullptr;
+};
+
 // Run one group of DP jobs on the GPU (its scratch fits the budget).  jobs[0..nj) are completed in place (scratch
-// offsets, layout); results and CIGAR ops stay in the worker's pinned buffers: *res_out / *cig_out are valid until the
-// worker's next group.
-static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const uint8_t *d_reads,
-                         const int64_t *d_read_off, const int32_t *d_read_len, int n_threads, const ExtRes **res_out,
-                         const uint32_t **cig_out, int64_t *cig_used, hipStream_t st) {
-    *res_out = nullptr; *cig_out = nullptr; *cig_used = 0;
+// offsets, layout) and uploaded to dv.jobs; dv's pointers are already offset to this group.
+static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const DevRound &dv, const uint8_t *d_reads,
+                         const int64_t *d_read_off, const int32_t *d_read_len, int n_threads, hipStream_t st) {
     if (nj == 0) return 0;
     WallTimer wt;
     const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
@@ -917,6 +880,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         Acc &A = accs[tid];
         for (int64_t j = lo; j < hi; ++j) {
             ExtJob &jb = jobs[j];
+            if (jb.flag & EZ_REFUSED) { list_id[j] = -1; band_v[j] = 0; band_c[j] = 0; redo_list[j] = -1; p_bytes[j] = 0; st_bytes[j] = 0; continue; }
             const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
             int n_col = std::min(jb.qlen, jb.tlen);
             n_col = std::min(n_col, w + 1) + 1;
@@ -985,6 +949,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     int cnt[N_LISTS] = {0}, base[N_LISTS + 1];
     for (int j = 0; j < nj; ++j) {
         ExtJob &jb = jobs[j];
+        if (list_id[j] < 0) continue;   // placeholder: no DP
         jb.p_off = p_tot; p_tot += p_bytes[j];
         jb.row_off = row_tot;
         if (band_v[j] < 0) row_tot += (int64_t)jb.qlen + jb.tlen - 1;  // band limits are stored only by the LDS-state kernels
@@ -1009,7 +974,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         int cur[N_LISTS];
         memcpy(cur, base, sizeof(cur));
         for (int l = L_STRIP; l < L_BAND; ++l) for (int k = base[l] + cnt[l]; k < base[l + 1]; ++k) flat[k] = -1;
-        for (int j = 0; j < nj; ++j) flat[cur[(int)list_id[j]]++] = j;
+        for (int j = 0; j < nj; ++j) if (list_id[j] >= 0) flat[cur[(int)list_id[j]]++] = j;
     }
     // the windows that share a wave should need the same number of steps: longest queries first within each strip list
     parallel_for(N_STRIP, nt, [&](int k, int) {
@@ -1033,24 +998,24 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
             fprintf(stderr, "[jobs] %s list %-2d n=%d cells=%.2fG max=%.1fM ext=%lld\n", fam[f], l, cnt[l], c / 1e9, mx / 1e6, (long long)ext);
         }
     }
-    if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob)) || SL.pool_P.ensure((size_t)p_tot) || SL.pool_OFF.ensure((size_t)row_tot * 2 * 4 + 16) ||
-        SL.pool_state.ensure((size_t)state_tot + 16) || SL.pool_CIG.ensure((size_t)cig_tot * 4) || SL.pool_res.ensure((size_t)nj * sizeof(ExtRes)) ||
-        SL.pool_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || SL.pool_compact.ensure((size_t)cig_tot * 4 * 2) ||
-        SL.pool_used.ensure(16))
+    if (SL.pool_P.ensure((size_t)p_tot) || SL.pool_OFF.ensure((size_t)row_tot * 2 * 4 + 16) ||
+        SL.pool_state.ensure((size_t)state_tot + 16) || SL.pool_CIG.ensure((size_t)cig_tot * 4 + 16) ||
+        SL.pool_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_res.ensure(64) || SL.pool_redo_ids.ensure((size_t)nj * 4 + 16))
         return -1;
     // the H2D copies leave from pinned memory, so they are truly asynchronous
     parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int) { memcpy(SL.pin_jobs.as<ExtJob>() + lo, jobs + lo, (size_t)(hi - lo) * sizeof(ExtJob)); }, 8);
     wt.stop_into(g_stats[27]);
-    struct { ExtJob *p; } d_jobs{SL.pool_jobs.as<ExtJob>()};
+    struct { ExtJob *p; } d_jobs{dv.jobs};
     struct { uint8_t *p; } P{SL.pool_P.as<uint8_t>()};
     struct { int32_t *p; } OFF{SL.pool_OFF.as<int32_t>()};
     struct { int8_t *p; } gstate{SL.pool_state.as<int8_t>()};
     struct { uint32_t *p; } CIG{SL.pool_CIG.as<uint32_t>()};
-    struct { ExtRes *p; } d_res{SL.pool_res.as<ExtRes>()};
+    struct { ExtRes *p; } d_res{dv.res};
     struct { int32_t *p; } d_order{SL.pool_order.as<int32_t>()};
-    uint32_t *d_compact = SL.pool_compact.as<uint32_t>();
-    unsigned long long *d_used = SL.pool_used.as<unsigned long long>();
-    MPN_HIP_CHECK(hipMemsetAsync(d_used, 0, 16, st));
+    uint32_t *d_compact = dv.compact;
+    unsigned long long *d_used = dv.used;   // [0] operations in the compact pool (the whole round), [1] windows listed for the second pass (this group)
+    int32_t *d_redo_ids = SL.pool_redo_ids.as<int32_t>();
+    MPN_HIP_CHECK(hipMemsetAsync(d_used + 1, 0, 8, st));
     MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, SL.pin_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
     MPN_HIP_CHECK(hipMemcpyAsync(d_order.p, flat, (size_t)n_flat * 4, hipMemcpyHostToDevice, st));
     ExtParams prm;
@@ -1123,7 +1088,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         // z-drop test of the gap-fill CIGARs (the kernel skips the other windows); flagged ones are recomputed with the exact maximum
         for (int k = 0; k < 2; ++k) {
             const int n = hi[k] - lo[k];
-            if (n > 0) hipLaunchKernelGGL(ext_ztest_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, prm, d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p);
+            if (n > 0) hipLaunchKernelGGL(ext_ztest_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, prm, d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p,
+                                          d_redo_ids, d_used + 1);
         }
         MPN_HIP_CHECK(hipGetLastError());
         if (timed) ev.mark(26);
@@ -1144,20 +1110,20 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     ev.mark(15);
     if (bt_ztest(main_lo, main_hi, st, true)) return -1;
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
-    ExtRes *h_res = SL.pin_res.as<ExtRes>();
-    unsigned long long *h_used = (unsigned long long *)((char *)SL.pin_res.p + (size_t)nj * sizeof(ExtRes));
-    MPN_HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long *h_used = SL.pin_res.as<unsigned long long>();
+    MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 16, hipMemcpyDeviceToHost, st));
     wt.stop_into(g_stats[28]);
     MPN_HIP_CHECK(stream_sync(st));
     wt.stop_into(g_stats[29]);
-    // second pass
-    std::vector<std::vector<int32_t>> redo_t(nt);
-    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int tid) {
-        for (int64_t j = lo; j < hi; ++j) if ((jobs[j].flag & EZ_APPROX_MAX) && h_res[j].zcode) redo_t[tid].push_back((int32_t)j);
-    });
-    std::vector<int32_t> redo;
-    for (auto &v : redo_t) redo.insert(redo.end(), v.begin(), v.end());
+    // second pass: the windows whose CIGAR failed the z-drop test were listed by the test kernel (in no particular order)
+    std::vector<int32_t> redo((size_t)h_used[1]);
+    if (!redo.empty()) {
+        if (SL.pin_order.ensure(redo.size() * 4 + 16)) return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_order.p, d_redo_ids, redo.size() * 4, hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(stream_sync(st));
+        memcpy(redo.data(), SL.pin_order.p, redo.size() * 4);
+        std::sort(redo.begin(), redo.end());
+    }
     g_stats[8] += (int64_t)redo.size();
     if (!redo.empty()) {
         const int nr = (int)redo.size();
@@ -1200,53 +1166,50 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         hipLaunchKernelGGL(ext_bt_kernel, dim3((nr + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p, nr, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
         MPN_HIP_CHECK(hipGetLastError());
         ev.mark(25);
-        MPN_HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, (size_t)nj * sizeof(ExtRes), hipMemcpyDeviceToHost, st));
-        MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 8, hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(stream_sync(st));
     }
     ev.resolve();
-    const unsigned long long used = *h_used;
-    if (SL.pin_cig.ensure((size_t)used * 4 + 16)) return -1;
-    if (used) MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_cig.p, d_compact, (size_t)used * 4, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(stream_sync(st));
-    *res_out = h_res; *cig_out = SL.pin_cig.as<uint32_t>(); *cig_used = (int64_t)used;
     wt.stop_into(g_stats[30]);
     return 0;
 }
 
-// Run all DP jobs of one round, in groups whose direction scratch stays under the budget.  The usual single group is
-// handed back in place (pinned buffers of the worker); several groups are gathered into res_store / cig_store.
+// Run all DP jobs of one round, in groups whose direction scratch stays under the budget (MPN_DP_BUDGET bytes, for tests).
+// The job records, results and compacted CIGARs of ALL groups stay in the worker's device pools (out); a group only
+// borrows the direction-matrix scratch.
 static int run_jobs(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const uint8_t *d_reads, const int64_t *d_read_off,
-                    const int32_t *d_read_len, int n_threads, std::vector<ExtRes> &res_store, std::vector<uint32_t> &cig_store,
-                    const ExtRes **res_out, const uint32_t **cig_out, hipStream_t st) {
-    const int64_t budget = (int64_t)40 << 30;  // bytes of direction codes per group
-    res_store.clear(); cig_store.clear();
-    *res_out = nullptr; *cig_out = nullptr;
+                    const int32_t *d_read_len, int n_threads, DevRound &out, hipStream_t st) {
+    static const int64_t budget = []() { const char *e = getenv("MPN_DP_BUDGET"); return e ? std::max<int64_t>(1 << 20, atoll(e)) : (int64_t)40 << 30; }();
     std::vector<int> cuts{0};
+    int64_t cig_all = 0;
     {
         int64_t acc = 0;
         for (int j = 0; j < nj; ++j) {
             const ExtJob &jb = jobs[j];
+            if (jb.flag & EZ_REFUSED) continue;
             const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
             const int nc = std::min(std::min(jb.qlen, jb.tlen), w + 1) + 1;
             const int64_t sz = ((int64_t)jb.qlen + jb.tlen - 1) * (nc <= 1024 ? std::max(128, 2 * nc) : nc);  // upper bound of every layout
             if (j > cuts.back() && acc + sz > budget) { cuts.push_back(j); acc = 0; }
             acc += sz;
+            cig_all += jb.qlen + jb.tlen + 2;
         }
         cuts.push_back(nj);
     }
+    Slot &SL = *tl_slot;
+    // (the compact pool holds every window's operations, and once more those of the windows that take the second pass)
+    if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob) + 16) || SL.pool_res.ensure((size_t)nj * sizeof(ExtRes) + 16) ||
+        SL.pool_compact.ensure((size_t)cig_all * 4 * 2 + 16) || SL.pool_used.ensure(32))
+        return -1;
+    out.jobs = SL.pool_jobs.as<ExtJob>(); out.res = SL.pool_res.as<ExtRes>(); out.compact = SL.pool_compact.as<uint32_t>();
+    out.used = SL.pool_used.as<unsigned long long>();
+    MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 32, st));   // [0] compacted ops, [1] second-pass windows, [2] stitched ops
     const int n_groups = (int)cuts.size() - 1;
     for (int g = 0; g < n_groups; ++g) {
         const int lo = cuts[g], hi = cuts[g + 1];
-        const ExtRes *r = nullptr; const uint32_t *c = nullptr; int64_t used = 0;
-        if (run_job_group(rv, opt, jobs + lo, hi - lo, d_reads, d_read_off, d_read_len, n_threads, &r, &c, &used, st)) return -1;
-        if (n_groups == 1) { *res_out = r; *cig_out = c; return 0; }
-        const int64_t cbase = (int64_t)cig_store.size();
-        res_store.resize((size_t)hi);
-        for (int k = 0; k < hi - lo; ++k) { res_store[lo + k] = r[k]; res_store[lo + k].cig_pos += cbase; }
-        cig_store.insert(cig_store.end(), c, c + used);
+        DevRound dv = out;
+        dv.jobs += lo; dv.res += lo;
+        if (run_job_group(rv, opt, jobs + lo, hi - lo, dv, d_reads, d_read_off, d_read_len, n_threads, st)) return -1;
     }
-    *res_out = res_store.data(); *cig_out = cig_store.data();
     return 0;
 }
 
@@ -1254,104 +1217,134 @@ static int run_jobs(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int
 
 using namespace mpn;
 
-// CIGAR fix-up + statistics of every alignment stitched in this round, on the device (fin_kernels.h): the stitched CIGARs
-// go up in one block, the fixed ones and eight integers per alignment come back.
-static int finish_alignments(const mpn_index *idx, const mpn_map_opt *opt, ReadState *rs, int n, const uint8_t *d_seqs, const int64_t *d_off,
-                             const int32_t *d_len, int n_threads, hipStream_t st) {
-    std::vector<int64_t> op_off((size_t)n + 1, 0);
-    std::vector<int32_t> job_off((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) {
-        int64_t ops = 0;
-        int32_t jobs = 0;
-        for (Reg &r : rs[i].regs) {
-            if (!r.fin_pending) continue;
-            if (r.cigar.empty()) { r.fin_pending = 0; r.blen = r.mlen = 0; r.dp_max = 0; continue; }  // (what update_extra leaves for an empty CIGAR)
-            ops += (int64_t)r.cigar.size(); ++jobs;
-        }
-        op_off[(size_t)i + 1] = op_off[(size_t)i] + ops; job_off[(size_t)i + 1] = job_off[(size_t)i] + jobs;
-    }
-    const int64_t n_ops = op_off[(size_t)n];
-    const int n_jobs = job_off[(size_t)n];
-    if (n_jobs == 0) return 0;
+// Stitching + CIGAR fix-up + statistics of every hit aligned in this round, on the device (stitch_kernels.h, fin_kernels.h):
+// the windows' CIGARs are concatenated per hit in HBM, fixed and measured there; the host gets 56 + 32 bytes per hit, and the
+// fixed CIGARs only when the caller wants text (need_cigar).
+static bool g_need_cigar = true;   // set per mapping call (the calls take turns: g_call_mu)
+
+static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadState *rs, int n, const int32_t *seq_len, const DevRound &dv,
+                             int64_t cig_cap, const std::vector<int> &job_base, const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len,
+                             int n_threads, hipStream_t st) {
+    std::vector<int32_t> sr_base((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) sr_base[(size_t)i + 1] = sr_base[(size_t)i] + (int32_t)rs[i].pending.size();
+    const int n_sr = sr_base[(size_t)n];
+    if (n_sr == 0) return 0;
     Slot &SL = *tl_slot;
-    if (SL.pin_fin_cig.ensure((size_t)n_ops * 4 + 16) || SL.pin_fin_jobs.ensure((size_t)n_jobs * sizeof(FinJob) + 16) ||
-        SL.pin_fin_out.ensure((size_t)n_jobs * sizeof(FinOut) + 16))
+    if (SL.pin_fin_jobs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut)) + 64) ||
+        SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pool_souts.ensure((size_t)n_sr * sizeof(StitchOut) + 16) ||
+        SL.pool_fin_jobs.ensure((size_t)n_sr * sizeof(FinJob) + 16) || SL.pool_fin_out.ensure((size_t)n_sr * sizeof(FinOut) + 16) ||
+        SL.pool_fin_cig.ensure((size_t)cig_cap * 4 + 16))
         return -1;
-    uint32_t *h_cig = SL.pin_fin_cig.as<uint32_t>();
-    FinJob *h_jobs = SL.pin_fin_jobs.as<FinJob>();
-    FinOut *h_out = SL.pin_fin_out.as<FinOut>();
+    StitchReg *h_sr = SL.pin_fin_jobs.as<StitchReg>();
     parallel_for(n, n_threads, [&](int i, int) {
-        int64_t o = op_off[(size_t)i];
-        int32_t j = job_off[(size_t)i];
-        for (Reg &r : rs[i].regs) {
-            if (!r.fin_pending) continue;
-            memcpy(h_cig + o, r.cigar.data(), r.cigar.size() * 4);
-            h_jobs[j++] = FinJob{o, 0, (int32_t)r.cigar.size(), i, r.rid, (int32_t)r.rev, r.fin_qs1, r.fin_rs1, r.fin_qspan, r.fin_tspan};
-            o += (int64_t)r.cigar.size();
+        const ReadState &S = rs[i];
+        for (size_t pi = 0; pi < S.pending.size(); ++pi) {
+            const Plan &pl = S.plans[pi];
+            h_sr[(size_t)sr_base[(size_t)i] + pi] = StitchReg{pl.first_job + job_base[(size_t)i], pl.n_jobs, pl.qs, pl.rs, pl.qe, pl.re, pl.qs0, pl.qe0, i, pl.rid, pl.rev, 0};
         }
     }, 9);
-    // launch lists by LDS need (CIGAR, shift table, both code arrays): three LDS classes, the rest works in global scratch
-    // (a fourth class of 152 KB for the longest alignments runs them faster but blocks whole CUs: -2 % under the full pipeline)
-    constexpr int NC = 3;  // LDS classes; list NC works in global scratch
+    StitchReg *d_sr = SL.pool_sregs.as<StitchReg>();
+    StitchOut *d_so = SL.pool_souts.as<StitchOut>();
+    FinJob *d_fj = SL.pool_fin_jobs.as<FinJob>();
+    FinOut *d_fo = SL.pool_fin_out.as<FinOut>();
+    uint32_t *d_cig = SL.pool_fin_cig.as<uint32_t>();
+    unsigned long long *d_out_used = dv.used + 2;
+    StitchOut *h_so = SL.pin_fin_out.as<StitchOut>();
+    FinOut *h_fo = reinterpret_cast<FinOut *>(h_so + n_sr);
+    unsigned long long *h_out_used = reinterpret_cast<unsigned long long *>(h_fo + n_sr);
+    EvTimer ev(st);
+    MPN_HIP_CHECK(hipMemsetAsync(d_out_used, 0, 8, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(d_sr, h_sr, (size_t)n_sr * sizeof(StitchReg), hipMemcpyHostToDevice, st));
+    ev.skip();
+    hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)std::min(n_sr, 256 * 32)), dim3(64), 0, st, (const StitchReg *)d_sr, n_sr, (const ExtJob *)dv.jobs,
+                       (const ExtRes *)dv.res, (const uint32_t *)dv.compact, d_cig, d_out_used, d_so, d_fj);
+    MPN_HIP_CHECK(hipGetLastError());
+    ev.mark(54);
+    MPN_HIP_CHECK(hipMemcpyAsync(h_so, d_so, (size_t)n_sr * sizeof(StitchOut), hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_out_used, d_out_used, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    const int64_t n_ops = (int64_t)*h_out_used;
+    // hits: coordinates, score, splits at z-drops
+    parallel_for(n, n_threads, [&](int i, int) {
+        ReadState &S = rs[i];
+        if (S.pending.empty()) return;
+        int shift = 0;
+        for (size_t pi = 0; pi < S.pending.size(); ++pi) {
+            const int k = S.pending[pi] + shift, fi = sr_base[(size_t)i] + (int)pi;
+            Reg r2;
+            const bool has = apply_stitch(opt, seq_len[i], S.regs[(size_t)k], r2, S.a.data(), S.plans[pi], h_so[fi], fi);
+            if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
+        }
+    }, 4);
+    // launch lists of the finishing kernel by LDS need (CIGAR, shift table, both code arrays): three LDS classes, the rest works
+    // in global scratch (a fourth class of 152 KB for the longest alignments runs them faster but blocks whole CUs: -2 % under
+    // the full pipeline).  Hits without operations have nothing to fix (what update_extra leaves for an empty CIGAR).
+    constexpr int NC = 3;
     static const size_t kLds[NC] = {(size_t)16 << 10, (size_t)32 << 10, (size_t)64 << 10};
     std::vector<int32_t> lists[NC + 1];
+    std::vector<int64_t> code_offs;
     int64_t code_bytes = 0;
-    for (int j = 0; j < n_jobs; ++j) {
-        const size_t codes = (size_t)((h_jobs[j].qspan + 3) & ~3) + (size_t)((h_jobs[j].tspan + 3) & ~3);
-        const size_t need = (size_t)h_jobs[j].n_cigar * 8 + codes + 16;
+    for (int j = 0; j < n_sr; ++j) {
+        const StitchOut &so = h_so[j];
+        if (so.n_ops == 0 || !so.has_p) continue;
+        const size_t codes = (size_t)((std::max(0, so.qe1 - so.qs1) + 3) & ~3) + (size_t)((std::max(0, so.re1 - so.rs1) + 3) & ~3);
+        const size_t need = (size_t)so.n_ops * 8 + codes + 16;
         int c = 0;
         while (c < NC && need > kLds[c]) ++c;
-        if (c == NC) { h_jobs[j].code_off = code_bytes; code_bytes += (int64_t)codes; }
+        if (c == NC) { code_offs.push_back(code_bytes); code_bytes += (int64_t)codes; }
         lists[c].push_back(j);
     }
-    DevBuf<uint32_t> d_cig, d_aux;
-    DevBuf<uint8_t> d_codes;
-    DevBuf<FinJob> d_jobs;
-    DevBuf<FinOut> d_out;
-    if (d_cig.alloc((size_t)n_ops) || d_jobs.alloc((size_t)n_jobs) || d_out.alloc((size_t)n_jobs)) return -1;
-    if (!lists[NC].empty() && (d_aux.alloc((size_t)n_ops) || d_codes.alloc((size_t)code_bytes + 16))) return -1;
-    MPN_HIP_CHECK(hipMemcpyAsync(d_cig.p, h_cig, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, h_jobs, (size_t)n_jobs * sizeof(FinJob), hipMemcpyHostToDevice, st));
-    FinParams prm;
-    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) prm.mat[i * 5 + j] = (int8_t)(i == j ? opt->a : -opt->b); prm.mat[i * 5 + 4] = (int8_t)-opt->sc_ambi; }
-    for (int i = 0; i < 5; ++i) prm.mat[20 + i] = (int8_t)-opt->sc_ambi;
-    prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e;
     std::vector<int32_t> order;
     int base[NC + 1];
     for (int c = 0; c <= NC; ++c) { base[c] = (int)order.size(); order.insert(order.end(), lists[c].begin(), lists[c].end()); }
-    DevBuf<int32_t> d_list;
-    if (d_list.upload(order.data(), order.size(), st)) return -1;
-    const RefView rvw{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
-    EvTimer ev(st);
-    static std::once_flag fin_attr;
-    std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[NC - 1]); });
-    for (int c = 0; c < NC; ++c)
-        if (!lists[c].empty())
-            hipLaunchKernelGGL(aln_finish_wave_kernel<true>, dim3((unsigned)std::min<size_t>(lists[c].size(), 256 * 64)), dim3(64), kLds[c], st, (const FinJob *)d_jobs.p,
-                               (const int32_t *)d_list.p + base[c], (int)lists[c].size(), d_cig.p, (uint32_t *)nullptr, (uint8_t *)nullptr, d_seqs, d_off, d_len, rvw, prm, d_out.p);
-    if (!lists[NC].empty())
-        hipLaunchKernelGGL(aln_finish_wave_kernel<false>, dim3((unsigned)std::min<size_t>(lists[NC].size(), 256 * 64)), dim3(64), 0, st, (const FinJob *)d_jobs.p,
-                           (const int32_t *)d_list.p + base[NC], (int)lists[NC].size(), d_cig.p, d_aux.p, d_codes.p, d_seqs, d_off, d_len, rvw, prm, d_out.p);
-    MPN_HIP_CHECK(hipGetLastError());
-    ev.mark(52);
-    MPN_HIP_CHECK(hipMemcpyAsync(h_out, d_out.p, (size_t)n_jobs * sizeof(FinOut), hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(h_cig, d_cig.p, (size_t)n_ops * 4, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(stream_sync(st));
+    if (!order.empty()) {
+        DevBuf<uint32_t> d_aux;
+        DevBuf<uint8_t> d_codes;
+        DevBuf<int64_t> d_code_offs;
+        DevBuf<int32_t> d_list;
+        if (!lists[NC].empty() && (d_aux.alloc((size_t)n_ops + 1) || d_codes.alloc((size_t)code_bytes + 16) || d_code_offs.upload(code_offs.data(), code_offs.size(), st)))
+            return -1;
+        if (d_list.upload(order.data(), order.size(), st)) return -1;
+        FinParams prm;
+        for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) prm.mat[i * 5 + j] = (int8_t)(i == j ? opt->a : -opt->b); prm.mat[i * 5 + 4] = (int8_t)-opt->sc_ambi; }
+        for (int i = 0; i < 5; ++i) prm.mat[20 + i] = (int8_t)-opt->sc_ambi;
+        prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e;
+        const RefView rvw{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
+        ev.skip();
+        static std::once_flag fin_attr;
+        std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[NC - 1]); });
+        for (int c = 0; c < NC; ++c)
+            if (!lists[c].empty())
+                hipLaunchKernelGGL(aln_finish_wave_kernel<true>, dim3((unsigned)std::min<size_t>(lists[c].size(), 256 * 64)), dim3(64), kLds[c], st, (const FinJob *)d_fj,
+                                   (const int32_t *)d_list.p + base[c], (int)lists[c].size(), d_cig, (uint32_t *)nullptr, (uint8_t *)nullptr, d_seqs, d_off, d_len, rvw, prm, d_fo,
+                                   (const int64_t *)nullptr);
+        if (!lists[NC].empty())
+            hipLaunchKernelGGL(aln_finish_wave_kernel<false>, dim3((unsigned)std::min<size_t>(lists[NC].size(), 256 * 64)), dim3(64), 0, st, (const FinJob *)d_fj,
+                               (const int32_t *)d_list.p + base[NC], (int)lists[NC].size(), d_cig, d_aux.p, d_codes.p, d_seqs, d_off, d_len, rvw, prm, d_fo,
+                               (const int64_t *)d_code_offs.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        ev.mark(52);
+        MPN_HIP_CHECK(hipMemcpyAsync(h_fo, d_fo, (size_t)n_sr * sizeof(FinOut), hipMemcpyDeviceToHost, st));
+        if (g_need_cigar) {
+            if (SL.pin_fin_cig.ensure((size_t)n_ops * 4 + 16)) return -1;
+            MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_fin_cig.p, d_cig, (size_t)n_ops * 4, hipMemcpyDeviceToHost, st));
+        }
+        MPN_HIP_CHECK(stream_sync(st));
+    }
     ev.resolve();
     g_stats[53] += n_ops;
+    const uint32_t *h_cig = SL.pin_fin_cig.as<uint32_t>();
     parallel_for(n, n_threads, [&](int i, int) {
-        int64_t o = op_off[(size_t)i];
-        int32_t j = job_off[(size_t)i];
         for (Reg &r : rs[i].regs) {
-            if (!r.fin_pending) continue;
-            const FinOut &f = h_out[j++];
-            const size_t old_n = r.cigar.size();
-            r.cigar.assign(h_cig + o, h_cig + o + f.n_cigar);
-            o += (int64_t)old_n;
+            if (r.fin_idx < 0) continue;
+            const StitchOut &so = h_so[r.fin_idx];
+            if (so.n_ops == 0) { r.blen = r.mlen = 0; r.dp_max = 0; r.fin_idx = -1; continue; }   // (what update_extra leaves for an empty CIGAR)
+            const FinOut &f = h_fo[r.fin_idx];
+            if (g_need_cigar) r.cigar.assign(h_cig + so.cig_off, h_cig + so.cig_off + f.n_cigar);
             if (f.qshift) { if (r.rev) r.qe -= f.qshift; else r.qs += f.qshift; }
             r.rs += f.tshift;
             r.blen = f.blen; r.mlen = f.mlen; r.n_ambi += f.n_ambi; r.dp_max = f.dp_max;
-            r.fin_pending = 0;
+            r.fin_idx = -1;
         }
     }, 9);
     return 0;
@@ -1457,26 +1450,14 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             wt.stop_into(g_stats[20]);
             if (!any) break;
             ++g_stats[7];
-            std::vector<ExtRes> res_store;
-            std::vector<uint32_t> cig_store;
-            const ExtRes *res = nullptr;
-            const uint32_t *cig = nullptr;
+            DevRound dv;
+            int64_t cig_cap = 0;
+            for (const ExtJob &jb : sink.jobs) cig_cap += jb.qlen + jb.tlen + 2;
             if (run_jobs(RefView{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns}, opt, sink.jobs.data(),
-                         (int)sink.jobs.size(), d_seqs.p, d_off.p, d_len.p, n_threads, res_store, cig_store, &res, &cig, st))
+                         (int)sink.jobs.size(), d_seqs.p, d_off.p, d_len.p, n_threads, dv, st))
                 return -1;
             wt.stop_into(g_stats[21]);
-            parallel_for(n, n_threads, [&](int i, int) {
-                ReadState &S = rs[i];
-                if (S.pending.empty()) return;
-                int shift = 0;
-                for (size_t pi = 0; pi < S.pending.size(); ++pi) {
-                    const int k = S.pending[pi] + shift;
-                    Reg r2;
-                    const bool has = stitch_align(opt, seq_len[i], S.regs[k], r2, S.a.data(), S.plans[pi], res, sink.jobs.data(), cig);
-                    if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
-                }
-            }, 4);
-            if (finish_alignments(idx, opt, rs, n, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
+            if (stitch_and_finish(idx, opt, rs, n, seq_len, dv, cig_cap, job_base, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
             wt.stop_into(g_stats[22]);
         }
     }
@@ -1779,6 +1760,7 @@ extern "C" int64_t mpn_map_batch_q(const mpn_index *idx, const mpn_map_opt *opt,
     std::vector<ReadState> rs;
     std::vector<int32_t> rep_len;
     int n_threads = 1;
+    g_need_cigar = paf != nullptr || opt->out_sam != 0;   // columns only: the CIGARs never leave the GPU
     if (map_batch_core(idx, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
     std::vector<std::vector<Reg>*> regs((size_t)n);
     for (int i = 0; i < n; ++i) regs[(size_t)i] = &rs[(size_t)i].regs;
@@ -1828,6 +1810,7 @@ extern "C" int mpn_map_batch_part(const mpn_index *part, const mpn_map_opt *opt,
         std::vector<ReadState> rs;
         std::vector<int32_t> rep_len;
         int n_threads = 1;
+        g_need_cigar = true;   // (whether text is wanted is only known at mpn_hits_finish)
         if (map_batch_core(part, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
         parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
             for (int64_t i = lo; i < hi; ++i) {
@@ -1960,18 +1943,21 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
         j.read = i; j.rid = i; j.rev = 0; j.qs = 0; j.qlen = q_len[i]; j.ts = 0; j.tlen = t_len[i]; j.reversed = 0;
         j.w = w[i]; j.zdrop = zdrop[i]; j.end_bonus = end_bonus[i]; j.flag = flag[i];
     }
-    std::vector<ExtRes> res_store;
-    std::vector<uint32_t> cig_store;
-    const ExtRes *res = nullptr;
-    const uint32_t *cig = nullptr;
     g_force_kernel = force_kernel;
     // no second pass here: the caller asks for exactly one DP per pair
     mpn_map_opt o2 = *opt;
     o2.zdrop = 0x3fffffff;
-    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, jobs.data(), n, d_reads.p, d_qoff.p, d_qlen.p, 4, res_store, cig_store,
-                            &res, &cig, st);
+    DevRound dv;
+    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, jobs.data(), n, d_reads.p, d_qoff.p, d_qlen.p, 4, dv, st);
     g_force_kernel = 0;
     if (rc) return rc;
+    // (the product keeps these on the device for the stitching kernel; the stage test reads them back)
+    std::vector<ExtRes> res((size_t)n);
+    unsigned long long h_used = 0;
+    MPN_HIP_CHECK(hipMemcpy(res.data(), dv.res, (size_t)n * sizeof(ExtRes), hipMemcpyDeviceToHost));
+    MPN_HIP_CHECK(hipMemcpy(&h_used, dv.used, 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cig((size_t)h_used + 1);
+    if (h_used) MPN_HIP_CHECK(hipMemcpy(cig.data(), dv.compact, (size_t)h_used * 4, hipMemcpyDeviceToHost));
     int64_t used = 0;
     for (int i = 0; i < n; ++i) {
         const ExtRes &e = res[i];
@@ -1980,7 +1966,7 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
         o[8] = e.n_cigar;
         cig_off[i] = used;
         if (used + e.n_cigar > cigar_cap) return -3;
-        if (e.n_cigar) memcpy(cigar_pool + used, cig + e.cig_pos, (size_t)e.n_cigar * 4);
+        if (e.n_cigar) memcpy(cigar_pool + used, cig.data() + e.cig_pos, (size_t)e.n_cigar * 4);
         used += e.n_cigar;
     }
     return 0;

@@ -885,20 +885,27 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
                                                        ExtParams prm, const uint8_t *__restrict__ reads,
                                                        const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                                                        RefView rv,
-                                                       const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res) {
+                                                       const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res,
+                                                       int32_t *__restrict__ redo_ids, unsigned long long *__restrict__ n_redo) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
     const int jid = order[k];
     if (jid < 0) return;  // padding of a strip launch list
     const ExtJob jb = jobs[jid];
     if (!(jb.flag & EZ_APPROX_MAX)) return;  // only gap fills are tested
+    // a window that fails the test is listed for the exact second pass: the host reads the COUNT (8 bytes), and the ids only
+    // when there are any -- not a result record per window
+    auto report = [&](int z) {
+        res[jid].zcode = z;
+        if (z) redo_ids[atomicAdd(n_redo, 1ULL)] = jid;
+    };
     const ExtRes r = res[jid];
     // No walk needed when a drop of more than zdrop is impossible: prefix scores satisfy S(i) <= a * (matches up to i)
     // and S(j) >= F - a * (matches after j), so S(i) - S(j) <= a * min(qlen, tlen) - F for the window's final score F.
     // (Only for the strip kernel, whose corner score is exact.)
     if (jb.layout == 1 && r.do_bt && !r.zdropped &&
         (int64_t)prm.sc_mch * (jb.qlen < jb.tlen ? jb.qlen : jb.tlen) - r.score <= prm.zdrop_thres) {
-        res[jid].zcode = 0;
+        report(0);
         return;
     }
     const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
@@ -931,7 +938,7 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
             } else { mx = score; max_i = i; max_j = j; }
         }
     }
-    res[jid].zcode = max_zdrop > prm.zdrop_thres ? 1 : 0;
+    report(max_zdrop > prm.zdrop_thres ? 1 : 0);
 }
 
 }  // namespace mpn

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64) void aln_finish_wave_kernel(const FinJob *__res
                                                              uint32_t *__restrict__ CIG, uint32_t *__restrict__ AUX, uint8_t *__restrict__ CODES,
                                                              const uint8_t *__restrict__ reads,
                                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                             RefView rv, FinParams prm, FinOut *__restrict__ out) {
+                                                             RefView rv, FinParams prm, FinOut *__restrict__ out,
+                                                             const int64_t *__restrict__ code_offs = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fin_lds[];
     __shared__ int32_t sum_l[64][8];
     const int lane = threadIdx.x;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(64) void aln_finish_wave_kernel(const FinJob *__res
         uint32_t *c_l, *aux;
         uint8_t *q_l;
         if constexpr (IN_LDS) { c_l = reinterpret_cast<uint32_t *>(fin_lds); aux = c_l + n; q_l = reinterpret_cast<uint8_t *>(aux + n); }
-        else { c_l = cg; aux = AUX + jb.cig_off; q_l = CODES + jb.code_off; }
+        else { c_l = cg; aux = AUX + jb.cig_off; q_l = CODES + (code_offs ? code_offs[li] : jb.code_off); }  // (code_offs: by list position)
         uint8_t *t_l = q_l + ((jb.qspan + 3) & ~3);
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from map_cases import small_world
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -417,3 +418,45 @@ def test_other_index_and_scoring_options(world, k, w, kw):
     finally:
         gidx.close()
         oidx.close()
+
+
+def test_columns_without_text_equal_columns_with_text(world):
+    """With columns only the stitched CIGARs never leave the GPU (csrc/stitch_kernels.h); the numbers must not depend on it."""
+    from megapath_nano_amd import mapper
+    gen, reads, gidx, _ = world
+    gopt = mapper.default_opt(best_n=50, pri_ratio=1.0)
+    packed = mapper.PackedReads([r['name'] for r in reads], [r['seq'] for r in reads])
+    paf, c1 = mapper.map_batch_ex(gidx, gopt, packed, want_paf=True, want_cols=True)
+    _, c2 = mapper.map_batch_ex(gidx, gopt, packed, want_paf=False, want_cols=True)
+    assert len(c1['rid']) == paf.count('\n') > 0
+    for k in c1:
+        assert np.array_equal(c1[k], c2[k]), k
+
+
+def test_dp_groups_share_the_round_pools():
+    """A round whose direction matrices exceed the scratch budget runs in several groups; job records, results and CIGARs of
+    all groups stay in the round's device pools for the stitching kernel.  MPN_DP_BUDGET (read once per process) forces many
+    groups on a small world; the PAF must equal the oracle's."""
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from map_cases import small_world, hard_reads
+from megapath_nano_amd import mapper
+from oracle import mm2_bindings as mb
+gen, reads = small_world(seed=5, n_genomes=5, glen=120000, n_reads=40, mean_len=4000)
+reads += hard_reads(gen)
+gidx, oidx = mapper.Index(gen), mb.Index(gen)
+gopt, oopt = mapper.default_opt(), mb.default_opt()
+names = [r['name'] for r in reads]
+got = mapper.map_batch(gidx, gopt, names, [r['seq'] for r in reads])
+want = ''.join(mb.map_read(oidx, oopt, r['name'], r['seq'])[2] for r in reads)
+by = {}
+for line in got.splitlines(keepends=True):
+    by.setdefault(line.split('\t', 1)[0], []).append(line)
+assert ''.join(''.join(by.get(n_, [])) for n_ in names) == want
+assert mapper.last_stats()['dp_jobs'] > 200
+print('OK')
+''' % (ROOT, os.path.join(ROOT, 'tests'))
+    env = dict(os.environ, MPN_DP_BUDGET=str(2 << 20))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
