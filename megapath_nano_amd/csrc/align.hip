@@ -10,6 +10,7 @@
 #include "ext_kernels.h"
 #include "fin_kernels.h"
 #include "stitch_kernels.h"
+#include "plan_kernels.h"
 #include "mapper_internal.h"
 #include "../../include/mpn_map.h"
 
@@ -355,190 +356,6 @@ static void split_reg(Reg &r, Reg &r2, int n, int qlen, const u128 *a) {
     r.split |= 1; r2.split |= 2;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// planning / stitching of one hit (minimap2 mm_align1 split in two around the GPU DP)
-struct Seg { int32_t qs, qe, rs, re, bw, anchor_i, job; };
-struct Plan {
-    int32_t as1 = 0, cnt1 = 0, rs = 0, qs = 0, re = 0, qe = 0, rs0 = 0, qs0 = 0, re0 = 0, qe0 = 0;
-    int32_t left_job = -1, right_job = -1;
-    int32_t first_job = 0, n_jobs = 0, rid = 0, rev = 0;   // the hit's jobs in the read's job list: left?, fills (incl. placeholders), right?
-    std::vector<Seg> segs;
-};
-
-static void fix_bad_ends(const Reg &r, const u128 *a, int bw, int min_match, int32_t *as, int32_t *cnt) {
-    *as = r.as; *cnt = r.cnt;
-    if (r.cnt < 3) return;
-    int32_t m, l;
-    m = l = a[r.as].y >> 32 & 0xff;
-    for (int i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
-        const int32_t q_span = a[i].y >> 32 & 0xff;
-        if (a[i].y & SEED_LONG_JOIN) break;
-        const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-        const int32_t min = lr < lq ? lr : lq, max = lr > lq ? lr : lq;
-        if (max - min > l >> 1) *as = i;
-        l += min;
-        m += min < q_span ? min : q_span;
-        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
-    }
-    *cnt = r.as + r.cnt - *as;
-    m = l = a[r.as + r.cnt - 1].y >> 32 & 0xff;
-    for (int i = r.as + r.cnt - 2; i > *as; --i) {
-        const int32_t q_span = a[i + 1].y >> 32 & 0xff;
-        if (a[i + 1].y & SEED_LONG_JOIN) break;
-        const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
-        const int32_t min = lr < lq ? lr : lq, max = lr > lq ? lr : lq;
-        if (max - min > l >> 1) *cnt = i + 1 - *as;
-        l += min;
-        m += min < q_span ? min : q_span;
-        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
-    }
-}
-
-static void filter_bad_seeds(int as1, int cnt1, u128 *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
-    std::vector<int> K;
-    for (int i = 1; i < cnt1; ++i) {
-        const int gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - ((int32_t)a[as1 + i].x - (int32_t)a[as1 + i - 1].x);
-        if (gap < -min_gap || gap > min_gap) K.push_back(i);
-    }
-    const int n = (int)K.size();
-    if (n <= 1) return;
-    int max = 0, max_st = -1, max_en = -1;
-    for (int k = 0;; ++k) {
-        int gap, l, n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1;
-        if (k == n || k >= max_en) {
-            if (max_en > 0) for (int i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= SEED_IGNORE;
-            max = 0; max_st = max_en = -1;
-            if (k == n) break;
-        }
-        const int i = K[k];
-        gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - (int32_t)(a[as1 + i].x - a[as1 + i - 1].x);
-        if (gap > 0) n_ins += gap; else n_del += -gap;
-        const int qs = (int32_t)a[as1 + i - 1].y, rs = (int32_t)a[as1 + i - 1].x;
-        for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
-            const int j = K[l];
-            if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
-            gap = ((int32_t)a[as1 + j].y - (int32_t)a[as1 + j - 1].y) - (int32_t)(a[as1 + j].x - a[as1 + j - 1].x);
-            if (gap > 0) n_ins += gap; else n_del += -gap;
-            const int diff = n_ins + n_del - abs(n_ins - n_del);
-            if (max_diff < diff) { max_diff = diff; max_diff_l = l; }
-        }
-        if (max_diff > diff_thres && max_diff > max) { max = max_diff; max_st = k; max_en = max_diff_l; }
-    }
-}
-
-struct JobSink {
-    std::vector<ExtJob> jobs;
-    int add(int read, int rid, int rev, int qs, int qlen, int ts, int tlen, int reversed, int w, int zdrop, int end_bonus, int flag) {
-        ExtJob j;
-        memset(&j, 0, sizeof(j));
-        j.read = read; j.rid = rid; j.rev = rev; j.qs = qs; j.qlen = qlen; j.ts = ts; j.tlen = tlen; j.reversed = reversed;
-        j.w = w; j.zdrop = zdrop; j.end_bonus = end_bonus; j.flag = flag;
-        jobs.push_back(j);
-        return (int)jobs.size() - 1;
-    }
-    // a window that gets no DP (refused by max_sw_mat, or empty): the placeholder keeps the hit's job list complete for the
-    // stitching kernel, which treats it as z-dropped at its start
-    void add_refused(int read, int rid, int rev, int qs, int ts, int reversed, int flag) {
-        add(read, rid, rev, qs, 0, ts, 0, reversed, 0, 0, 0, flag | EZ_REFUSED);
-    }
-};
-
-static void plan_align(const mpn_map_opt *opt, const mpn_index *mi, int read, int qlen, Reg &r, int n_a, u128 *a, Plan &pl,
-                       JobSink &sink) {
-    const int32_t rid = a[r.as].x << 1 >> 33, rev = a[r.as].x >> 63;
-    const int32_t tlen_all = mi->lens[rid], kh = mi->k >> 1;
-    const int bw = (int)(opt->bw * 1.5 + 1.);
-    int32_t as1, cnt1, l, i;
-    fix_bad_ends(r, a, opt->bw, opt->min_chain_score * 2, &as1, &cnt1);
-    filter_bad_seeds(as1, cnt1, a, 10, 40, opt->max_gap >> 1, 10);
-    int32_t rs = (int32_t)a[as1].x - kh, qs = (int32_t)a[as1].y - kh;
-    int32_t re = (int32_t)a[as1 + cnt1 - 1].x - kh, qe = (int32_t)a[as1 + cnt1 - 1].y - kh;
-    int32_t rs0, qs0, re0, qe0, rs1 = 0, qs1 = 0, re1, qe1;
-    rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
-    qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
-    if (rs0 < 0) rs0 = 0;
-    for (i = r.as - 1, l = 0; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
-        const int32_t x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff), y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
-        if (x < rs0 && y < qs0) {
-            if (++l > opt->min_cnt) {
-                l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
-                rs1 = rs0 - l; qs1 = qs0 - l;
-                if (rs1 < 0) rs1 = 0;
-                break;
-            }
-        }
-    }
-    if (qs > 0 && rs > 0) {
-        l = qs < opt->max_gap ? qs : opt->max_gap;
-        qs1 = qs1 > qs - l ? qs1 : qs - l;
-        qs0 = qs0 < qs1 ? qs0 : qs1;
-        l += l * opt->a > opt->q ? (l * opt->a - opt->q) / opt->e : 0;
-        l = l < opt->max_gap ? l : opt->max_gap;
-        l = l < rs ? l : rs;
-        rs1 = rs1 > rs - l ? rs1 : rs - l;
-        rs0 = rs0 < rs1 ? rs0 : rs1;
-        rs0 = rs0 < rs ? rs0 : rs;
-    } else { rs0 = rs; qs0 = qs; }
-    re0 = (int32_t)a[r.as + r.cnt - 1].x + 1;
-    qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
-    re1 = tlen_all; qe1 = qlen;
-    for (i = r.as + r.cnt, l = 0; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
-        const int32_t x = (int32_t)a[i].x + 1, y = (int32_t)a[i].y + 1;
-        if (x > re0 && y > qe0) {
-            if (++l > opt->min_cnt) {
-                l = x - re0 > y - qe0 ? x - re0 : y - qe0;
-                re1 = re0 + l; qe1 = qe0 + l;
-                break;
-            }
-        }
-    }
-    if (qe < qlen && re < tlen_all) {
-        l = qlen - qe < opt->max_gap ? qlen - qe : opt->max_gap;
-        qe1 = qe1 < qe + l ? qe1 : qe + l;
-        qe0 = qe0 > qe1 ? qe0 : qe1;
-        l += l * opt->a > opt->q ? (l * opt->a - opt->q) / opt->e : 0;
-        l = l < opt->max_gap ? l : opt->max_gap;
-        l = l < tlen_all - re ? l : tlen_all - re;
-        re1 = re1 < re + l ? re1 : re + l;
-        re0 = re0 > re1 ? re0 : re1;
-    } else { re0 = re; qe0 = qe; }
-    pl.as1 = as1; pl.cnt1 = cnt1; pl.rs = rs; pl.qs = qs; pl.rs0 = rs0; pl.qs0 = qs0; pl.re0 = re0; pl.qe0 = qe0;
-    pl.segs.clear();
-    pl.left_job = pl.right_job = -1;
-    const int maxsw = opt->max_sw_mat > 0;
-    auto too_big = [&](int ql, int tl) { return maxsw && (int64_t)tl * ql > opt->max_sw_mat; };
-    pl.first_job = (int32_t)sink.jobs.size();
-    if (qs > 0 && rs > 0) {
-        if (!too_big(qs - qs0, rs - rs0))
-            pl.left_job = sink.add(read, rid, rev, qs0, qs - qs0, rs0, rs - rs0, 1, bw, r.split_inv ? opt->zdrop_inv : opt->zdrop,
-                                   opt->end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR);
-        else sink.add_refused(read, rid, rev, qs0, rs0, 1, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR);
-    }
-    for (i = 1; i < cnt1; ++i) {
-        if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
-        re = (int32_t)a[as1 + i].x - kh; qe = (int32_t)a[as1 + i].y - kh;
-        if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= opt->min_ksw_len && re - rs >= opt->min_ksw_len)) {
-            int bw1 = bw;
-            if (a[as1 + i].y & SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
-            Seg s;
-            s.qs = qs; s.qe = qe; s.rs = rs; s.re = re; s.bw = bw1; s.anchor_i = i; s.job = -1;
-            if (!too_big(qe - qs, re - rs) && qe - qs > 0 && re - rs > 0)
-                s.job = sink.add(read, rid, rev, qs, qe - qs, rs, re - rs, 0, bw1, opt->zdrop, -1, EZ_APPROX_MAX);
-            else sink.add_refused(read, rid, rev, qs, rs, 0, EZ_APPROX_MAX);
-            pl.segs.push_back(s);
-            rs = re; qs = qe;
-        }
-    }
-    pl.re = re; pl.qe = qe;
-    if (qe < qe0 && re < re0) {
-        if (!too_big(qe0 - qe, re0 - re))
-            pl.right_job = sink.add(read, rid, rev, qe, qe0 - qe, re, re0 - re, 0, bw, opt->zdrop, opt->end_bonus, EZ_EXTZ_ONLY);
-        else sink.add_refused(read, rid, rev, qe, re, 0, EZ_EXTZ_ONLY);
-    }
-    pl.n_jobs = (int32_t)sink.jobs.size() - pl.first_job;
-    pl.rid = rid; pl.rev = rev;
-}
-
 // MPN_DEBUG_CPU: thread CPU time of the sections of a host phase (g_cpu_ns[16 + k])
 struct CpuSect {
     timespec t;
@@ -548,26 +365,20 @@ struct CpuSect {
 };
 
 // What the stitching kernel found for one hit (stitch_kernels.h) applied to the hit: coordinates, DP score, and -- when a
-// gap fill z-dropped -- the split of the hit at the last anchor before the drop (mm_align1's `dropped` branch).
-// returns true if a split remainder was produced in r2
-static bool apply_stitch(const mpn_map_opt *opt, int qlen, Reg &r, Reg &r2, const u128 *a, const Plan &pl, const StitchOut &so, int fin_idx) {
+// gap fill z-dropped -- the split of the hit at the last anchor before the drop (mm_align1's `dropped` branch; the kernel
+// has located the anchor).  returns true if a split remainder was produced in r2
+static bool apply_stitch(int qlen, Reg &r, Reg &r2, const u128 *a, const StitchOut &so, int fin_idx) {
     bool has_r2 = false;
     r2.cnt = 0;
     if (so.has_p) r.has_p = 1;
     r.dp_score += so.dp_score;
-    if (so.dropped) {
-        const Seg &sg = pl.segs[(size_t)so.drop_fill];
-        int j;
-        for (j = sg.anchor_i - 1; j >= 0; --j) if ((int32_t)a[pl.as1 + j].x <= sg.rs + so.drop_max_t) break;
-        if (j < 0) j = 0;
-        if (pl.cnt1 - (j + 1) >= opt->min_cnt) {
-            const int old_cnt = r.cnt;
-            split_reg(r, r2, pl.as1 + j + 1 - r.as, qlen, a);
-            has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
-        }
+    if (so.split_n > 0) {
+        const int old_cnt = r.cnt;
+        split_reg(r, r2, so.split_n, qlen, a);
+        has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
     }
     r.rs = so.rs1; r.re = so.re1;
-    if (pl.rev) { r.qs = qlen - so.qe1; r.qe = qlen - so.qs1; }
+    if (r.rev) { r.qs = qlen - so.qe1; r.qe = qlen - so.qs1; }
     else { r.qs = so.qs1; r.qe = so.qe1; }
     // the CIGAR fix-up and the alignment statistics (mm_update_extra) are done for the whole round by aln_finish_wave_kernel
     r.fin_idx = r.has_p ? fin_idx : -1;
@@ -656,9 +467,8 @@ static void parallel_for(int n, int n_threads, const std::function<void(int, int
 
 struct ReadState {
     std::vector<Reg> regs;
-    std::vector<u128> a;   // chained anchors (squeezed)
+    u128 *a = nullptr;     // chained anchors (squeezed): a slice of the worker's pinned slab, valid while its sub-batch is mapped
     int n_a = 0;
-    std::vector<Plan> plans;  // per reg (only for regs being aligned this round)
     std::vector<int> pending; // reg indices aligned this round
 };
 
@@ -815,6 +625,8 @@ struct Slot {
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
+    PoolBuf pool_sizes, pool_buckets, pool_tot, pool_pregs, pool_psum, pool_njobs, pool_joboff, pool_job_anchor;
+    PoolBuf pin_anchors{nullptr, 0, true}, pin_pregs{nullptr, 0, true};
     PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
     PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_jobs{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
@@ -842,182 +654,78 @@ __global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const in
     jb.p_off = p_off[k];
 }
 
-// launch lists: every DP job of a group belongs to exactly one
-// (strip lists: lane-group class (16/32/64 lanes per window) x strip height 1..16; each is padded to whole waves)
-enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 48, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
-static inline int strip_windows_per_wave(int l) { return 4 >> ((l - L_STRIP) / 16); }
-
-// Device-resident results of a round's DP jobs: the job records, one result record per job, and the pool of compacted CIGAR
-// operations; `used` = [operations in the pool, windows listed for the exact second pass].  They stay in HBM for the stitching
-// kernel (valid until the worker's next round); nothing per window travels to the host.
+// Device-resident state of a round's DP windows: the job records, one result record per window, and the pool of compacted
+// CIGAR operations; `used` = [operations in the pool, windows listed for the exact second pass, stitched operations].  They stay
+// in HBM for the stitching kernel (valid until the worker's next round); nothing per window travels to the host.
 struct DevRound {
     ExtJob *jobs = nullptr;
     ExtRes *res = nullptr;
     uint32_t *compact = nullptr;
     unsigned long long *used = nullptr;
+    int64_t cig_cap = 0;   // CIGAR operations the round's windows can produce at most
 };
 
-// Run one group of DP jobs on the GPU (its scratch fits the budget).  jobs[0..nj) are completed in place (scratch
-// offsets, layout) and uploaded to dv.jobs; dv's pointers are already offset to this group.
-static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const DevRound &dv, const uint8_t *d_reads,
-                         const int64_t *d_read_off, const int32_t *d_read_len, int n_threads, hipStream_t st) {
+// Run one group of DP windows whose raw job records are on the device (dv.jobs[0..nj), as plan_kernel or the stage test wrote
+// them): kernel choice, direction-matrix layout and launch lists are made on the device (plan_kernels.h) and a block of counters
+// comes back; then the DP kernels, the traceback, the z-drop test and the rare exact second pass.  budget > 0: returns 1
+// without launching any DP if the direction matrices need more than that (the caller then cuts the range).
+static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj, DevRound &dv, const uint8_t *d_reads,
+                         const int64_t *d_read_off, const int32_t *d_read_len, int64_t budget, hipStream_t st) {
     if (nj == 0) return 0;
     WallTimer wt;
-    const size_t lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
-    struct Acc {
-        size_t lds_need[5] = {0, 0, 0, 0, 0}, strip_lds[3] = {0, 0, 0}, band_lds[4] = {64, 64, 64, 64};
-        int64_t cells = 0, strip_cells = 0, strip_cells_c[3] = {0, 0, 0};
-        int too_large = 0, tl_q = 0, tl_t = 0;
-    };
-    const int nt = std::max(1, n_threads);
-    const bool strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi);
-    std::vector<Acc> accs(nt);
-    std::vector<int8_t> list_id(nj), band_v(nj), band_c(nj), redo_list(nj);
-    std::vector<int64_t> p_bytes(nj);
-    std::vector<int32_t> st_bytes(nj);
-    // pass A (parallel): kernel choice, direction-matrix layout and scratch needs of every window
-    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int tid) {
-        Acc &A = accs[tid];
-        for (int64_t j = lo; j < hi; ++j) {
-            ExtJob &jb = jobs[j];
-            if (jb.flag & EZ_REFUSED) { list_id[j] = -1; band_v[j] = 0; band_c[j] = 0; redo_list[j] = -1; p_bytes[j] = 0; st_bytes[j] = 0; continue; }
-            const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
-            int n_col = std::min(jb.qlen, jb.tlen);
-            n_col = std::min(n_col, w + 1) + 1;
-            jb.n_col = n_col;
-            const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
-            // strip kernel: lane-group class by target rows (16 x 16, 32 x 16, 64 x 16) and by what the queries of one wave may
-            // take in LDS (1024 / 2048 / 4096 bases per window)
-            int glc = -1;
-            if ((jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed && w >= std::max(jb.qlen, jb.tlen) &&
-                strip_scores && (g_force_kernel == 0 || g_force_kernel == 4)) {
-                for (int c = 0; c < 3 && glc < 0; ++c)
-                    if (jb.tlen <= (256 << c) && jb.qlen <= (1024 << c)) glc = c;
-            }
-            const bool strip = glc >= 0;
-            const size_t seqb = (size_t)((jb.qlen + 3) & ~3) + (size_t)((jb.tlen + 3) & ~3);
-            // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
-            int bv = n_col <= 128 ? 0 : n_col <= 256 ? 1 : n_col <= 512 ? 2 : n_col <= 1024 ? 3 : -1;
-            if (seqb > lds_cap[3] || !(g_force_kernel == 0 || g_force_kernel == 4 || g_force_kernel == 5)) bv = -1;
-            int bc = 3;
-            for (int c = 0; c < 4; ++c) if (seqb <= lds_cap[c]) { bc = c; break; }
-            band_v[j] = (int8_t)bv; band_c[j] = (int8_t)bc;
-            if (bv >= 0) A.band_lds[bc] = std::max(A.band_lds[bc], seqb);
-            jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
-            const int strip_gl = 16 << std::max(glc, 0);
-            jb.strip_s = std::max(1, std::min(16, (jb.tlen + strip_gl - 1) / strip_gl));  // strip height: the window's rows over its lane group
-            const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
-            jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << std::max(bv, 0);  // row width of the direction matrix (layouts 1, 2)
-            const int64_t strip_bytes = (int64_t)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
-            // (the rare exact second pass of a strip window gets its direction matrix from a pool of its own)
-            p_bytes[j] = ((strip ? strip_bytes : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~(int64_t)15;
-            A.cells += n_r * n_col;
-            if (strip) { A.strip_cells += (int64_t)jb.qlen * jb.tlen; A.strip_cells_c[glc] += (int64_t)jb.qlen * jb.tlen; }
-            const size_t stateb = (size_t)(((size_t)6 * jb.tlen + 3) & ~(size_t)3) + (size_t)4 * jb.tlen;
-            int cls = 4;
-            for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
-            st_bytes[j] = 0;
-            jb.state_mode = 0;
-            int lid;
-            const bool use_wg = g_force_kernel == 3 || (g_force_kernel != 1 && n_col - 1 > 128);
-            const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
-            redo_list[j] = (int8_t)(bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls);
-            if (strip) { lid = L_STRIP + glc * 16 + jb.strip_s - 1; A.strip_lds[glc] = std::max(A.strip_lds[glc], (size_t)((jb.qlen + 15) & ~15)); }
-            else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
-            else lid = redo_list[j];
-            if (bv < 0) {  // the LDS-state kernels may run this window (now or in the second pass)
-                if (cls == 4) {
-                    if (seqb > lds_cap[3]) { A.too_large = 1; A.tl_q = jb.qlen; A.tl_t = jb.tlen; }
-                    jb.state_mode = 1; st_bytes[j] = (int32_t)((stateb + 15) & ~(size_t)15);
-                    A.lds_need[4] = std::max(A.lds_need[4], seqb);
-                } else A.lds_need[cls] = std::max(A.lds_need[cls], seqb + stateb);
-            }
-            list_id[j] = (int8_t)lid;
-        }
-    }, 6);
-    Acc M;
-    for (const Acc &A : accs) {
-        for (int c = 0; c < 5; ++c) M.lds_need[c] = std::max(M.lds_need[c], A.lds_need[c]);
-        for (int c = 0; c < 3; ++c) M.strip_lds[c] = std::max(M.strip_lds[c], A.strip_lds[c]);
-        for (int c = 0; c < 4; ++c) M.band_lds[c] = std::max(M.band_lds[c], A.band_lds[c]);
-        M.cells += A.cells; M.strip_cells += A.strip_cells;
-        for (int c = 0; c < 3; ++c) M.strip_cells_c[c] += A.strip_cells_c[c];
-        if (A.too_large) { set_error("DP window too large for LDS staging (%d x %d)", A.tl_q, A.tl_t); return -4; }
-    }
-    // pass B (serial, a few adds per window): scratch offsets and the launch lists (stable in job order)
-    int64_t p_tot = 0, row_tot = 0, cig_tot = 0, state_tot = 0;
-    int cnt[N_LISTS] = {0}, base[N_LISTS + 1];
-    for (int j = 0; j < nj; ++j) {
-        ExtJob &jb = jobs[j];
-        if (list_id[j] < 0) continue;   // placeholder: no DP
-        jb.p_off = p_tot; p_tot += p_bytes[j];
-        jb.row_off = row_tot;
-        if (band_v[j] < 0) row_tot += (int64_t)jb.qlen + jb.tlen - 1;  // band limits are stored only by the LDS-state kernels
-        cig_tot += jb.qlen + jb.tlen + 2; jb.cig_off = cig_tot;
-        jb.state_off = state_tot; state_tot += st_bytes[j];
-        ++cnt[(int)list_id[j]];
-    }
-    // strip lists are padded to whole waves (entries of -1), so that the strip height is uniform per wave
-    base[0] = 0;
-    for (int l = 0; l < N_LISTS; ++l) {
-        int c = cnt[l];
-        if (l >= L_STRIP && l < L_BAND) { const int per = strip_windows_per_wave(l); c = (c + per - 1) / per * per; }
-        base[l + 1] = base[l] + c;
-    }
-    const int n_flat = base[N_LISTS];
-    g_stats[4] += nj; g_stats[5] += M.cells; g_stats[31] += M.strip_cells;
-    for (int c = 0; c < 3; ++c) g_stats[41 + c] += M.strip_cells_c[c];
     Slot &SL = *tl_slot;
-    if (SL.pin_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_jobs.ensure((size_t)nj * sizeof(ExtJob))) return -1;
-    int32_t *flat = SL.pin_order.as<int32_t>();
-    {
-        int cur[N_LISTS];
-        memcpy(cur, base, sizeof(cur));
-        for (int l = L_STRIP; l < L_BAND; ++l) for (int k = base[l] + cnt[l]; k < base[l + 1]; ++k) flat[k] = -1;
-        for (int j = 0; j < nj; ++j) if (list_id[j] >= 0) flat[cur[(int)list_id[j]]++] = j;
+    const int strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi) ? 1 : 0;
+    const size_t order_cap = (size_t)nj + (size_t)N_STRIP * 4 + 16;
+    if (SL.pool_sizes.ensure((size_t)nj * sizeof(JobSizes) + 16) || SL.pool_buckets.ensure((size_t)2 * N_BUCKETS * 4 + 16) ||
+        SL.pool_tot.ensure(sizeof(LayoutTotals) + 16) || SL.pool_order.ensure(order_cap * 4) || SL.pin_res.ensure(sizeof(LayoutTotals) + 64) ||
+        SL.pool_redo_ids.ensure((size_t)nj * 4 + 16))
+        return -1;
+    struct { ExtJob *p; } d_jobs{dv.jobs};
+    JobSizes *d_sizes = SL.pool_sizes.as<JobSizes>();
+    int32_t *d_bcnt = SL.pool_buckets.as<int32_t>(), *d_bcur = d_bcnt + N_BUCKETS;
+    LayoutTotals *d_tot = SL.pool_tot.as<LayoutTotals>();
+    struct { int32_t *p; } d_order{SL.pool_order.as<int32_t>()};
+    MPN_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)2 * N_BUCKETS * 4, st));
+    MPN_HIP_CHECK(hipMemsetAsync(d_tot, 0, sizeof(LayoutTotals), st));
+    MPN_HIP_CHECK(hipMemsetAsync(d_order.p, 0xff, order_cap * 4, st));   // -1: the padding of the strip lists
+    const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, nj, strip_scores, g_force_kernel, d_sizes, d_bcnt, d_tot);
+    hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, nj, (const int32_t *)d_bcnt, d_bcur, d_tot);
+    hipLaunchKernelGGL(job_layout_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, nj, (const JobSizes *)d_sizes, d_bcur, d_order.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    LayoutTotals *h_tot = SL.pin_res.as<LayoutTotals>();
+    MPN_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(LayoutTotals), hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    const LayoutTotals T = *h_tot;
+    if (T.too_large) { set_error("DP window too large for LDS staging (%d x %d)", T.tl_q, T.tl_t); return -4; }
+    if (!dv.compact) {
+        // (the compact pool holds every window's operations, and once more those of the windows that take the second pass)
+        if (SL.pool_compact.ensure((size_t)T.cig_tot * 4 * 2 + 16)) return -1;
+        dv.compact = SL.pool_compact.as<uint32_t>();
+        dv.cig_cap = T.cig_tot;
     }
-    // the windows that share a wave should need the same number of steps: longest queries first within each strip list
-    parallel_for(N_STRIP, nt, [&](int k, int) {
-        const int l = L_STRIP + k;
-        if (strip_windows_per_wave(l) > 1 && cnt[l] > 1)
-            std::sort(flat + base[l], flat + base[l] + cnt[l], [&](int32_t x, int32_t y) {
-                return jobs[x].qlen != jobs[y].qlen ? jobs[x].qlen > jobs[y].qlen : x < y;
-            });
-    }, 7);
+    if (budget > 0 && T.p_tot > budget && nj > 1) return 1;
+    const int *cnt = T.cnt, *base = T.base;
+    g_stats[4] += nj; g_stats[5] += T.cells; g_stats[31] += T.strip_cells[0] + T.strip_cells[1] + T.strip_cells[2];
+    for (int c = 0; c < 3; ++c) g_stats[41 + c] += T.strip_cells[c];
     if (getenv("MPN_DEBUG_JOBS")) {
         static const char *const fam[] = {"lds", "wg", "strip", "band"};
-        for (int l = 0; l < N_LISTS; ++l) {
-            if (!cnt[l]) continue;
-            int64_t c = 0, mx = 0, ext = 0;
-            for (int k = base[l]; k < base[l] + cnt[l]; ++k) {
-                const ExtJob &jb = jobs[flat[k]];
-                const int64_t z = ((int64_t)jb.qlen + jb.tlen - 1) * jb.n_col;
-                c += z; mx = std::max(mx, z); ext += (jb.flag & EZ_EXTZ_ONLY) != 0;
-            }
-            const int f = l < L_WG ? 0 : l < L_STRIP ? 1 : l < L_BAND ? 2 : 3;
-            fprintf(stderr, "[jobs] %s list %-2d n=%d cells=%.2fG max=%.1fM ext=%lld\n", fam[f], l, cnt[l], c / 1e9, mx / 1e6, (long long)ext);
-        }
+        for (int l = 0; l < N_LISTS; ++l)
+            if (cnt[l]) fprintf(stderr, "[jobs] %s list %-2d n=%d\n", fam[l < L_WG ? 0 : l < L_STRIP ? 1 : l < L_BAND ? 2 : 3], l, cnt[l]);
     }
-    if (SL.pool_P.ensure((size_t)p_tot) || SL.pool_OFF.ensure((size_t)row_tot * 2 * 4 + 16) ||
-        SL.pool_state.ensure((size_t)state_tot + 16) || SL.pool_CIG.ensure((size_t)cig_tot * 4 + 16) ||
-        SL.pool_order.ensure((size_t)n_flat * 4 + 16) || SL.pin_res.ensure(64) || SL.pool_redo_ids.ensure((size_t)nj * 4 + 16))
+    if (SL.pool_P.ensure((size_t)T.p_tot + 16) || SL.pool_OFF.ensure((size_t)T.row_tot * 2 * 4 + 16) ||
+        SL.pool_state.ensure((size_t)T.state_tot + 16) || SL.pool_CIG.ensure((size_t)T.cig_tot * 4 + 16))
         return -1;
-    // the H2D copies leave from pinned memory, so they are truly asynchronous
-    parallel_chunks(nj, nt, [&](int64_t lo, int64_t hi, int) { memcpy(SL.pin_jobs.as<ExtJob>() + lo, jobs + lo, (size_t)(hi - lo) * sizeof(ExtJob)); }, 8);
     wt.stop_into(g_stats[27]);
-    struct { ExtJob *p; } d_jobs{dv.jobs};
     struct { uint8_t *p; } P{SL.pool_P.as<uint8_t>()};
     struct { int32_t *p; } OFF{SL.pool_OFF.as<int32_t>()};
     struct { int8_t *p; } gstate{SL.pool_state.as<int8_t>()};
     struct { uint32_t *p; } CIG{SL.pool_CIG.as<uint32_t>()};
     struct { ExtRes *p; } d_res{dv.res};
-    struct { int32_t *p; } d_order{SL.pool_order.as<int32_t>()};
     uint32_t *d_compact = dv.compact;
     unsigned long long *d_used = dv.used;   // [0] operations in the compact pool (the whole round), [1] windows listed for the second pass (this group)
     int32_t *d_redo_ids = SL.pool_redo_ids.as<int32_t>();
     MPN_HIP_CHECK(hipMemsetAsync(d_used + 1, 0, 8, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(d_jobs.p, SL.pin_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(d_order.p, flat, (size_t)n_flat * 4, hipMemcpyHostToDevice, st));
     ExtParams prm;
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
@@ -1025,13 +733,13 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     auto launch_list = [&](int l, const int32_t *ord, int n, hipStream_t s) -> int {
         if (n == 0) return 0;
         if (l < L_WG) {
-            const size_t lds = std::max<size_t>(M.lds_need[l - L_LDS], 64);
+            const size_t lds = std::max<size_t>((size_t)T.lds_need[l - L_LDS], 64);
             if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(ext_dp_kernel, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, OFF.p,
                                gstate.p, d_res.p);
         } else if (l < L_STRIP) {
             const int ntc = (l - L_WG) / 5;
-            const size_t lds = std::max<size_t>(M.lds_need[(l - L_WG) % 5], 64);
+            const size_t lds = std::max<size_t>((size_t)T.lds_need[(l - L_WG) % 5], 64);
 #define MPN_WG_LAUNCH(NT)                                                                                                             \
             do {                                                                                                                      \
                 if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_wg_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1042,14 +750,14 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
 #undef MPN_WG_LAUNCH
         } else if (l < L_BAND) {  // called once per lane-group class with the class's whole (padded) range: l = first list of the class
             const int glc = (l - L_STRIP) / 16, per = 4 >> glc;
-            const int stride = (int)std::max<size_t>(M.strip_lds[glc], 16);
+            const int stride = std::max(T.strip_lds[glc], 16);
             const size_t lds = (size_t)stride * per;
             if (glc == 0) hipLaunchKernelGGL(ext_dp_strip_kernel<16>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
             else if (glc == 1) hipLaunchKernelGGL(ext_dp_strip_kernel<32>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
             else hipLaunchKernelGGL(ext_dp_strip_kernel<64>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
         } else {
             const int bvar = (l - L_BAND) / 4;
-            const size_t lds = M.band_lds[(l - L_BAND) % 4];
+            const size_t lds = std::max<size_t>((size_t)T.band_lds[(l - L_BAND) % 4], 64);
 #define MPN_BAND_LAUNCH(NW, TT)                                                                                                       \
             do {                                                                                                                      \
                 if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_band_kernel<NW, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1110,24 +818,27 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     ev.mark(15);
     if (bt_ztest(main_lo, main_hi, st, true)) return -1;
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
-    unsigned long long *h_used = SL.pin_res.as<unsigned long long>();
+    unsigned long long *h_used = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(SL.pin_res.p) + ((sizeof(LayoutTotals) + 15) & ~(size_t)15));
     MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 16, hipMemcpyDeviceToHost, st));
     wt.stop_into(g_stats[28]);
     MPN_HIP_CHECK(stream_sync(st));
     wt.stop_into(g_stats[29]);
     // second pass: the windows whose CIGAR failed the z-drop test were listed by the test kernel (in no particular order)
     std::vector<int32_t> redo((size_t)h_used[1]);
-    if (!redo.empty()) {
-        if (SL.pin_order.ensure(redo.size() * 4 + 16)) return -1;
-        MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_order.p, d_redo_ids, redo.size() * 4, hipMemcpyDeviceToHost, st));
-        MPN_HIP_CHECK(stream_sync(st));
-        memcpy(redo.data(), SL.pin_order.p, redo.size() * 4);
-        std::sort(redo.begin(), redo.end());
-    }
     g_stats[8] += (int64_t)redo.size();
     if (!redo.empty()) {
         const int nr = (int)redo.size();
-        std::stable_sort(redo.begin(), redo.end(), [&](int x, int y) { return redo_list[x] < redo_list[y]; });
+        // (rare: the job records of the group come to the host for it)
+        std::vector<ExtJob> jobs((size_t)nj);
+        if (SL.pin_order.ensure(redo.size() * 4 + 16)) return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_order.p, d_redo_ids, redo.size() * 4, hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(hipMemcpyAsync(jobs.data(), d_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(stream_sync(st));
+        memcpy(redo.data(), SL.pin_order.p, redo.size() * 4);
+        auto list_of = [&](int j) { return jobs[(size_t)j].cls & 0xff; };
+        auto redo_list_of = [&](int j) { return jobs[(size_t)j].cls >> 8 & 0xff; };
+        auto band_of = [&](int j) { return (jobs[(size_t)j].cls >> 16 & 0xff) - 1; };
+        std::sort(redo.begin(), redo.end(), [&](int x, int y) { return redo_list_of(x) != redo_list_of(y) ? redo_list_of(x) < redo_list_of(y) : x < y; });
         // [ids | layout | qstride | p_off (int64)]: a strip window's second pass needs a band / anti-diagonal matrix, which
         // comes from a pool of its own (offsets are relative to the main pool's base: one flat address space)
         std::vector<int32_t> pack((size_t)nr * 5 + 2);
@@ -1135,20 +846,18 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         int64_t p2_tot = 0;
         for (int k = 0; k < nr; ++k) {
             const int j = redo[k];
-            ExtJob &jb = jobs[j];
-            jb.flag &= ~EZ_APPROX_MAX;
-            jb.layout = band_v[j] >= 0 ? 2 : 0;
-            jb.qstride = 128 << std::max<int>(band_v[j], 0);
-            pack[k] = j; pack[nr + k] = jb.layout; pack[2 * nr + k] = jb.qstride;
-            if (list_id[j] >= L_STRIP && list_id[j] < L_BAND) {
+            const ExtJob &jb = jobs[(size_t)j];
+            const int bv = band_of(j);
+            pack[k] = j; pack[nr + k] = bv >= 0 ? 2 : 0; pack[2 * nr + k] = 128 << std::max(bv, 0);
+            if (list_of(j) >= L_STRIP && list_of(j) < L_BAND) {
                 const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
                 pack_off[k] = -1 - p2_tot;  // resolved below, once the pool address is known
-                p2_tot += ((band_v[j] >= 0 ? n_r * (128 << band_v[j]) : n_r * jb.n_col) + 15) & ~(int64_t)15;
+                p2_tot += ((bv >= 0 ? n_r * (128 << bv) : n_r * jb.n_col) + 15) & ~(int64_t)15;
             } else pack_off[k] = jb.p_off;
         }
         if (SL.pool_P2.ensure((size_t)p2_tot + 16)) return -1;
         const int64_t p2_base = (int64_t)(SL.pool_P2.as<uint8_t>() - P.p);
-        for (int k = 0; k < nr; ++k) if (pack_off[k] < 0) { pack_off[k] = p2_base + (-1 - pack_off[k]); jobs[redo[k]].p_off = pack_off[k]; }
+        for (int k = 0; k < nr; ++k) if (pack_off[k] < 0) pack_off[k] = p2_base + (-1 - pack_off[k]);
         if (SL.pool_redo.ensure(pack.size() * 4)) return -1;
         struct { int32_t *p; } d_redo{SL.pool_redo.as<int32_t>()};
         MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
@@ -1158,8 +867,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
         ev.skip();
         for (int lo = 0; lo < nr;) {
             int hi = lo;
-            while (hi < nr && redo_list[redo[hi]] == redo_list[redo[lo]]) ++hi;
-            if (launch_list(redo_list[redo[lo]], d_redo.p + lo, hi - lo, st)) return -1;
+            while (hi < nr && redo_list_of(redo[hi]) == redo_list_of(redo[lo])) ++hi;
+            if (launch_list(redo_list_of(redo[lo]), d_redo.p + lo, hi - lo, st)) return -1;
             lo = hi;
         }
         ev.mark(15);
@@ -1173,42 +882,30 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs
     return 0;
 }
 
-// Run all DP jobs of one round, in groups whose direction scratch stays under the budget (MPN_DP_BUDGET bytes, for tests).
-// The job records, results and compacted CIGARs of ALL groups stay in the worker's device pools (out); a group only
-// borrows the direction-matrix scratch.
-static int run_jobs(const RefView &rv, const mpn_map_opt *opt, ExtJob *jobs, int nj, const uint8_t *d_reads, const int64_t *d_read_off,
-                    const int32_t *d_read_len, int n_threads, DevRound &out, hipStream_t st) {
+// Run the DP windows whose raw job records the caller has put at the start of the worker's job pool (SL.pool_jobs), in groups
+// whose direction scratch stays under the budget (MPN_DP_BUDGET bytes, for tests).  The job records, results and compacted
+// CIGARs of ALL groups stay in the worker's device pools (out); a group only borrows the direction-matrix scratch.
+static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj, const uint8_t *d_reads, const int64_t *d_read_off,
+                    const int32_t *d_read_len, DevRound &out, hipStream_t st) {
     static const int64_t budget = []() { const char *e = getenv("MPN_DP_BUDGET"); return e ? std::max<int64_t>(1 << 20, atoll(e)) : (int64_t)40 << 30; }();
-    std::vector<int> cuts{0};
-    int64_t cig_all = 0;
-    {
-        int64_t acc = 0;
-        for (int j = 0; j < nj; ++j) {
-            const ExtJob &jb = jobs[j];
-            if (jb.flag & EZ_REFUSED) continue;
-            const int w = jb.w < 0 ? std::max(jb.tlen, jb.qlen) : jb.w;
-            const int nc = std::min(std::min(jb.qlen, jb.tlen), w + 1) + 1;
-            const int64_t sz = ((int64_t)jb.qlen + jb.tlen - 1) * (nc <= 1024 ? std::max(128, 2 * nc) : nc);  // upper bound of every layout
-            if (j > cuts.back() && acc + sz > budget) { cuts.push_back(j); acc = 0; }
-            acc += sz;
-            cig_all += jb.qlen + jb.tlen + 2;
-        }
-        cuts.push_back(nj);
-    }
     Slot &SL = *tl_slot;
-    // (the compact pool holds every window's operations, and once more those of the windows that take the second pass)
-    if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob) + 16) || SL.pool_res.ensure((size_t)nj * sizeof(ExtRes) + 16) ||
-        SL.pool_compact.ensure((size_t)cig_all * 4 * 2 + 16) || SL.pool_used.ensure(32))
-        return -1;
-    out.jobs = SL.pool_jobs.as<ExtJob>(); out.res = SL.pool_res.as<ExtRes>(); out.compact = SL.pool_compact.as<uint32_t>();
+    if (SL.pool_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || SL.pool_used.ensure(32)) return -1;
+    out.jobs = SL.pool_jobs.as<ExtJob>(); out.res = SL.pool_res.as<ExtRes>(); out.compact = nullptr;
     out.used = SL.pool_used.as<unsigned long long>();
     MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 32, st));   // [0] compacted ops, [1] second-pass windows, [2] stitched ops
-    const int n_groups = (int)cuts.size() - 1;
-    for (int g = 0; g < n_groups; ++g) {
-        const int lo = cuts[g], hi = cuts[g + 1];
+    const int rc = run_job_group(rv, opt, nj, out, d_reads, d_read_off, d_read_len, budget, st);
+    if (rc != 1) return rc;
+    // over the budget: cut the range where the direction matrices (their offsets are in the size table) fill it
+    std::vector<JobSizes> sz((size_t)nj);
+    MPN_HIP_CHECK(hipMemcpy(sz.data(), SL.pool_sizes.p, (size_t)nj * sizeof(JobSizes), hipMemcpyDeviceToHost));
+    std::vector<int> cuts{0};
+    for (int j = 1; j < nj; ++j) if (sz[(size_t)j].p - sz[(size_t)cuts.back()].p > budget) cuts.push_back(j);
+    cuts.push_back(nj);
+    for (size_t g = 0; g + 1 < cuts.size(); ++g) {
         DevRound dv = out;
-        dv.jobs += lo; dv.res += lo;
-        if (run_job_group(rv, opt, jobs + lo, hi - lo, dv, d_reads, d_read_off, d_read_len, n_threads, st)) return -1;
+        dv.jobs += cuts[g]; dv.res += cuts[g];
+        const int r2 = run_job_group(rv, opt, cuts[g + 1] - cuts[g], dv, d_reads, d_read_off, d_read_len, 0, st);
+        if (r2) return r2 < 0 ? r2 : -1;
     }
     return 0;
 }
@@ -1222,28 +919,23 @@ using namespace mpn;
 // fixed CIGARs only when the caller wants text (need_cigar).
 static bool g_need_cigar = true;   // set per mapping call (the calls take turns: g_call_mu)
 
+// n_sr hits of the round; their StitchReg / PlanReg / PlanSum records and the windows' anchor indices are on the device (written
+// by plan_kernel); sr_base[i] = index of read i's first hit of the round, S.pending its hits.
+struct RoundDev {
+    const StitchReg *sregs; const PlanReg *pregs; const PlanSum *psum; const int32_t *job_anchor; const u128 *anchors;
+};
+
 static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadState *rs, int n, const int32_t *seq_len, const DevRound &dv,
-                             int64_t cig_cap, const std::vector<int> &job_base, const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len,
+                             const RoundDev &rd, const std::vector<int32_t> &sr_base, const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len,
                              int n_threads, hipStream_t st) {
-    std::vector<int32_t> sr_base((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) sr_base[(size_t)i + 1] = sr_base[(size_t)i] + (int32_t)rs[i].pending.size();
     const int n_sr = sr_base[(size_t)n];
     if (n_sr == 0) return 0;
     Slot &SL = *tl_slot;
-    if (SL.pin_fin_jobs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut)) + 64) ||
-        SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pool_souts.ensure((size_t)n_sr * sizeof(StitchOut) + 16) ||
+    if (SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut)) + 64) ||
+        SL.pool_souts.ensure((size_t)n_sr * sizeof(StitchOut) + 16) ||
         SL.pool_fin_jobs.ensure((size_t)n_sr * sizeof(FinJob) + 16) || SL.pool_fin_out.ensure((size_t)n_sr * sizeof(FinOut) + 16) ||
-        SL.pool_fin_cig.ensure((size_t)cig_cap * 4 + 16))
+        SL.pool_fin_cig.ensure((size_t)dv.cig_cap * 4 + 16))
         return -1;
-    StitchReg *h_sr = SL.pin_fin_jobs.as<StitchReg>();
-    parallel_for(n, n_threads, [&](int i, int) {
-        const ReadState &S = rs[i];
-        for (size_t pi = 0; pi < S.pending.size(); ++pi) {
-            const Plan &pl = S.plans[pi];
-            h_sr[(size_t)sr_base[(size_t)i] + pi] = StitchReg{pl.first_job + job_base[(size_t)i], pl.n_jobs, pl.qs, pl.rs, pl.qe, pl.re, pl.qs0, pl.qe0, i, pl.rid, pl.rev, 0};
-        }
-    }, 9);
-    StitchReg *d_sr = SL.pool_sregs.as<StitchReg>();
     StitchOut *d_so = SL.pool_souts.as<StitchOut>();
     FinJob *d_fj = SL.pool_fin_jobs.as<FinJob>();
     FinOut *d_fo = SL.pool_fin_out.as<FinOut>();
@@ -1254,10 +946,10 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     unsigned long long *h_out_used = reinterpret_cast<unsigned long long *>(h_fo + n_sr);
     EvTimer ev(st);
     MPN_HIP_CHECK(hipMemsetAsync(d_out_used, 0, 8, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(d_sr, h_sr, (size_t)n_sr * sizeof(StitchReg), hipMemcpyHostToDevice, st));
     ev.skip();
-    hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)std::min(n_sr, 256 * 32)), dim3(64), 0, st, (const StitchReg *)d_sr, n_sr, (const ExtJob *)dv.jobs,
-                       (const ExtRes *)dv.res, (const uint32_t *)dv.compact, d_cig, d_out_used, d_so, d_fj);
+    hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)std::min(n_sr, 256 * 32)), dim3(64), 0, st, rd.sregs, n_sr, (const ExtJob *)dv.jobs,
+                       (const ExtRes *)dv.res, (const uint32_t *)dv.compact, d_cig, d_out_used, d_so, d_fj, rd.pregs, rd.psum, rd.job_anchor, rd.anchors,
+                       opt->min_cnt);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(54);
     MPN_HIP_CHECK(hipMemcpyAsync(h_so, d_so, (size_t)n_sr * sizeof(StitchOut), hipMemcpyDeviceToHost, st));
@@ -1272,7 +964,7 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
         for (size_t pi = 0; pi < S.pending.size(); ++pi) {
             const int k = S.pending[pi] + shift, fi = sr_base[(size_t)i] + (int)pi;
             Reg r2;
-            const bool has = apply_stitch(opt, seq_len[i], S.regs[(size_t)k], r2, S.a.data(), S.plans[pi], h_so[fi], fi);
+            const bool has = apply_stitch(seq_len[i], S.regs[(size_t)k], r2, S.a, h_so[fi], fi);
             if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
         }
     }, 4);
@@ -1386,7 +1078,11 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     }
     g_stats[3] += h.chain_off[n];
     for (int i = 0; i < n; ++i) rep_len_all[lo + i] = h.rep_len[i];
-    // hits from chains
+    // hits from chains; the chained anchors of the sub-batch live in ONE pinned slab (read i at b_off[i]): the planning kernel
+    // needs them on the device, and they go up from where the host squeezed them, without another copy
+    Slot &SL = *tl_slot;
+    if (SL.pin_anchors.ensure((size_t)h.b_off[(size_t)n] * sizeof(u128) + 64)) return -1;
+    u128 *slab = SL.pin_anchors.as<u128>();
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
         const int nc = h.n_chain[i];
@@ -1394,70 +1090,96 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         const int qlen = seq_len[i];
         CpuSect sect(g_cpu_on);
         std::vector<uint64_t> u_loc(nc);
-        S.a.resize((size_t)h.n_chained[i]);
-        h.read_chains(i, u_loc.data(), S.a.data());
+        S.a = slab + h.b_off[(size_t)i];
+        h.read_chains(i, u_loc.data(), S.a);
         sect.lap(3);
         uint32_t hash = names && names[lo + i] ? x31_hash(names[lo + i]) : 0;
         hash ^= wang32((uint32_t)qlen) + wang32(opt->seed);
         hash = wang32(hash);
-        gen_regs(hash, qlen, nc, u_loc.data(), S.a.data(), S.regs);
+        gen_regs(hash, qlen, nc, u_loc.data(), S.a, S.regs);
         set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
         select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
-        join_long(opt, qlen, S.regs, S.a.data());
+        join_long(opt, qlen, S.regs, S.a);
         sect.lap(4);
         if (opt->with_cigar) {
-            S.n_a = squeeze_a(S.regs, S.a.data());
+            S.n_a = squeeze_a(S.regs, S.a);
             sect.lap(5);
         }
     }, 1);
     wt.stop_into(g_stats[19]);
-    if (opt->with_cigar) {
+    if (opt->with_cigar && h.b_off[(size_t)n] > 0) {
+        DevBuf<u128> d_a;
+        if (d_a.alloc((size_t)h.b_off[(size_t)n])) return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(d_a.p, slab, (size_t)h.b_off[(size_t)n] * sizeof(u128), hipMemcpyHostToDevice, st));
+        PlanOpt po;
+        po.bw = opt->bw; po.bw15 = (int)(opt->bw * 1.5 + 1.); po.min_chain_score = opt->min_chain_score; po.max_gap = opt->max_gap;
+        po.min_cnt = opt->min_cnt; po.a = opt->a; po.q = opt->q; po.e = opt->e; po.zdrop = opt->zdrop; po.zdrop_inv = opt->zdrop_inv;
+        po.end_bonus = opt->end_bonus; po.min_ksw_len = opt->min_ksw_len; po.k = idx->k; po.pad = 0; po.max_sw_mat = opt->max_sw_mat;
+        const RefView rv{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
+        std::vector<int32_t> sr_base((size_t)n + 1, 0);
         for (int round = 0; round < 64; ++round) {
             wt.stop_into(g_stats[23]);
-            // plan: every read fills its own job list in parallel; lists are concatenated in read order, so job ids
-            // do not depend on the thread schedule
-            std::vector<JobSink> sinks(n);
+            // the hits to align in this round: 40 bytes each go up; their windows are planned, laid out, computed, traced back and
+            // stitched on the device
             parallel_for(n, n_threads, [&](int i, int) {
                 ReadState &S = rs[i];
-                S.pending.clear(); S.plans.clear();
+                S.pending.clear();
                 for (int k = 0; k < (int)S.regs.size(); ++k) {
-                    Reg &r = S.regs[k];
+                    Reg &r = S.regs[(size_t)k];
                     if (r.aligned) continue;
                     if (r.cnt == 0) { r.aligned = 1; continue; }
                     S.pending.push_back(k);
-                    S.plans.emplace_back();
-                    plan_align(opt, idx, i, seq_len[i], r, S.n_a, S.a.data(), S.plans.back(), sinks[i]);
                 }
             }, 2);
-            JobSink sink;
-            std::vector<int> job_base(n, 0);
-            {
-                size_t tot = 0;
-                for (int i = 0; i < n; ++i) { job_base[i] = (int)tot; tot += sinks[i].jobs.size(); }
-                sink.jobs.resize(tot);
-            }
-            bool any = !sink.jobs.empty();
-            for (int i = 0; i < n && !any; ++i) any = !rs[i].pending.empty();
+            for (int i = 0; i < n; ++i) sr_base[(size_t)i + 1] = sr_base[(size_t)i] + (int32_t)rs[i].pending.size();
+            const int n_sr = sr_base[(size_t)n];
+            if (n_sr == 0) { wt.stop_into(g_stats[20]); break; }
+            if (SL.pin_pregs.ensure((size_t)n_sr * sizeof(PlanReg) + 64) || SL.pool_pregs.ensure((size_t)n_sr * sizeof(PlanReg) + 16) ||
+                SL.pool_psum.ensure((size_t)n_sr * sizeof(PlanSum) + 16) || SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) ||
+                SL.pool_njobs.ensure(((size_t)n_sr + 1) * 8 + 16) || SL.pool_joboff.ensure(((size_t)n_sr + 1) * 8 + 16))
+                return -1;
+            PlanReg *h_pr = SL.pin_pregs.as<PlanReg>();
             parallel_for(n, n_threads, [&](int i, int) {
-                const int base = job_base[i];
-                if (!sinks[i].jobs.empty()) memcpy(&sink.jobs[base], sinks[i].jobs.data(), sinks[i].jobs.size() * sizeof(ExtJob));
-                for (Plan &pl : rs[i].plans) {
-                    if (pl.left_job >= 0) pl.left_job += base;
-                    if (pl.right_job >= 0) pl.right_job += base;
-                    for (Seg &sg : pl.segs) if (sg.job >= 0) sg.job += base;
+                const ReadState &S = rs[i];
+                for (size_t pi = 0; pi < S.pending.size(); ++pi) {
+                    const Reg &r = S.regs[(size_t)S.pending[pi]];
+                    h_pr[(size_t)sr_base[(size_t)i] + pi] = PlanReg{h.b_off[(size_t)i], S.n_a, r.as, r.cnt, r.mlen, i, seq_len[i], (int32_t)r.split_inv, 0};
                 }
             }, 3);
+            PlanReg *d_pr = SL.pool_pregs.as<PlanReg>();
+            PlanSum *d_ps = SL.pool_psum.as<PlanSum>();
+            StitchReg *d_sr = SL.pool_sregs.as<StitchReg>();
+            int64_t *d_nj = SL.pool_njobs.as<int64_t>(), *d_joff = SL.pool_joboff.as<int64_t>();
+            MPN_HIP_CHECK(hipMemcpyAsync(d_pr, h_pr, (size_t)n_sr * sizeof(PlanReg), hipMemcpyHostToDevice, st));
+            const int pg = std::max(1, std::min((n_sr + 63) / 64, 256 * 16));
+            hipLaunchKernelGGL(plan_kernel<false>, dim3(pg), dim3(64), 0, st, po, (const PlanReg *)d_pr, n_sr, d_a.p, (const int32_t *)idx->d_lens.p, d_nj,
+                               (const int64_t *)nullptr, (ExtJob *)nullptr, (int32_t *)nullptr, (StitchReg *)nullptr, (PlanSum *)nullptr);
+            hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)d_nj, d_joff, n_sr);
+            MPN_HIP_CHECK(hipGetLastError());
+            int64_t *h_nj = reinterpret_cast<int64_t *>(h_pr + n_sr);
+            MPN_HIP_CHECK(hipMemcpyAsync(h_nj, d_joff + n_sr, 8, hipMemcpyDeviceToHost, st));
+            MPN_HIP_CHECK(stream_sync(st));
+            const int64_t nj64 = *h_nj;
+            if (nj64 > 0x7fffffff) { set_error("too many DP windows in one round"); return -1; }
+            const int nj = (int)nj64;
+            if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob) + 16) || SL.pool_job_anchor.ensure((size_t)nj * 4 + 16)) return -1;
+            ExtJob *d_jobs = SL.pool_jobs.as<ExtJob>();
+            int32_t *d_janchor = SL.pool_job_anchor.as<int32_t>();
+            hipLaunchKernelGGL(plan_kernel<true>, dim3(pg), dim3(64), 0, st, po, (const PlanReg *)d_pr, n_sr, d_a.p, (const int32_t *)idx->d_lens.p, (int64_t *)nullptr,
+                               (const int64_t *)d_joff, d_jobs, d_janchor, d_sr, d_ps);
+            MPN_HIP_CHECK(hipGetLastError());
             wt.stop_into(g_stats[20]);
-            if (!any) break;
             ++g_stats[7];
             DevRound dv;
-            int64_t cig_cap = 0;
-            for (const ExtJob &jb : sink.jobs) cig_cap += jb.qlen + jb.tlen + 2;
-            if (run_jobs(RefView{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns}, opt, sink.jobs.data(),
-                         (int)sink.jobs.size(), d_seqs.p, d_off.p, d_len.p, n_threads, dv, st))
-                return -1;
+            if (nj > 0 && run_jobs(rv, opt, nj, d_seqs.p, d_off.p, d_len.p, dv, st)) return -1;
+            if (nj == 0) {   // (hits without any window: the stitching kernel still sets their coordinates)
+                if (SL.pool_res.ensure(64) || SL.pool_used.ensure(32) || SL.pool_compact.ensure(64)) return -1;
+                dv.jobs = d_jobs; dv.res = SL.pool_res.as<ExtRes>(); dv.compact = SL.pool_compact.as<uint32_t>(); dv.used = SL.pool_used.as<unsigned long long>();
+                MPN_HIP_CHECK(hipMemsetAsync(dv.used, 0, 32, st));
+            }
             wt.stop_into(g_stats[21]);
-            if (stitch_and_finish(idx, opt, rs, n, seq_len, dv, cig_cap, job_base, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
+            const RoundDev rd{d_sr, d_pr, d_ps, d_janchor, d_a.p};
+            if (stitch_and_finish(idx, opt, rs, n, seq_len, dv, rd, sr_base, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
             wt.stop_into(g_stats[22]);
         }
     }
@@ -1478,8 +1200,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
         }
         n_aln += (int64_t)S.regs.size();
-        // the per-read scratch is no longer needed
-        std::vector<u128>().swap(S.a);
+        S.a = nullptr;   // (the slab belongs to the worker's next sub-batch from here on)
     }, 5);
     g_stats[6] += n_aln;
     wt.stop_into(g_stats[23]);
@@ -1948,7 +1669,10 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
     mpn_map_opt o2 = *opt;
     o2.zdrop = 0x3fffffff;
     DevRound dv;
-    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, jobs.data(), n, d_reads.p, d_qoff.p, d_qlen.p, 4, dv, st);
+    for (ExtJob &j : jobs) { j.strip_s = 1; j.cls = -1; }
+    if (tl_slot->pool_jobs.ensure((size_t)n * sizeof(ExtJob) + 16)) return -1;
+    MPN_HIP_CHECK(hipMemcpy(tl_slot->pool_jobs.p, jobs.data(), (size_t)n * sizeof(ExtJob), hipMemcpyHostToDevice));
+    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, n, d_reads.p, d_qoff.p, d_qlen.p, dv, st);
     g_force_kernel = 0;
     if (rc) return rc;
     // (the product keeps these on the device for the stitching kernel; the stage test reads them back)

@@ -34,6 +34,7 @@ struct ExtJob {
                          // 2 = band kernel: [anti-diagonal][t mod SL]
     int32_t qstride;     // layout 1: row width W = n_lanes * S bytes; layout 2: SL
     int32_t strip_s;     // layout 1: S
+    int32_t cls;         // launch list | second-pass list << 8 | (band variant + 1) << 16 (job_classify_kernel); -1: placeholder without DP
 };
 
 struct ExtRes {

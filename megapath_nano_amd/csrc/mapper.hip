@@ -564,7 +564,7 @@ static int build_index_device(mpn_index *idx, const uint8_t *d_seqs, const std::
     MPN_HIP_CHECK(hipMemcpyAsync(idx->key_off.p + n_keys, &n_mz, 8, hipMemcpyHostToDevice, st));
     MPN_HIP_CHECK(stream_sync(st));
     MPN_HIP_CHECK(hipGetLastError());
-    if (build_bucket_table(idx, st) || idx->d_seq_off.upload(off.data(), off.size(), st)) return -1;
+    if (build_bucket_table(idx, st) || idx->d_seq_off.upload(off.data(), off.size(), st) || idx->d_lens.upload(idx->lens.data(), idx->lens.size(), st)) return -1;
     MPN_HIP_CHECK(stream_sync(st));
     return 0;
 }
@@ -755,6 +755,7 @@ mpn_index *mpn_index_load(const char *path) {
     hipStream_t st = 0;
     if (idx->keys.upload(keys.data(), keys.size(), st) || idx->key_off.upload(h_key_off.data(), h_key_off.size(), st) ||
         idx->pos.upload(pos.data(), pos.size(), st) || idx->d_seq_off.upload(idx->seq_off.data(), idx->seq_off.size(), st) ||
+        idx->d_lens.upload(idx->lens.data(), idx->lens.size(), st) ||
         idx->d_seq2.upload(idx->h_seq2.data(), idx->h_seq2.size(), st) || idx->d_nrun_s.upload(ns.data(), ns.size(), st) ||
         idx->d_nrun_e.upload(ne.data(), ne.size(), st) || build_bucket_table(idx, st) || stream_sync(st) != hipSuccess) {
         delete idx;  // (the failing HIP call has set the error text)

@@ -33,6 +33,7 @@ struct mpn_index {
     int bucket_shift = 0;
     mpn::DevBuf<uint32_t> d_seq2;     // device: targets packed 2 bits per base
     mpn::DevBuf<int64_t> d_seq_off, d_nrun_s, d_nrun_e;  // + ambiguous-base runs (concatenated coordinates)
+    mpn::DevBuf<int32_t> d_lens;      // target lengths (the planning kernel clips the extension windows with them)
     int32_t n_nruns = 0;
     mutable std::mutex mu;
     mutable std::vector<std::pair<float, int32_t>> mid_occ_cache;

@@ -1,0 +1,378 @@
+// Planning of the base-level extension on the GPU: the first half of minimap2's mm_align1 (mm_fix_bad_ends, mm_filter_bad_seeds,
+// the extension limits, the cut of a chain into gap-fill windows) for every hit of a round, followed by the choice of a DP kernel
+// and of the direction-matrix layout for every window and by the launch lists.  The host hands over 40 bytes per hit and
+// reads back a few counters; no job record is built, copied or sorted on the host.
+//
+//   plan_kernel<false / true>   one LANE per hit (the logic is a sequential walk over the hit's anchors with early exits): count
+//                               its windows / write their job records + the hit's stitching record
+//   job_classify_kernel         one lane per window: band width, strip / band / LDS kernel, matrix layout, scratch needs, list
+//   job_layout_kernel           scratch offsets from the scans, scatter of the windows into their launch lists (strip lists
+//                               bucketed by query length, so that the windows that share a wave need a similar number of steps)
+#pragma once
+#include "stitch_kernels.h"
+
+namespace mpn {
+
+constexpr uint64_t PK_SEED_LONG_JOIN = 1ULL << 40, PK_SEED_IGNORE = 1ULL << 41, PK_SEED_TANDEM = 1ULL << 42;
+
+struct PlanOpt {
+    int32_t bw, bw15, min_chain_score, max_gap, min_cnt, a, q, e, zdrop, zdrop_inv, end_bonus, min_ksw_len, k, pad;
+    int64_t max_sw_mat;
+};
+
+__device__ __forceinline__ int32_t pk_x(const u128 &v) { return (int32_t)v.x; }
+__device__ __forceinline__ int32_t pk_y(const u128 &v) { return (int32_t)v.y; }
+__device__ __forceinline__ int32_t pk_span(const u128 &v) { return (int32_t)(v.y >> 32 & 0xff); }
+
+// mm_filter_bad_seeds without its index array: K = the anchors whose gap to their predecessor exceeds min_gap is walked as a
+// virtual sequence (an entry is found by scanning forward), K-indices and anchor indices are tracked side by side
+__device__ inline void pk_filter_bad_seeds(int as1, int cnt1, u128 *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+    auto gap_at = [&](int i) { return (pk_y(a[as1 + i]) - pk_y(a[as1 + i - 1])) - (pk_x(a[as1 + i]) - pk_x(a[as1 + i - 1])); };
+    auto is_k = [&](int i) { const int g = gap_at(i); return g < -min_gap || g > min_gap; };
+    auto next_k = [&](int i) { for (++i; i < cnt1; ++i) if (is_k(i)) return i; return cnt1; };   // anchor index of the next K entry (cnt1: none)
+    int first = next_k(0);
+    if (first >= cnt1 || next_k(first) >= cnt1) return;   // fewer than two entries
+    int max = 0, max_st_k = -1, max_en_k = -1, max_st_i = -1, max_en_i = -1;
+    int ik = first;   // anchor index of K[k]
+    for (int k = 0;; ++k) {
+        const bool at_end = ik >= cnt1;
+        if (at_end || k >= max_en_k) {
+            if (max_en_k > 0) for (int i = max_st_i; i < max_en_i; ++i) a[as1 + i].y |= PK_SEED_IGNORE;
+            max = 0; max_st_k = max_en_k = -1;
+            if (at_end) break;
+        }
+        int gap = gap_at(ik), n_ins = 0, n_del = 0, max_diff = 0, max_diff_l = -1, max_diff_i = -1;
+        if (gap > 0) n_ins += gap; else n_del += -gap;
+        const int qs = pk_y(a[as1 + ik - 1]), rs = pk_x(a[as1 + ik - 1]);
+        int jl = ik;
+        for (int l = k + 1; l <= k + max_ext_cnt; ++l) {
+            jl = next_k(jl);
+            if (jl >= cnt1) break;
+            if (pk_y(a[as1 + jl]) - qs > max_ext_len || pk_x(a[as1 + jl]) - rs > max_ext_len) break;
+            gap = gap_at(jl);
+            if (gap > 0) n_ins += gap; else n_del += -gap;
+            const int d = n_ins - n_del, diff = n_ins + n_del - (d < 0 ? -d : d);
+            if (max_diff < diff) { max_diff = diff; max_diff_l = l; max_diff_i = jl; }
+        }
+        if (max_diff > diff_thres && max_diff > max) { max = max_diff; max_st_k = k; max_en_k = max_diff_l; max_st_i = ik; max_en_i = max_diff_i; }
+        ik = next_k(ik);
+    }
+    (void)max_st_k;
+}
+
+// The planning half of mm_align1 for one hit.  FILL = false counts the windows; FILL = true writes them (jobs, job_anchor) and
+// the hit's stitching record.  Both passes set the same SEED_IGNORE flags (the filter is idempotent).
+template <bool FILL>
+__device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, u128 *a, const int32_t *__restrict__ tlens, int32_t ri, int32_t first_job,
+                               ExtJob *__restrict__ jobs, int32_t *__restrict__ job_anchor, StitchReg *__restrict__ sregs, PlanSum *__restrict__ psum) {
+    const int32_t rid = (int32_t)(a[pr.as].x << 1 >> 33), rev = (int32_t)(a[pr.as].x >> 63);
+    const int32_t tlen_all = tlens[rid], kh = o.k >> 1, qlen = pr.qlen;
+    const int bw = o.bw15;
+    int nj = 0;
+    auto emit = [&](int qs_, int ql, int ts_, int tl, int reversed, int w, int zdrop, int end_bonus, int flag, int anchor_i) {
+        if constexpr (FILL) {
+            ExtJob j;
+            j.read = pr.read; j.rid = rid; j.rev = rev; j.qs = qs_; j.qlen = ql; j.ts = ts_; j.tlen = tl; j.reversed = reversed;
+            j.w = w; j.zdrop = zdrop; j.end_bonus = end_bonus; j.flag = flag;
+            j.p_off = 0; j.row_off = 0; j.cig_off = 0; j.n_col = 0; j.state_mode = 0; j.state_off = 0; j.layout = 0; j.qstride = 0; j.strip_s = 1; j.cls = -1;
+            jobs[first_job + nj] = j;
+            job_anchor[first_job + nj] = anchor_i;
+        }
+        ++nj;
+    };
+    auto too_big = [&](int ql, int tl) { return o.max_sw_mat > 0 && (int64_t)tl * ql > o.max_sw_mat; };
+    // ---- mm_fix_bad_ends ----
+    int32_t as1 = pr.as, cnt1 = pr.cnt;
+    if (pr.cnt >= 3) {
+        const int min_match = o.min_chain_score * 2;
+        int32_t m, l;
+        m = l = pk_span(a[pr.as]);
+        for (int i = pr.as + 1; i < pr.as + pr.cnt - 1; ++i) {
+            const int32_t q_span = pk_span(a[i]);
+            if (a[i].y & PK_SEED_LONG_JOIN) break;
+            const int32_t lr = pk_x(a[i]) - pk_x(a[i - 1]), lq = pk_y(a[i]) - pk_y(a[i - 1]);
+            const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+            if (mx - mn > l >> 1) as1 = i;
+            l += mn;
+            m += mn < q_span ? mn : q_span;
+            if (l >= o.bw << 1 || (m >= min_match && m >= o.bw) || m >= pr.mlen >> 1) break;
+        }
+        cnt1 = pr.as + pr.cnt - as1;
+        m = l = pk_span(a[pr.as + pr.cnt - 1]);
+        for (int i = pr.as + pr.cnt - 2; i > as1; --i) {
+            const int32_t q_span = pk_span(a[i + 1]);
+            if (a[i + 1].y & PK_SEED_LONG_JOIN) break;
+            const int32_t lr = pk_x(a[i + 1]) - pk_x(a[i]), lq = pk_y(a[i + 1]) - pk_y(a[i]);
+            const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+            if (mx - mn > l >> 1) cnt1 = i + 1 - as1;
+            l += mn;
+            m += mn < q_span ? mn : q_span;
+            if (l >= o.bw << 1 || (m >= min_match && m >= o.bw) || m >= pr.mlen >> 1) break;
+        }
+    }
+    pk_filter_bad_seeds(as1, cnt1, a, 10, 40, o.max_gap >> 1, 10);
+    // ---- limits of the two extensions ----
+    int32_t rs = pk_x(a[as1]) - kh, qs = pk_y(a[as1]) - kh;
+    int32_t re = pk_x(a[as1 + cnt1 - 1]) - kh, qe = pk_y(a[as1 + cnt1 - 1]) - kh;
+    int32_t rs0, qs0, re0, qe0, rs1 = 0, qs1 = 0, re1, qe1, l, i;
+    rs0 = pk_x(a[pr.as]) + 1 - pk_span(a[pr.as]);
+    qs0 = pk_y(a[pr.as]) + 1 - pk_span(a[pr.as]);
+    if (rs0 < 0) rs0 = 0;
+    for (i = pr.as - 1, l = 0; i >= 0 && a[i].x >> 32 == a[pr.as].x >> 32; --i) {
+        const int32_t x = pk_x(a[i]) + 1 - pk_span(a[i]), y = pk_y(a[i]) + 1 - pk_span(a[i]);
+        if (x < rs0 && y < qs0) {
+            if (++l > o.min_cnt) {
+                l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+                rs1 = rs0 - l; qs1 = qs0 - l;
+                if (rs1 < 0) rs1 = 0;
+                break;
+            }
+        }
+    }
+    if (qs > 0 && rs > 0) {
+        l = qs < o.max_gap ? qs : o.max_gap;
+        qs1 = qs1 > qs - l ? qs1 : qs - l;
+        qs0 = qs0 < qs1 ? qs0 : qs1;
+        l += l * o.a > o.q ? (l * o.a - o.q) / o.e : 0;
+        l = l < o.max_gap ? l : o.max_gap;
+        l = l < rs ? l : rs;
+        rs1 = rs1 > rs - l ? rs1 : rs - l;
+        rs0 = rs0 < rs1 ? rs0 : rs1;
+        rs0 = rs0 < rs ? rs0 : rs;
+    } else { rs0 = rs; qs0 = qs; }
+    re0 = pk_x(a[pr.as + pr.cnt - 1]) + 1;
+    qe0 = pk_y(a[pr.as + pr.cnt - 1]) + 1;
+    re1 = tlen_all; qe1 = qlen;
+    for (i = pr.as + pr.cnt, l = 0; i < pr.n_a && a[i].x >> 32 == a[pr.as].x >> 32; ++i) {
+        const int32_t x = pk_x(a[i]) + 1, y = pk_y(a[i]) + 1;
+        if (x > re0 && y > qe0) {
+            if (++l > o.min_cnt) {
+                l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+                re1 = re0 + l; qe1 = qe0 + l;
+                break;
+            }
+        }
+    }
+    if (qe < qlen && re < tlen_all) {
+        l = qlen - qe < o.max_gap ? qlen - qe : o.max_gap;
+        qe1 = qe1 < qe + l ? qe1 : qe + l;
+        qe0 = qe0 > qe1 ? qe0 : qe1;
+        l += l * o.a > o.q ? (l * o.a - o.q) / o.e : 0;
+        l = l < o.max_gap ? l : o.max_gap;
+        l = l < tlen_all - re ? l : tlen_all - re;
+        re1 = re1 < re + l ? re1 : re + l;
+        re0 = re0 > re1 ? re0 : re1;
+    } else { re0 = re; qe0 = qe; }
+    const int32_t first_qs = qs, first_rs = rs;
+    // ---- the windows: left extension, gap fills, right extension ----
+    if (qs > 0 && rs > 0) {
+        if (!too_big(qs - qs0, rs - rs0))
+            emit(qs0, qs - qs0, rs0, rs - rs0, 1, bw, pr.split_inv ? o.zdrop_inv : o.zdrop, o.end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR, -1);
+        else emit(qs0, 0, rs0, 0, 1, 0, 0, 0, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR | EZ_REFUSED, -1);
+    }
+    for (i = 1; i < cnt1; ++i) {
+        const uint64_t fl = a[as1 + i].y;
+        if ((fl & (PK_SEED_IGNORE | PK_SEED_TANDEM)) && i != cnt1 - 1) continue;
+        re = pk_x(a[as1 + i]) - kh; qe = pk_y(a[as1 + i]) - kh;
+        if (i == cnt1 - 1 || (fl & PK_SEED_LONG_JOIN) || (qe - qs >= o.min_ksw_len && re - rs >= o.min_ksw_len)) {
+            int bw1 = bw;
+            if (fl & PK_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+            if (!too_big(qe - qs, re - rs) && qe - qs > 0 && re - rs > 0) emit(qs, qe - qs, rs, re - rs, 0, bw1, o.zdrop, -1, EZ_APPROX_MAX, i);
+            else emit(qs, 0, rs, 0, 0, 0, 0, 0, EZ_APPROX_MAX | EZ_REFUSED, i);
+            rs = re; qs = qe;
+        }
+    }
+    if (qe < qe0 && re < re0) {
+        if (!too_big(qe0 - qe, re0 - re)) emit(qe, qe0 - qe, re, re0 - re, 0, bw, o.zdrop, o.end_bonus, EZ_EXTZ_ONLY, -1);
+        else emit(qe, 0, re, 0, 0, 0, 0, 0, EZ_EXTZ_ONLY | EZ_REFUSED, -1);
+    }
+    if constexpr (FILL) {
+        sregs[ri] = StitchReg{first_job, nj, first_qs, first_rs, qe, re, qs0, qe0, pr.read, rid, rev, 0};
+        psum[ri] = PlanSum{as1, cnt1};
+    }
+    return nj;
+}
+
+// one block: exclusive scan of n counts (out has n + 1 entries, the last one the total)
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t *__restrict__ in, int64_t *__restrict__ out, int n) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
+    long long s = 0;
+    for (int j = lo; j < hi; ++j) s += in[j];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { long long acc = 0; for (int k = 0; k < 1024; ++k) { const long long v = part[k]; part[k] = acc; acc += v; } out[n] = acc; }
+    __syncthreads();
+    long long o = part[t];
+    for (int j = lo; j < hi; ++j) { const long long v = in[j]; out[j] = o; o += v; }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void plan_kernel(PlanOpt o, const PlanReg *__restrict__ pregs, int n_regs, u128 *__restrict__ A,
+                                                  const int32_t *__restrict__ tlens, int64_t *__restrict__ n_jobs, const int64_t *__restrict__ job_off,
+                                                  ExtJob *__restrict__ jobs, int32_t *__restrict__ job_anchor, StitchReg *__restrict__ sregs,
+                                                  PlanSum *__restrict__ psum) {
+    for (int ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_regs; ri += gridDim.x * blockDim.x) {
+        const PlanReg pr = pregs[ri];
+        const int nj = plan_hit<FILL>(o, pr, A + pr.a_off, tlens, ri, FILL ? (int32_t)job_off[ri] : 0, jobs, job_anchor, sregs, psum);
+        if constexpr (!FILL) n_jobs[ri] = nj;
+    }
+}
+
+// ---- kernel choice and direction-matrix layout of every window --------------------------------------------------------------
+// launch lists: every DP window belongs to exactly one
+// (strip lists: lane-group class (16/32/64 lanes per window) x strip height 1..16; each is padded to whole waves)
+enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 48, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
+constexpr int STRIP_QB = 64;                                  // query-length buckets inside a strip list (longest first)
+constexpr int N_BUCKETS = N_LISTS + N_STRIP * (STRIP_QB - 1);  // scatter buckets: a strip list is STRIP_QB consecutive buckets
+__host__ __device__ inline int strip_windows_per_wave(int l) { return 4 >> ((l - L_STRIP) / 16); }
+__host__ __device__ inline int bucket_of_list(int l) {       // first bucket of list l
+    return l < L_STRIP ? l : l < L_BAND ? L_STRIP + (l - L_STRIP) * STRIP_QB : L_STRIP + N_STRIP * STRIP_QB + (l - L_BAND);
+}
+
+struct LayoutTotals {          // read back by the host after job_layout_kernel
+    long long p_tot, row_tot, cig_tot, state_tot, cells, strip_cells[3];
+    int lds_need[5], strip_lds[3], band_lds[4];
+    int too_large, tl_q, tl_t, pad;
+    int cnt[N_LISTS], base[N_LISTS + 1];   // launch lists in the flat order array (strip lists padded to whole waves)
+};
+
+struct JobSizes { long long p, row, cig, st; };   // scratch needs of a window (scanned into offsets)
+
+__global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ jobs, int nj, int strip_scores, int force_kernel,
+                                                           JobSizes *__restrict__ sizes, int32_t *__restrict__ bucket_cnt,
+                                                           LayoutTotals *__restrict__ tot) {
+    const int lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
+    long long cells = 0, scells[3] = {0, 0, 0};
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        ExtJob jb = jobs[j];
+        JobSizes sz{0, 0, 0, 0};
+        if (jb.flag & EZ_REFUSED) { jb.cls = -1; jobs[j].cls = -1; sizes[j] = sz; continue; }
+        const int w = jb.w < 0 ? max(jb.tlen, jb.qlen) : jb.w;
+        int n_col = min(jb.qlen, jb.tlen);
+        n_col = min(n_col, w + 1) + 1;
+        jb.n_col = n_col;
+        const long long n_r = (long long)jb.qlen + jb.tlen - 1;
+        // strip kernel: lane-group class by target rows (16 x 16, 32 x 16, 64 x 16) and by what the queries of one wave may
+        // take in LDS (1024 / 2048 / 4096 bases per window)
+        int glc = -1;
+        if ((jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed && w >= max(jb.qlen, jb.tlen) && strip_scores &&
+            (force_kernel == 0 || force_kernel == 4)) {
+            for (int c = 0; c < 3 && glc < 0; ++c)
+                if (jb.tlen <= (256 << c) && jb.qlen <= (1024 << c)) glc = c;
+        }
+        const bool strip = glc >= 0;
+        const int seqb = ((jb.qlen + 3) & ~3) + ((jb.tlen + 3) & ~3);
+        // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
+        int bv = n_col <= 128 ? 0 : n_col <= 256 ? 1 : n_col <= 512 ? 2 : n_col <= 1024 ? 3 : -1;
+        if (seqb > lds_cap[3] || !(force_kernel == 0 || force_kernel == 4 || force_kernel == 5)) bv = -1;
+        int bc = 3;
+        for (int c = 0; c < 4; ++c) if (seqb <= lds_cap[c]) { bc = c; break; }
+        if (bv >= 0) atomicMax(&tot->band_lds[bc], seqb);
+        jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
+        const int strip_gl = 16 << max(glc, 0);
+        jb.strip_s = max(1, min(16, (jb.tlen + strip_gl - 1) / strip_gl));   // strip height: the window's rows over its lane group
+        const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
+        jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << max(bv, 0);   // row width of the direction matrix (layouts 1, 2)
+        const long long strip_bytes = (long long)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
+        // (the rare exact second pass of a strip window gets its direction matrix from a pool of its own)
+        sz.p = ((strip ? strip_bytes : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~15LL;
+        cells += n_r * n_col;
+        if (strip) scells[glc] += (long long)jb.qlen * jb.tlen;
+        const int stateb = ((6 * jb.tlen + 3) & ~3) + 4 * jb.tlen;
+        int cls = 4;
+        for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
+        jb.state_mode = 0;
+        const bool use_wg = force_kernel == 3 || (force_kernel != 1 && n_col - 1 > 128);
+        const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
+        const int redo_list = bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls;
+        int lid;
+        if (strip) { lid = L_STRIP + glc * 16 + jb.strip_s - 1; atomicMax(&tot->strip_lds[glc], (jb.qlen + 15) & ~15); }
+        else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
+        else lid = redo_list;
+        if (bv < 0) {   // the LDS-state kernels may run this window (now or in the second pass)
+            if (cls == 4) {
+                if (seqb > lds_cap[3]) { tot->too_large = 1; tot->tl_q = jb.qlen; tot->tl_t = jb.tlen; }
+                jb.state_mode = 1; sz.st = (stateb + 15) & ~15;
+                atomicMax(&tot->lds_need[4], seqb);
+            } else atomicMax(&tot->lds_need[cls], seqb + stateb);
+            sz.row = n_r;   // band limits are stored only by the LDS-state kernels
+        }
+        sz.cig = jb.qlen + jb.tlen + 2;
+        jb.cls = lid | redo_list << 8 | (bv + 1) << 16;
+        jobs[j] = jb;
+        sizes[j] = sz;
+        // bucket: a strip list is split by query length, longest first
+        int b = bucket_of_list(lid);
+        if (strip) b += STRIP_QB - 1 - min(STRIP_QB - 1, jb.qlen >> (4 + glc));
+        atomicAdd(&bucket_cnt[b], 1);
+    }
+    // (per-block reduction of the cell counters, one atomic per block)
+    __shared__ long long red[4];
+    if (threadIdx.x < 4) red[threadIdx.x] = 0;
+    __syncthreads();
+    long long v[4] = {cells, scells[0], scells[1], scells[2]};
+    for (int q = 0; q < 4; ++q) {
+        for (int d = 32; d; d >>= 1) v[q] += __shfl_xor(v[q], d);
+        if ((threadIdx.x & 63) == 0 && v[q]) atomicAdd((unsigned long long *)&red[q], (unsigned long long)v[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (red[0]) atomicAdd((unsigned long long *)&tot->cells, (unsigned long long)red[0]);
+        for (int c = 0; c < 3; ++c) if (red[1 + c]) atomicAdd((unsigned long long *)&tot->strip_cells[c], (unsigned long long)red[1 + c]);
+    }
+}
+
+// one block: exclusive scans of the four scratch sizes (in place: sizes[j] becomes the window's offsets), of the bucket counts
+// (bucket_cur = first slot of every bucket in the flat order array, strip lists padded to whole waves) and the list table
+__global__ __launch_bounds__(1024) void job_scan_kernel(JobSizes *__restrict__ sizes, int nj, const int32_t *__restrict__ bucket_cnt,
+                                                        int32_t *__restrict__ bucket_cur, LayoutTotals *__restrict__ tot) {
+    __shared__ long long part[1024][4];
+    const int t = threadIdx.x, per = (nj + 1023) / 1024, lo = min(nj, t * per), hi = min(nj, lo + per);
+    long long s[4] = {0, 0, 0, 0};
+    for (int j = lo; j < hi; ++j) { s[0] += sizes[j].p; s[1] += sizes[j].row; s[2] += sizes[j].cig; s[3] += sizes[j].st; }
+    for (int q = 0; q < 4; ++q) part[t][q] = s[q];
+    __syncthreads();
+    if (t < 4) {
+        long long acc = 0;
+        for (int k = 0; k < 1024; ++k) { const long long v = part[k][t]; part[k][t] = acc; acc += v; }
+        if (t == 0) tot->p_tot = acc; else if (t == 1) tot->row_tot = acc; else if (t == 2) tot->cig_tot = acc; else tot->state_tot = acc;
+    }
+    __syncthreads();
+    long long o[4] = {part[t][0], part[t][1], part[t][2], part[t][3]};
+    for (int j = lo; j < hi; ++j) {
+        const JobSizes z = sizes[j];
+        // (cig: the window's END offset in the CIGAR scratch, as the traceback kernel expects)
+        sizes[j] = JobSizes{o[0], o[1], o[2] + z.cig, o[3]};
+        o[0] += z.p; o[1] += z.row; o[2] += z.cig; o[3] += z.st;
+    }
+    if (t == 0) {
+        int pos = 0;
+        for (int l = 0; l < N_LISTS; ++l) {
+            const int b0 = bucket_of_list(l), nb = (l >= L_STRIP && l < L_BAND) ? STRIP_QB : 1;
+            int c = 0;
+            tot->base[l] = pos;
+            for (int b = 0; b < nb; ++b) { bucket_cur[b0 + b] = pos + c; c += bucket_cnt[b0 + b]; }
+            tot->cnt[l] = c;
+            if (nb > 1) { const int pw = strip_windows_per_wave(l); c = (c + pw - 1) / pw * pw; }
+            pos += c;
+        }
+        tot->base[N_LISTS] = pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void job_layout_kernel(ExtJob *__restrict__ jobs, int nj, const JobSizes *__restrict__ offs,
+                                                         int32_t *__restrict__ bucket_cur, int32_t *__restrict__ order) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        ExtJob &jb = jobs[j];
+        if (jb.cls < 0) continue;
+        const JobSizes z = offs[j];
+        jb.p_off = z.p; jb.row_off = z.row; jb.cig_off = z.cig; jb.state_off = z.st;
+        const int lid = jb.cls & 0xff;
+        int b = bucket_of_list(lid);
+        if (lid >= L_STRIP && lid < L_BAND) b += STRIP_QB - 1 - min(STRIP_QB - 1, jb.qlen >> (4 + (lid - L_STRIP) / 16));
+        order[atomicAdd(&bucket_cur[b], 1)] = j;
+    }
+}
+
+}  // namespace mpn

@@ -21,8 +21,20 @@ struct StitchReg {
 struct StitchOut {
     int64_t cig_off;                  // start of the stitched CIGAR in the round's pool
     int32_t n_ops, dp_score, rs1, re1, qs1, qe1;
-    int32_t has_p, dropped, drop_fill, drop_max_t, drop_max_q, pad;   // drop_fill: index of the z-dropped gap fill among the hit's fills
+    int32_t has_p, dropped, drop_fill, drop_max_t, drop_max_q;   // drop_fill: index of the z-dropped gap fill among the hit's fills
+    int32_t split_n;                  // > 0: a z-drop cuts the hit after its first split_n anchors (mm_align1's mm_split_reg call)
 };
+
+
+
+// One hit to align in this round, as the host hands it to the planning kernel (plan_kernels.h), and what that kernel leaves
+// for the split of a z-dropped hit
+struct PlanReg {
+    int64_t a_off;                   // the read's (squeezed) chained anchors in the device copy
+    int32_t n_a, as, cnt, mlen;      // anchors of the read; the hit's anchors [as, as + cnt); its approximate match length
+    int32_t read, qlen, split_inv, pad;
+};
+struct PlanSum { int32_t as1, cnt1; };   // the hit's anchors after mm_fix_bad_ends
 
 constexpr uint32_t OP_NONE = 0xf;
 
@@ -32,7 +44,9 @@ constexpr uint32_t OP_NONE = 0xf;
 __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict__ regs, int n_regs, const ExtJob *__restrict__ jobs,
                                                     const ExtRes *__restrict__ res, const uint32_t *__restrict__ COMPACT,
                                                     uint32_t *__restrict__ OUT, unsigned long long *__restrict__ out_used,
-                                                    StitchOut *__restrict__ outs, FinJob *__restrict__ fin_jobs) {
+                                                    StitchOut *__restrict__ outs, FinJob *__restrict__ fin_jobs,
+                                                    const PlanReg *__restrict__ pregs, const PlanSum *__restrict__ psum,
+                                                    const int32_t *__restrict__ job_anchor, const u128 *__restrict__ A, int min_cnt) {
     const int lane = threadIdx.x;
     for (int ri = blockIdx.x; ri < n_regs; ri += gridDim.x) {
         const StitchReg sr = regs[ri];
@@ -125,13 +139,20 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                 qs1 = sr.qs - (reach ? sr.qs - sr.qs0 : max_q + 1);
             }
             StitchOut o;
-            o.drop_fill = -1; o.drop_max_t = o.drop_max_q = -1;
+            o.drop_fill = -1; o.drop_max_t = o.drop_max_q = -1; o.split_n = 0;
             if (dropped) {
                 const ExtJob &jb = jb0[k_stop];
                 int max_t = -1, max_q = -1;
                 if (!(jb.flag & EZ_REFUSED)) { max_t = rs0[k_stop].max_t; max_q = rs0[k_stop].max_q; }
                 re1 = jb.ts + (max_t + 1); qe1 = jb.qs + (max_q + 1);
                 o.drop_fill = k_stop - (has_left ? 1 : 0); o.drop_max_t = max_t; o.drop_max_q = max_q;
+                // the hit is cut after the last anchor that lies before the drop, if enough anchors remain behind it
+                const u128 *a = A + pregs[ri].a_off;
+                const int as1 = psum[ri].as1, cnt1 = psum[ri].cnt1;
+                int j;
+                for (j = job_anchor[sr.first_job + k_stop] - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= jb.ts + max_t) break;
+                if (j < 0) j = 0;
+                if (cnt1 - (j + 1) >= min_cnt) o.split_n = as1 + j + 1 - pregs[ri].as;
             } else if (n > 0 && (jb0[n - 1].flag & EZ_EXTZ_ONLY) && !jb0[n - 1].reversed) {
                 int reach = 0, max_t = -1, max_q = -1, mqe_t = -1;
                 if (!(jb0[n - 1].flag & EZ_REFUSED)) { const ExtRes &e = rs0[n - 1]; reach = e.reach_end; max_t = e.max_t; max_q = e.max_q; mqe_t = e.mqe_t; }
@@ -139,7 +160,7 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                 qe1 = sr.qe + (reach ? sr.qe0 - sr.qe : max_q + 1);
             }
             o.cig_off = (int64_t)base; o.n_ops = total; o.dp_score = dp; o.rs1 = rs1; o.re1 = re1; o.qs1 = qs1; o.qe1 = qe1;
-            o.has_p = any_ops || dropped; o.dropped = dropped; o.pad = 0;
+            o.has_p = any_ops || dropped; o.dropped = dropped;
             outs[ri] = o;
             FinJob f;
             f.cig_off = (int64_t)base; f.code_off = 0; f.n_cigar = total; f.read = sr.read; f.rid = sr.rid; f.rev = sr.rev;
