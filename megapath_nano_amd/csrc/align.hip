@@ -402,7 +402,7 @@ void CpuSect::lap(int k) {
 class HostPool {
     struct Job {
         const std::function<void(int, int)> *fn;
-        int n, max_par, tag = 0;
+        int n, max_par, tag = 0, chunk = 1;   // items are handed out `chunk` at a time: one atomic per item is a hot cache line
         std::atomic<int> next{0};
         int slots = 1, active = 0;  // guarded by mu (slot 0 is the posting thread)
     };
@@ -412,11 +412,19 @@ class HostPool {
     std::vector<std::thread> threads;
     bool stop = false;
 
+    static void drain(Job &j, int slot) {
+        for (;;) {
+            const int i0 = j.next.fetch_add(j.chunk);
+            if (i0 >= j.n) break;
+            const int i1 = std::min(j.n, i0 + j.chunk);
+            for (int i = i0; i < i1; ++i) (*j.fn)(i, slot);
+        }
+    }
     static void run(Job &j, int slot) {
-        if (!g_cpu_on) { for (;;) { const int i = j.next.fetch_add(1); if (i >= j.n) break; (*j.fn)(i, slot); } return; }
+        if (!g_cpu_on) { drain(j, slot); return; }
         timespec a, b;
         clock_gettime(CLOCK_THREAD_CPUTIME_ID, &a);
-        for (;;) { const int i = j.next.fetch_add(1); if (i >= j.n) break; (*j.fn)(i, slot); }
+        drain(j, slot);
         clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b);
         g_cpu_ns[j.tag & 31] += (b.tv_sec - a.tv_sec) * 1000000000LL + (b.tv_nsec - a.tv_nsec);
     }
@@ -448,6 +456,7 @@ public:
         if (max_par <= 1 || n < 2) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
         Job j;
         j.fn = &fn; j.n = n; j.max_par = max_par; j.tag = tag;
+        j.chunk = std::max(1, std::min(32, n / (max_par * 8)));
         { std::lock_guard<std::mutex> g(mu); jobs.push_back(&j); }
         cv_work.notify_all();
         run(j, 0);
@@ -663,15 +672,18 @@ struct DevRound {
     uint32_t *compact = nullptr;
     unsigned long long *used = nullptr;
     int64_t cig_cap = 0;   // CIGAR operations the round's windows can produce at most
+    int n_jobs = 0;        // windows of the round (read back with the layout counters)
 };
 
 // Run one group of DP windows whose raw job records are on the device (dv.jobs[0..nj), as plan_kernel or the stage test wrote
 // them): kernel choice, direction-matrix layout and launch lists are made on the device (plan_kernels.h) and a block of counters
 // comes back; then the DP kernels, the traceback, the z-drop test and the rare exact second pass.  budget > 0: returns 1
 // without launching any DP if the direction matrices need more than that (the caller then cuts the range).
-static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj, DevRound &dv, const uint8_t *d_reads,
+static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, const unsigned long long *d_nj, DevRound &dv, const uint8_t *d_reads,
                          const int64_t *d_read_off, const int32_t *d_read_len, int64_t budget, hipStream_t st) {
-    if (nj == 0) return 0;
+    // nj_cap: an upper bound of the number of windows (the count itself is on the device, *d_nj: the planning kernel wrote it)
+    if (nj_cap == 0) return 0;
+    int nj = nj_cap;
     WallTimer wt;
     Slot &SL = *tl_slot;
     const int strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi) ? 1 : 0;
@@ -688,15 +700,21 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj, DevR
     MPN_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)2 * N_BUCKETS * 4, st));
     MPN_HIP_CHECK(hipMemsetAsync(d_tot, 0, sizeof(LayoutTotals), st));
     MPN_HIP_CHECK(hipMemsetAsync(d_order.p, 0xff, order_cap * 4, st));   // -1: the padding of the strip lists
-    const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256 * 8));
-    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, nj, strip_scores, g_force_kernel, d_sizes, d_bcnt, d_tot);
-    hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, nj, (const int32_t *)d_bcnt, d_bcur, d_tot);
-    hipLaunchKernelGGL(job_layout_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, nj, (const JobSizes *)d_sizes, d_bcur, d_order.p);
+    const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256));   // (a block per CU: every block flushes its counters once)
+    EvTimer evl(st);
+    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, g_force_kernel, d_sizes, d_bcnt, d_tot);
+    hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, d_nj, (const int32_t *)d_bcnt, d_bcur, d_tot);
+    hipLaunchKernelGGL(job_layout_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, (const JobSizes *)d_sizes, d_bcur, d_order.p);
     MPN_HIP_CHECK(hipGetLastError());
     LayoutTotals *h_tot = SL.pin_res.as<LayoutTotals>();
+    evl.mark(56);
     MPN_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(LayoutTotals), hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(stream_sync(st));
+    evl.resolve();
     const LayoutTotals T = *h_tot;
+    nj = T.n_jobs;
+    dv.n_jobs = nj;
+    if (nj == 0) return 0;
     if (T.too_large) { set_error("DP window too large for LDS staging (%d x %d)", T.tl_q, T.tl_t); return -4; }
     if (!dv.compact) {
         // (the compact pool holds every window's operations, and once more those of the windows that take the second pass)
@@ -885,17 +903,18 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj, DevR
 // Run the DP windows whose raw job records the caller has put at the start of the worker's job pool (SL.pool_jobs), in groups
 // whose direction scratch stays under the budget (MPN_DP_BUDGET bytes, for tests).  The job records, results and compacted
 // CIGARs of ALL groups stay in the worker's device pools (out); a group only borrows the direction-matrix scratch.
-static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj, const uint8_t *d_reads, const int64_t *d_read_off,
+static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj_cap, const uint8_t *d_reads, const int64_t *d_read_off,
                     const int32_t *d_read_len, DevRound &out, hipStream_t st) {
     static const int64_t budget = []() { const char *e = getenv("MPN_DP_BUDGET"); return e ? std::max<int64_t>(1 << 20, atoll(e)) : (int64_t)40 << 30; }();
     Slot &SL = *tl_slot;
-    if (SL.pool_res.ensure((size_t)nj * sizeof(ExtRes) + 16) || SL.pool_used.ensure(32)) return -1;
+    if (SL.pool_res.ensure((size_t)nj_cap * sizeof(ExtRes) + 16) || SL.pool_used.ensure(64)) return -1;
     out.jobs = SL.pool_jobs.as<ExtJob>(); out.res = SL.pool_res.as<ExtRes>(); out.compact = nullptr;
-    out.used = SL.pool_used.as<unsigned long long>();
-    MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 32, st));   // [0] compacted ops, [1] second-pass windows, [2] stitched ops
-    const int rc = run_job_group(rv, opt, nj, out, d_reads, d_read_off, d_read_len, budget, st);
+    out.used = SL.pool_used.as<unsigned long long>();   // [0] compacted ops, [1] second-pass windows, [2] stitched ops, [3] windows of the round, [4] of a sub-range
+    MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 24, st));
+    const int rc = run_job_group(rv, opt, nj_cap, out.used + 3, out, d_reads, d_read_off, d_read_len, budget, st);
     if (rc != 1) return rc;
     // over the budget: cut the range where the direction matrices (their offsets are in the size table) fill it
+    const int nj = out.n_jobs;
     std::vector<JobSizes> sz((size_t)nj);
     MPN_HIP_CHECK(hipMemcpy(sz.data(), SL.pool_sizes.p, (size_t)nj * sizeof(JobSizes), hipMemcpyDeviceToHost));
     std::vector<int> cuts{0};
@@ -904,9 +923,12 @@ static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj, const uin
     for (size_t g = 0; g + 1 < cuts.size(); ++g) {
         DevRound dv = out;
         dv.jobs += cuts[g]; dv.res += cuts[g];
-        const int r2 = run_job_group(rv, opt, cuts[g + 1] - cuts[g], dv, d_reads, d_read_off, d_read_len, 0, st);
+        const unsigned long long cnt = (unsigned long long)(cuts[g + 1] - cuts[g]);
+        MPN_HIP_CHECK(hipMemcpy(out.used + 4, &cnt, 8, hipMemcpyHostToDevice));
+        const int r2 = run_job_group(rv, opt, (int)cnt, out.used + 4, dv, d_reads, d_read_off, d_read_len, 0, st);
         if (r2) return r2 < 0 ? r2 : -1;
     }
+    out.n_jobs = nj;
     return 0;
 }
 
@@ -1134,48 +1156,45 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             for (int i = 0; i < n; ++i) sr_base[(size_t)i + 1] = sr_base[(size_t)i] + (int32_t)rs[i].pending.size();
             const int n_sr = sr_base[(size_t)n];
             if (n_sr == 0) { wt.stop_into(g_stats[20]); break; }
+            std::vector<int64_t> cap_t((size_t)std::max(1, n_threads), 0);
             if (SL.pin_pregs.ensure((size_t)n_sr * sizeof(PlanReg) + 64) || SL.pool_pregs.ensure((size_t)n_sr * sizeof(PlanReg) + 16) ||
-                SL.pool_psum.ensure((size_t)n_sr * sizeof(PlanSum) + 16) || SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) ||
-                SL.pool_njobs.ensure(((size_t)n_sr + 1) * 8 + 16) || SL.pool_joboff.ensure(((size_t)n_sr + 1) * 8 + 16))
+                SL.pool_psum.ensure((size_t)n_sr * sizeof(PlanSum) + 16) || SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pool_used.ensure(64))
                 return -1;
             PlanReg *h_pr = SL.pin_pregs.as<PlanReg>();
-            parallel_for(n, n_threads, [&](int i, int) {
+            parallel_for(n, n_threads, [&](int i, int slot) {
                 const ReadState &S = rs[i];
                 for (size_t pi = 0; pi < S.pending.size(); ++pi) {
                     const Reg &r = S.regs[(size_t)S.pending[pi]];
                     h_pr[(size_t)sr_base[(size_t)i] + pi] = PlanReg{h.b_off[(size_t)i], S.n_a, r.as, r.cnt, r.mlen, i, seq_len[i], (int32_t)r.split_inv, 0};
+                    cap_t[(size_t)slot % cap_t.size()] += r.cnt + 2;   // a hit of cnt anchors has at most cnt + 1 windows
                 }
             }, 3);
+            int64_t nj_cap64 = 0;
+            for (int64_t c : cap_t) nj_cap64 += c;
+            if (nj_cap64 > 0x7fffffff) { set_error("too many DP windows in one round"); return -1; }
+            const int nj_cap = (int)nj_cap64;
+            if (SL.pool_jobs.ensure((size_t)nj_cap * sizeof(ExtJob) + 16) || SL.pool_job_anchor.ensure((size_t)nj_cap * 4 + 16)) return -1;
             PlanReg *d_pr = SL.pool_pregs.as<PlanReg>();
             PlanSum *d_ps = SL.pool_psum.as<PlanSum>();
             StitchReg *d_sr = SL.pool_sregs.as<StitchReg>();
-            int64_t *d_nj = SL.pool_njobs.as<int64_t>(), *d_joff = SL.pool_joboff.as<int64_t>();
-            MPN_HIP_CHECK(hipMemcpyAsync(d_pr, h_pr, (size_t)n_sr * sizeof(PlanReg), hipMemcpyHostToDevice, st));
-            const int pg = std::max(1, std::min((n_sr + 63) / 64, 256 * 16));
-            hipLaunchKernelGGL(plan_kernel<false>, dim3(pg), dim3(64), 0, st, po, (const PlanReg *)d_pr, n_sr, d_a.p, (const int32_t *)idx->d_lens.p, d_nj,
-                               (const int64_t *)nullptr, (ExtJob *)nullptr, (int32_t *)nullptr, (StitchReg *)nullptr, (PlanSum *)nullptr);
-            hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)d_nj, d_joff, n_sr);
-            MPN_HIP_CHECK(hipGetLastError());
-            int64_t *h_nj = reinterpret_cast<int64_t *>(h_pr + n_sr);
-            MPN_HIP_CHECK(hipMemcpyAsync(h_nj, d_joff + n_sr, 8, hipMemcpyDeviceToHost, st));
-            MPN_HIP_CHECK(stream_sync(st));
-            const int64_t nj64 = *h_nj;
-            if (nj64 > 0x7fffffff) { set_error("too many DP windows in one round"); return -1; }
-            const int nj = (int)nj64;
-            if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob) + 16) || SL.pool_job_anchor.ensure((size_t)nj * 4 + 16)) return -1;
             ExtJob *d_jobs = SL.pool_jobs.as<ExtJob>();
             int32_t *d_janchor = SL.pool_job_anchor.as<int32_t>();
-            hipLaunchKernelGGL(plan_kernel<true>, dim3(pg), dim3(64), 0, st, po, (const PlanReg *)d_pr, n_sr, d_a.p, (const int32_t *)idx->d_lens.p, (int64_t *)nullptr,
-                               (const int64_t *)d_joff, d_jobs, d_janchor, d_sr, d_ps);
+            unsigned long long *d_used = SL.pool_used.as<unsigned long long>();
+            MPN_HIP_CHECK(hipMemsetAsync(d_used + 3, 0, 8, st));
+            MPN_HIP_CHECK(hipMemcpyAsync(d_pr, h_pr, (size_t)n_sr * sizeof(PlanReg), hipMemcpyHostToDevice, st));
+            EvTimer evp(st);
+            hipLaunchKernelGGL(plan_kernel, dim3((unsigned)std::min(n_sr, 256 * 4)), dim3(64), 0, st, po, (const PlanReg *)d_pr, n_sr, d_a.p,
+                               (const int32_t *)idx->d_lens.p, d_used + 3, d_jobs, d_janchor, d_sr, d_ps);
             MPN_HIP_CHECK(hipGetLastError());
+            evp.mark(55);
             wt.stop_into(g_stats[20]);
             ++g_stats[7];
             DevRound dv;
-            if (nj > 0 && run_jobs(rv, opt, nj, d_seqs.p, d_off.p, d_len.p, dv, st)) return -1;
-            if (nj == 0) {   // (hits without any window: the stitching kernel still sets their coordinates)
-                if (SL.pool_res.ensure(64) || SL.pool_used.ensure(32) || SL.pool_compact.ensure(64)) return -1;
-                dv.jobs = d_jobs; dv.res = SL.pool_res.as<ExtRes>(); dv.compact = SL.pool_compact.as<uint32_t>(); dv.used = SL.pool_used.as<unsigned long long>();
-                MPN_HIP_CHECK(hipMemsetAsync(dv.used, 0, 32, st));
+            if (run_jobs(rv, opt, nj_cap, d_seqs.p, d_off.p, d_len.p, dv, st)) return -1;
+            evp.resolve();
+            if (!dv.compact) {   // (a round without any window: the stitching kernel still sets the hits' coordinates)
+                if (SL.pool_compact.ensure(64)) return -1;
+                dv.compact = SL.pool_compact.as<uint32_t>();
             }
             wt.stop_into(g_stats[21]);
             const RoundDev rd{d_sr, d_pr, d_ps, d_janchor, d_a.p};
@@ -1672,6 +1691,11 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
     for (ExtJob &j : jobs) { j.strip_s = 1; j.cls = -1; }
     if (tl_slot->pool_jobs.ensure((size_t)n * sizeof(ExtJob) + 16)) return -1;
     MPN_HIP_CHECK(hipMemcpy(tl_slot->pool_jobs.p, jobs.data(), (size_t)n * sizeof(ExtJob), hipMemcpyHostToDevice));
+    {
+        const unsigned long long cnt = (unsigned long long)n;
+        if (tl_slot->pool_used.ensure(64)) return -1;
+        MPN_HIP_CHECK(hipMemcpy(tl_slot->pool_used.as<unsigned long long>() + 3, &cnt, 8, hipMemcpyHostToDevice));
+    }
     const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, n, d_reads.p, d_qoff.p, d_qlen.p, dv, st);
     g_force_kernel = 0;
     if (rc) return rc;

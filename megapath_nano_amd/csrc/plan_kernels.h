@@ -24,9 +24,20 @@ __device__ __forceinline__ int32_t pk_x(const u128 &v) { return (int32_t)v.x; }
 __device__ __forceinline__ int32_t pk_y(const u128 &v) { return (int32_t)v.y; }
 __device__ __forceinline__ int32_t pk_span(const u128 &v) { return (int32_t)(v.y >> 32 & 0xff); }
 
+// The read's anchors as the planning walks see them: the hit's own anchors [lo, hi) are staged in LDS by the wave (a walk is a
+// chain of dependent loads: ~30 ns each from LDS, ~1 us from HBM), the few neighbours outside come from global memory.  Flags
+// are written to both copies (the global one carries them to the next round).
+struct AnchorView {
+    u128 *g;          // the read's anchors in global memory
+    u128 *l;          // LDS copy of [lo, hi)
+    int lo, hi;
+    __device__ __forceinline__ u128 operator[](int i) const { return (i >= lo && i < hi) ? l[i - lo] : g[i]; }
+    __device__ __forceinline__ void or_y(int i, uint64_t f) { g[i].y |= f; if (i >= lo && i < hi) l[i - lo].y |= f; }
+};
+
 // mm_filter_bad_seeds without its index array: K = the anchors whose gap to their predecessor exceeds min_gap is walked as a
 // virtual sequence (an entry is found by scanning forward), K-indices and anchor indices are tracked side by side
-__device__ inline void pk_filter_bad_seeds(int as1, int cnt1, u128 *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+__device__ inline void pk_filter_bad_seeds(int as1, int cnt1, AnchorView &a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
     auto gap_at = [&](int i) { return (pk_y(a[as1 + i]) - pk_y(a[as1 + i - 1])) - (pk_x(a[as1 + i]) - pk_x(a[as1 + i - 1])); };
     auto is_k = [&](int i) { const int g = gap_at(i); return g < -min_gap || g > min_gap; };
     auto next_k = [&](int i) { for (++i; i < cnt1; ++i) if (is_k(i)) return i; return cnt1; };   // anchor index of the next K entry (cnt1: none)
@@ -37,7 +48,7 @@ __device__ inline void pk_filter_bad_seeds(int as1, int cnt1, u128 *a, int min_g
     for (int k = 0;; ++k) {
         const bool at_end = ik >= cnt1;
         if (at_end || k >= max_en_k) {
-            if (max_en_k > 0) for (int i = max_st_i; i < max_en_i; ++i) a[as1 + i].y |= PK_SEED_IGNORE;
+            if (max_en_k > 0) for (int i = max_st_i; i < max_en_i; ++i) a.or_y(as1 + i, PK_SEED_IGNORE);
             max = 0; max_st_k = max_en_k = -1;
             if (at_end) break;
         }
@@ -63,7 +74,7 @@ __device__ inline void pk_filter_bad_seeds(int as1, int cnt1, u128 *a, int min_g
 // The planning half of mm_align1 for one hit.  FILL = false counts the windows; FILL = true writes them (jobs, job_anchor) and
 // the hit's stitching record.  Both passes set the same SEED_IGNORE flags (the filter is idempotent).
 template <bool FILL>
-__device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, u128 *a, const int32_t *__restrict__ tlens, int32_t ri, int32_t first_job,
+__device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, AnchorView &a, const int32_t *__restrict__ tlens, int32_t ri, int32_t first_job,
                                ExtJob *__restrict__ jobs, int32_t *__restrict__ job_anchor, StitchReg *__restrict__ sregs, PlanSum *__restrict__ psum) {
     const int32_t rid = (int32_t)(a[pr.as].x << 1 >> 33), rev = (int32_t)(a[pr.as].x >> 63);
     const int32_t tlen_all = tlens[rid], kh = o.k >> 1, qlen = pr.qlen;
@@ -193,29 +204,27 @@ __device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, u128 *a, con
     return nj;
 }
 
-// one block: exclusive scan of n counts (out has n + 1 entries, the last one the total)
-__global__ __launch_bounds__(1024) void plan_scan_kernel(const int64_t *__restrict__ in, int64_t *__restrict__ out, int n) {
-    __shared__ long long part[1024];
-    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
-    long long s = 0;
-    for (int j = lo; j < hi; ++j) s += in[j];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) { long long acc = 0; for (int k = 0; k < 1024; ++k) { const long long v = part[k]; part[k] = acc; acc += v; } out[n] = acc; }
-    __syncthreads();
-    long long o = part[t];
-    for (int j = lo; j < hi; ++j) { const long long v = in[j]; out[j] = o; o += v; }
-}
-
-template <bool FILL>
+// One wave per hit: the 64 lanes stage the hit's anchors in LDS, lane 0 counts the hit's windows, reserves their slots in the
+// job array (one atomic per hit; the windows of a hit are contiguous, hits come in no particular order) and writes them.
+constexpr int PLAN_LDS_ANCHORS = 1024;   // 16 KB: the rest of a longer hit (reads beyond ~50 kb) is walked in global memory
 __global__ __launch_bounds__(64) void plan_kernel(PlanOpt o, const PlanReg *__restrict__ pregs, int n_regs, u128 *__restrict__ A,
-                                                  const int32_t *__restrict__ tlens, int64_t *__restrict__ n_jobs, const int64_t *__restrict__ job_off,
+                                                  const int32_t *__restrict__ tlens, unsigned long long *__restrict__ n_jobs_total,
                                                   ExtJob *__restrict__ jobs, int32_t *__restrict__ job_anchor, StitchReg *__restrict__ sregs,
                                                   PlanSum *__restrict__ psum) {
-    for (int ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_regs; ri += gridDim.x * blockDim.x) {
+    __shared__ u128 lds_a[PLAN_LDS_ANCHORS];
+    const int lane = threadIdx.x;
+    for (int ri = blockIdx.x; ri < n_regs; ri += gridDim.x) {
         const PlanReg pr = pregs[ri];
-        const int nj = plan_hit<FILL>(o, pr, A + pr.a_off, tlens, ri, FILL ? (int32_t)job_off[ri] : 0, jobs, job_anchor, sregs, psum);
-        if constexpr (!FILL) n_jobs[ri] = nj;
+        AnchorView av;
+        av.g = A + pr.a_off; av.l = lds_a; av.lo = pr.as; av.hi = pr.as + (pr.cnt < PLAN_LDS_ANCHORS ? pr.cnt : PLAN_LDS_ANCHORS);
+        for (int i = lane; i < av.hi - av.lo; i += 64) lds_a[i] = av.g[av.lo + i];
+        __syncthreads();
+        if (lane == 0) {
+            const int nj = plan_hit<false>(o, pr, av, tlens, ri, 0, jobs, job_anchor, sregs, psum);
+            const int32_t first = (int32_t)atomicAdd(n_jobs_total, (unsigned long long)nj);
+            plan_hit<true>(o, pr, av, tlens, ri, first, jobs, job_anchor, sregs, psum);
+        }
+        __syncthreads();
     }
 }
 
@@ -233,16 +242,24 @@ __host__ __device__ inline int bucket_of_list(int l) {       // first bucket of 
 struct LayoutTotals {          // read back by the host after job_layout_kernel
     long long p_tot, row_tot, cig_tot, state_tot, cells, strip_cells[3];
     int lds_need[5], strip_lds[3], band_lds[4];
-    int too_large, tl_q, tl_t, pad;
+    int too_large, tl_q, tl_t, n_jobs;
     int cnt[N_LISTS], base[N_LISTS + 1];   // launch lists in the flat order array (strip lists padded to whole waves)
 };
 
 struct JobSizes { long long p, row, cig, st; };   // scratch needs of a window (scanned into offsets)
 
-__global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ jobs, int nj, int strip_scores, int force_kernel,
-                                                           JobSizes *__restrict__ sizes, int32_t *__restrict__ bucket_cnt,
+__global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ jobs, const unsigned long long *__restrict__ nj_p, int strip_scores,
+                                                           int force_kernel, JobSizes *__restrict__ sizes, int32_t *__restrict__ bucket_cnt,
                                                            LayoutTotals *__restrict__ tot) {
+    const int nj = (int)*nj_p;   // (written by plan_kernel, or by the host for the stage test)
     const int lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
+    // counters and maxima are gathered per block in LDS and leave with one atomic per block and slot: a hundred thousand
+    // windows adding to ONE global address serialise at the memory side (DESIGN.md lesson 4)
+    __shared__ int s_bucket[N_BUCKETS];
+    __shared__ int s_max[12];   // lds_need[5] | strip_lds[3] | band_lds[4]
+    for (int k = threadIdx.x; k < N_BUCKETS; k += blockDim.x) s_bucket[k] = 0;
+    if (threadIdx.x < 12) s_max[threadIdx.x] = 0;
+    __syncthreads();
     long long cells = 0, scells[3] = {0, 0, 0};
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         ExtJob jb = jobs[j];
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         if (seqb > lds_cap[3] || !(force_kernel == 0 || force_kernel == 4 || force_kernel == 5)) bv = -1;
         int bc = 3;
         for (int c = 0; c < 4; ++c) if (seqb <= lds_cap[c]) { bc = c; break; }
-        if (bv >= 0) atomicMax(&tot->band_lds[bc], seqb);
+        if (bv >= 0) atomicMax(&s_max[8 + bc], seqb);
         jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
         const int strip_gl = 16 << max(glc, 0);
         jb.strip_s = max(1, min(16, (jb.tlen + strip_gl - 1) / strip_gl));   // strip height: the window's rows over its lane group
@@ -287,15 +304,15 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
         const int redo_list = bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls;
         int lid;
-        if (strip) { lid = L_STRIP + glc * 16 + jb.strip_s - 1; atomicMax(&tot->strip_lds[glc], (jb.qlen + 15) & ~15); }
+        if (strip) { lid = L_STRIP + glc * 16 + jb.strip_s - 1; atomicMax(&s_max[5 + glc], (jb.qlen + 15) & ~15); }
         else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
         else lid = redo_list;
         if (bv < 0) {   // the LDS-state kernels may run this window (now or in the second pass)
             if (cls == 4) {
                 if (seqb > lds_cap[3]) { tot->too_large = 1; tot->tl_q = jb.qlen; tot->tl_t = jb.tlen; }
                 jb.state_mode = 1; sz.st = (stateb + 15) & ~15;
-                atomicMax(&tot->lds_need[4], seqb);
-            } else atomicMax(&tot->lds_need[cls], seqb + stateb);
+                atomicMax(&s_max[4], seqb);
+            } else atomicMax(&s_max[cls], seqb + stateb);
             sz.row = n_r;   // band limits are stored only by the LDS-state kernels
         }
         sz.cig = jb.qlen + jb.tlen + 2;
@@ -305,8 +322,13 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         // bucket: a strip list is split by query length, longest first
         int b = bucket_of_list(lid);
         if (strip) b += STRIP_QB - 1 - min(STRIP_QB - 1, jb.qlen >> (4 + glc));
-        atomicAdd(&bucket_cnt[b], 1);
+        atomicAdd(&s_bucket[b], 1);
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N_BUCKETS; k += blockDim.x) if (s_bucket[k]) atomicAdd(&bucket_cnt[k], s_bucket[k]);
+    if (threadIdx.x < 5) { if (s_max[threadIdx.x]) atomicMax(&tot->lds_need[threadIdx.x], s_max[threadIdx.x]); }
+    else if (threadIdx.x < 8) { if (s_max[threadIdx.x]) atomicMax(&tot->strip_lds[threadIdx.x - 5], s_max[threadIdx.x]); }
+    else if (threadIdx.x < 12) { if (s_max[threadIdx.x]) atomicMax(&tot->band_lds[threadIdx.x - 8], s_max[threadIdx.x]); }
     // (per-block reduction of the cell counters, one atomic per block)
     __shared__ long long red[4];
     if (threadIdx.x < 4) red[threadIdx.x] = 0;
@@ -325,9 +347,13 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
 
 // one block: exclusive scans of the four scratch sizes (in place: sizes[j] becomes the window's offsets), of the bucket counts
 // (bucket_cur = first slot of every bucket in the flat order array, strip lists padded to whole waves) and the list table
-__global__ __launch_bounds__(1024) void job_scan_kernel(JobSizes *__restrict__ sizes, int nj, const int32_t *__restrict__ bucket_cnt,
-                                                        int32_t *__restrict__ bucket_cur, LayoutTotals *__restrict__ tot) {
+__global__ __launch_bounds__(1024) void job_scan_kernel(JobSizes *__restrict__ sizes, const unsigned long long *__restrict__ nj_p,
+                                                        const int32_t *__restrict__ bucket_cnt, int32_t *__restrict__ bucket_cur,
+                                                        LayoutTotals *__restrict__ tot) {
     __shared__ long long part[1024][4];
+    __shared__ int list_cnt[N_LISTS], list_base[N_LISTS + 1];
+    const int nj = (int)*nj_p;
+    if (threadIdx.x == 0) tot->n_jobs = nj;
     const int t = threadIdx.x, per = (nj + 1023) / 1024, lo = min(nj, t * per), hi = min(nj, lo + per);
     long long s[4] = {0, 0, 0, 0};
     for (int j = lo; j < hi; ++j) { s[0] += sizes[j].p; s[1] += sizes[j].row; s[2] += sizes[j].cig; s[3] += sizes[j].st; }
@@ -346,23 +372,37 @@ __global__ __launch_bounds__(1024) void job_scan_kernel(JobSizes *__restrict__ s
         sizes[j] = JobSizes{o[0], o[1], o[2] + z.cig, o[3]};
         o[0] += z.p; o[1] += z.row; o[2] += z.cig; o[3] += z.st;
     }
+    // launch lists: a thread per list adds up its buckets, thread 0 places the lists, then every list's thread places its buckets
+    if (t < N_LISTS) {
+        const int b0 = bucket_of_list(t), nb = (t >= L_STRIP && t < L_BAND) ? STRIP_QB : 1;
+        int c = 0;
+        for (int b = 0; b < nb; ++b) c += bucket_cnt[b0 + b];
+        list_cnt[t] = c;
+    }
+    __syncthreads();
     if (t == 0) {
         int pos = 0;
         for (int l = 0; l < N_LISTS; ++l) {
-            const int b0 = bucket_of_list(l), nb = (l >= L_STRIP && l < L_BAND) ? STRIP_QB : 1;
-            int c = 0;
-            tot->base[l] = pos;
-            for (int b = 0; b < nb; ++b) { bucket_cur[b0 + b] = pos + c; c += bucket_cnt[b0 + b]; }
-            tot->cnt[l] = c;
-            if (nb > 1) { const int pw = strip_windows_per_wave(l); c = (c + pw - 1) / pw * pw; }
+            int c = list_cnt[l];
+            list_base[l] = pos;
+            if (l >= L_STRIP && l < L_BAND) { const int pw = strip_windows_per_wave(l); c = (c + pw - 1) / pw * pw; }
             pos += c;
         }
-        tot->base[N_LISTS] = pos;
+        list_base[N_LISTS] = pos;
     }
+    __syncthreads();
+    if (t < N_LISTS) {
+        const int b0 = bucket_of_list(t), nb = (t >= L_STRIP && t < L_BAND) ? STRIP_QB : 1;
+        int pos = list_base[t];
+        for (int b = 0; b < nb; ++b) { bucket_cur[b0 + b] = pos; pos += bucket_cnt[b0 + b]; }
+        tot->cnt[t] = list_cnt[t]; tot->base[t] = list_base[t];
+    }
+    if (t == 0) tot->base[N_LISTS] = list_base[N_LISTS];
 }
 
-__global__ __launch_bounds__(256) void job_layout_kernel(ExtJob *__restrict__ jobs, int nj, const JobSizes *__restrict__ offs,
-                                                         int32_t *__restrict__ bucket_cur, int32_t *__restrict__ order) {
+__global__ __launch_bounds__(256) void job_layout_kernel(ExtJob *__restrict__ jobs, const unsigned long long *__restrict__ nj_p,
+                                                         const JobSizes *__restrict__ offs, int32_t *__restrict__ bucket_cur, int32_t *__restrict__ order) {
+    const int nj = (int)*nj_p;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         ExtJob &jb = jobs[j];
         if (jb.cls < 0) continue;
