@@ -338,6 +338,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
+    thr0 = None
+    if os.environ.get('MPN_DEBUG_THREADS'):
+        sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+        import thread_cpu
+        thr0 = thread_cpu.snapshot()
     stats_acc = {}
     counts = None
     sampled = np.zeros(n, dtype=np.int64)   # what this rank's generator sampled in the timed steps, per genome
@@ -355,6 +360,9 @@ def main():
     mdist.barrier()
     dt = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0
+    if thr0 is not None and rank == 0:
+        for name, (cnt, sec) in thread_cpu.diff(thr0, thread_cpu.snapshot())[:12]:
+            log(f'threads {name!r} x{cnt}: {sec / max(1, args.steps):.3f} CPU-s per step')
     for s in range(args.steps):
         sampled += np.bincount(batches[(args.warmup + s) % n_distinct].truth['genome'], minlength=n)
     host_cpu_max = host_cpu_s

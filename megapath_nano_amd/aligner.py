@@ -453,11 +453,12 @@ def Align(*, assembly_metadata, global_options, temp_dir_name, log_file, query_f
                                         read_batch_bases=batch_bases, cache_key=cache_key, on_header=sam_f.write,
                                         on_batch=lambda b: (paf_f.write(b.paf), sam_f.write(b.sam)))
         print('Finished species alignment step.')                                                        # aligner.py:244
-        from . import bam
+        from . import abundance, bam
         # samtools view -F<flags> -b | samtools sort; samtools index (aligner.py:245-252): 1796 = unmapped | secondary | QC fail |
         # duplicate; the amplicon filter keeps everything that is mapped
         exclude = 4 if module_option == 'amplicon_filter_module' else 1796
-        bam.sam_to_sorted_bam(f'{paf_path_and_prefix}.sam', f'{paf_path_and_prefix}.bam', exclude_flags=exclude)
+        bam.sam_to_sorted_bam(f'{paf_path_and_prefix}.sam', f'{paf_path_and_prefix}.bam', exclude_flags=exclude,
+                              sort_keys=abundance.device_sort_order)   # the coordinate sort runs on the GPU (mpn_sort_order)
         if module_option in ('taxon_and_AMR_module', 'AMR_module_only'):                                # aligner.py:250-256
             _run_amr(global_options, f'{paf_path_and_prefix}.bam', AMR_output_folder, log_file)
         if module_option in ('AMR_module_only', 'amplicon_filter_module'):                               # aligner.py:257-259

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <thread>
+#include <pthread.h>
 #include <time.h>
 #include <atomic>
 #include <functional>
@@ -434,6 +435,7 @@ class HostPool {
         return nullptr;
     }
     void worker() {
+        pthread_setname_np(pthread_self(), "mpn-pool");
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             int slot = 0;
@@ -1351,6 +1353,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     const auto t_call = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     auto worker = [&](int wid) {
+        pthread_setname_np(pthread_self(), "mpn-work");
         if (hipSetDevice(dev) != hipSuccess) { failed = 1; return; }
         Slot &S = g_slots[wid];
         if (!S.st && hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }

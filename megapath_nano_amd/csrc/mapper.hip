@@ -246,7 +246,8 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             (void)hipFuncSetAttribute((const void *)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLT_LDS_BYTES);
         });
         hipLaunchKernelGGL(seed_order_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)o.n_anchor.p, n, order.p);
-        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, 256))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
+        static const int flt_wgs = []() { const char *e = getenv("MPN_FLT_WGS"); return e ? std::max(1, atoi(e)) : 256; }();
+        hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, flt_wgs))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
                            pos_start.p, rel_off.p, idx->pos.p, (const int64_t *)full_off.p, (const int64_t *)blk_base.p, (const int32_t *)order.p,
                            fp, keep.p, blk_kept.p, blk_read.p, next_read.p);
         MPN_HIP_CHECK(hipGetLastError());

@@ -1,0 +1,25 @@
+"""debug: CPU seconds of this process's threads by name (Linux /proc), e.g. around bench.py's timed steps"""
+import os
+
+
+def snapshot():
+    out = {}
+    tck = os.sysconf('SC_CLK_TCK')
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            s = open(f'/proc/self/task/{tid}/stat').read()
+        except OSError:
+            continue
+        name = s[s.index('(') + 1:s.rindex(')')]
+        f = s[s.rindex(')') + 2:].split()
+        out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tck)
+    return out
+
+
+def diff(a, b):
+    agg = {}
+    for tid, (name, t) in b.items():
+        d = t - a.get(tid, (name, 0.0))[1]
+        n, tot = agg.get(name, (0, 0.0))
+        agg[name] = (n + 1, tot + d)
+    return sorted(agg.items(), key=lambda kv: -kv[1][1])

@@ -202,7 +202,9 @@ def test_abundance_statistic_against_plain_restatement():
     from megapath_nano_amd.abundance import align_stat_by_assembly_id, covered_bp_by_assembly
     t = pd.DataFrame({'assembly_id': ['A'] * 5 + ['B'] * 2, 'sequence_id': ['s1', 's1', 's1', 's2', 's1', 's1', 's1'],
                       'sequence_from': [0, 10, 20, 0, 100, 5, 5], 'sequence_to': [10, 20, 25, 7, 130, 9, 9]})
-    assert covered_bp_by_assembly(t) == {'A': 25 + 7 + 30, 'B': 4}
+    assert covered_bp_by_assembly(t, device=False) == {'A': 25 + 7 + 30, 'B': 4}
+    noise = pd.DataFrame({'sequence_id': ['s1', 's1', 's9'], 'start': [5, 110, 0], 'end': [12, 200, 50], 'assembly_id': ['A', 'A', 'Z']})
+    assert covered_bp_by_assembly(t, noise_bed=noise, device=False) == {'A': (25 - 7) + 7 + (30 - 20), 'B': 4 - 4}
     rng = np.random.default_rng(11)
     for trial in range(10):
         rows = []
@@ -217,7 +219,7 @@ def test_abundance_statistic_against_plain_restatement():
         al = pd.DataFrame(rows, columns=['read_id', 'read_length', 'assembly_id', 'sequence_id', 'sequence_from', 'sequence_to', 'match',
                                          'edit_dist', 'alignment_score', 'alignment_score_tiebreaker'])
         lens = pd.DataFrame({'assembly_id': ['A1', 'A2'], 'assembly_length': [4000, 0]})   # A3 unknown, A2 zero length
-        got = align_stat_by_assembly_id(al, lens).set_index('assembly_id')
+        got = align_stat_by_assembly_id(al, lens, device=False).set_index('assembly_id')
         best = {}
         for row in rows:
             key = (row[0], row[2])
