@@ -105,6 +105,112 @@ def make_batch(flat, weights, args, seed, device):
     return b
 
 
+def build_workload(args, device, rank, world):
+    """Targets and read batches of --config, generated in HBM and indexed from HBM.  -> dict (see main)."""
+    import torch
+    from megapath_nano_amd import mapper, synth
+    from megapath_nano_amd.pipeline import Taxonomy
+    cfg = args.config
+    W = dict(kind=None, cpu_genomes=None)
+    n_distinct = max(1, min(args.distinct_batches, args.warmup + args.steps))
+    if cfg == 'c2':
+        # configs[1]: 24 chromosomes x 129 Mbp = 3.1 Gbp, 45 % interspersed repeats, + 8 plasmid-like decoys; the reads: 70 % human-like,
+        # 5 % decoy, 25 % from 5 microbial genomes that are NOT in the index (they must come out as microbe reads)
+        n_chrom, chrom_len = (24, 129_000_000) if args.genomes == 0 else (args.genomes, args.genome_len)
+        names, flat, lens, kind = synth.make_humanlike_device(20240901, n_chrom, chrom_len, device)
+        mic_names, mic, mic_lens = synth.make_genomes_device(4242, 5, 4_000_000, 0, device)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        idx = mapper.Index.from_device(names, flat.data_ptr(), lens)
+        W['index_s'] = time.time() - t0
+        opt_kw = dict(best_n=5, pri_ratio=0.8)   # megapath_nano.py:1124: -x map-ont defaults
+        all_flat = torch.cat([flat, mic])
+        all_lens = np.concatenate([lens, mic_lens])
+        w = np.concatenate([0.70 * lens[kind == 0] / lens[kind == 0].sum(), 0.05 * lens[kind == 1] / lens[kind == 1].sum(), np.full(5, 0.05)])
+        batches = []
+        for s_ in range(n_distinct):
+            buf, off, ln, truth = synth.make_reads_from_targets_device(1000 * (rank + 1) + s_, all_flat, all_lens, args.reads_per_step, w, device,
+                                                                       mean_len=args.mean_len)
+            torch.cuda.synchronize()
+            b = mapper.PackedReads.from_arrays([f'read{r:07d}' for r in range(args.reads_per_step)], buf.cpu().numpy(), off.cpu().numpy(),
+                                               ln.cpu().numpy(), dev=(buf, off, ln))
+            b.truth = truth
+            batches.append(b)
+        n = len(names)
+        W.update(idx=idx, tax=None, kind=np.concatenate([kind, np.full(5, 2, dtype=np.int32)]), n=n, members=list(range(n)),
+                 twin_of=np.full(n + 5, -1, dtype=np.int64), index_bp=int(lens.sum()), n_index_genomes=n,
+                 workload=f'configs[1] (100k ONT reads vs human+decoy, decoy-filter alignment stage) at a synthetic human-like genome of {n_chrom} x {chrom_len} '
+                          f'bp = {n_chrom * chrom_len / 1e9:.2f} Gbp with 45% interspersed repeat families + 8 plasmid-like decoys; reads: 70% human-like, 5% decoy, '
+                          f'25% from 5 microbial genomes outside the index; {args.reads_per_step} reads/step, -x map-ont -c (-N 5 -p 0.8), human/decoy '
+                          f'classification (megapath_nano.py:1135-1200) inside the step')
+        del flat, mic, all_flat
+    else:
+        n = args.genomes
+        families = (10, 100, 0.97, 0.999) if cfg == 'strain' else None
+        strain_pairs = 0 if families else args.strain_pairs
+        if families:
+            members = list(range(10))
+            weights = np.zeros(n)
+            weights[members] = np.random.default_rng(7).lognormal(0.0, 1.0, size=10)
+            twin_of = np.full(n, -1, dtype=np.int64)
+            twin_of[n - 1000:] = np.repeat(np.arange(10), 100)
+        else:
+            members, weights = community(n, strain_pairs)
+            twin_of = np.full(n, -1, dtype=np.int64)       # strain copy -> the genome it was copied from
+            twin_of[n - strain_pairs:] = np.arange(strain_pairs)
+        names, flat, lens = synth.make_genomes_device(20240901, n, args.genome_len, strain_pairs, device, families=families)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if cfg == 'parts':
+            # two index parts, both resident (288 GB of HBM hold what a CPU host must stream through -I): the hits of the parts
+            # are merged per read like minimap2 --split-prefix merges its dumps
+            h = n // 2
+            idx = [mapper.Index.from_device(names[:h], flat.data_ptr(), lens[:h]),
+                   mapper.Index.from_device(names[h:], flat.data_ptr() + h * args.genome_len, lens[h:])]
+        else:
+            idx = mapper.Index.from_device(names, flat.data_ptr(), lens)
+        W['index_s'] = time.time() - t0
+        opt_kw = dict(best_n=50, pri_ratio=1.0)  # megapath_nano.py:1270  -N 50 -p 1 -x map-ont
+        batches = [make_batch(flat, weights, args, 1000 * (rank + 1) + s_, device) for s_ in range(n_distinct)]
+        # host copies of the genomes the CPU baseline indexes (the community + fillers), then the ASCII targets leave HBM
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and cfg == 'c3':
+            want = max(len(members), min(n, args.cpu_index_genomes))
+            ms = set(members)
+            pick = sorted(members + [g for g in range(n) if g not in ms][:want - len(members)])
+            view = flat.view(n, args.genome_len)
+            W['cpu_genomes'] = [(names[g], view[g].cpu().numpy()) for g in pick]
+        del flat
+        what = {'c3': f'incl. {strain_pairs} 99%-identity strain copies', 'big': f'incl. {strain_pairs} 99%-identity strain copies (the largest one-piece index)',
+                'parts': f'incl. {strain_pairs} 99%-identity strain copies, held as TWO resident index parts whose hits are merged per read (mpn_hits, minimap2 --split-prefix)',
+                'strain': 'of which 1000 are 100 assemblies of each of the 10 community species at 97-99.9% identity (strain-rich)'}[cfg]
+        W.update(idx=idx, tax=Taxonomy(np.arange(n, dtype=np.int32), n, np.arange(n, dtype=np.int32), n), n=n, members=members, twin_of=twin_of,
+                 index_bp=n * args.genome_len, n_index_genomes=n,
+                 workload=f'configs[2] (1M-read 10-species community vs full RefSeq bacterial, reassignment on) at N_g = {n} synthetic genomes x '
+                          f'{args.genome_len} bp = {n * args.genome_len / 1e9:.1f} Gbp of targets {what}, resident on every GPU; '
+                          f'{args.reads_per_step} synthetic ONT-like reads/step/GPU (Gamma lengths, mean {args.mean_len} bp, 12% errors; in-repo stand-in '
+                          f'for badread, generated on the GPU; {n_distinct} distinct batches rotated over the steps), -N 50 -p 1 -x map-ont -c')
+    torch.cuda.empty_cache()
+    idx0 = W['idx'][0] if isinstance(W['idx'], (list, tuple)) else W['idx']
+    opt = mapper.default_opt(**opt_kw)
+    if not isinstance(W['idx'], (list, tuple)):
+        opt.mid_occ = idx0.mid_occ()      # (index parts: every part applies its own -f cut-off, like minimap2)
+    W.update(opt=opt, opt_kw=opt_kw, batches=batches)
+    if rank == 0:
+        log(f'index built in {W["index_s"]:.1f} s: {sum(i.n_minimizers for i in (W["idx"] if isinstance(W["idx"], (list, tuple)) else [W["idx"]]))} minimizers')
+    return W
+
+
+def human_decoy_step(idx, opt, b, kind, rnd, use_device):
+    """configs[1]'s step: map against human+decoy, then the human / decoy / microbe classification on integer columns."""
+    from megapath_nano_amd import mapper
+    from megapath_nano_amd.filters import classify_codes
+    from megapath_nano_amd.pipeline import random_block
+    _, c = mapper.map_batch_ex(idx, opt, b, want_paf=False, want_cols=True, use_device=use_device)
+    tb = random_block(rnd, len(c['read_idx']))
+    cls = classify_codes(c['read_idx'], kind[c['rid']], c['as_'], tb, b.lens, b.n)
+    return dict(read_count=np.bincount(cls, minlength=3).astype(np.int64), classes=cls, n_rows=len(tb))
+
+
 def cpu_baseline(genomes, packed, opt_kw, seconds_target=15.0):
     """Oracle (port of the minimap2 path) on a bounded sample of the step batch, all host cores up to the CPU quota, against
     an index of >= 1 Gbp (so that the port, too, meets stray seed hits and the -f cut-off)."""
@@ -144,7 +250,7 @@ def cpu_baseline(genomes, packed, opt_kw, seconds_target=15.0):
 
 class TargetSlices:
     """name -> sequence view for tests/paf_check.py over targets that live only in HBM: len() from the index, slices fetched
-    through mpn_index_fetch_seq (the 2-bit targets decoded on the device)."""
+    through mpn_index_fetch_seq (the 2-bit targets decoded on the device).  Takes one index or a list of index parts."""
 
     class _Seq:
         def __init__(self, idx, i):
@@ -159,14 +265,74 @@ class TargetSlices:
             return self.idx.fetch_seq(self.i, lo, max(0, hi - lo)).decode()
 
     def __init__(self, idx):
-        self.idx = idx
-        self.by_name = {n: i for i, n in enumerate(idx.names)}
+        self.by_name = {}
+        for part in (idx if isinstance(idx, (list, tuple)) else [idx]):
+            for i, n in enumerate(part.names):
+                self.by_name[n] = (part, i)
 
     def __contains__(self, name):
         return name in self.by_name
 
     def __getitem__(self, name):
-        return TargetSlices._Seq(self.idx, self.by_name[name])
+        return TargetSlices._Seq(*self.by_name[name])
+
+
+def map_text_and_cols(idx, opt, sub):
+    """PAF text + columns of a batch against one index or against index parts (merged like --split-prefix)"""
+    from megapath_nano_amd import mapper
+    if isinstance(idx, (list, tuple)):
+        h = mapper.Hits(sub)
+        try:
+            for part in idx:
+                h.add_part(part, opt, use_device=False)
+            paf, _, c = h.finish(opt, want_paf=True, want_cols=True)
+        finally:
+            h.close()
+        return paf, c
+    return mapper.map_batch_ex(idx, opt, sub, want_paf=True, want_cols=True, use_device=False)
+
+
+def sub_batch(batch, n):
+    from megapath_nano_amd import mapper
+    end = int(batch.off[n - 1] + batch.lens[n - 1])
+    return mapper.PackedReads.from_arrays(batch.names[:n], np.concatenate([batch.buf[:end], np.full(16, ord('A'), dtype=np.uint8)]),
+                                          batch.off[:n], batch.lens[:n])
+
+
+def c2_correctness(idx, opt, batch, kind, rnd, n_check=16384, n_paf_reads=1024):
+    """configs[1]: the class of every read against the target it was sampled from (reads >= 2 kb: at 12 % errors their alignment
+    score clears the reference's thresholds, AS >= 1000 or AS >= read length), and the independent PAF checker."""
+    from megapath_nano_amd.filters import classify_codes
+    from megapath_nano_amd.pipeline import random_block
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import paf_check
+    out = {'ok': True, 'failures': []}
+    n = min(n_check, batch.n)
+    sub = sub_batch(batch, n)
+    paf, c = map_text_and_cols(idx, opt, sub)
+    cls = classify_codes(c['read_idx'], kind[c['rid']], c['as_'], random_block(rnd, len(c['read_idx'])), sub.lens, n)
+    want = np.array([1, 2, 0], dtype=np.int8)[kind[batch.truth['genome'][:n]]]     # human target -> 1, decoy -> 2, microbe (not indexed) -> 0
+    longr = sub.lens >= 2000
+    for name, code in (('human', 1), ('decoy', 2), ('microbe', 0)):
+        m = longr & (want == code)
+        frac = float((cls[m] == code).mean()) if m.any() else 1.0
+        out[f'{name}_reads_ge_2kb'] = int(m.sum())
+        out[f'{name}_classified_frac'] = round(frac, 5)
+        if frac < 0.97:
+            out['ok'] = False
+            out['failures'].append(f'fewer than 97 % of the {name} reads >= 2 kb were classified {name}')
+    names_m = set(batch.names[:min(n_paf_reads, n)])
+    text = ''.join(l for l in paf.splitlines(keepends=True) if l.split('\t', 1)[0] in names_m)
+    reads = {batch.names[i]: bytes(batch.seq(i)).decode() for i in range(min(n_paf_reads, n))}
+    st = {}
+    try:
+        paf_check.check_paf(text, reads, TargetSlices(idx), best_n=opt.best_n, stats=st, fast=True)
+        out['paf_check'] = dict(lines=st.get('lines', 0), primaries=st.get('primaries', 0), as_equals_cigar_score=st.get('as_equal', 0))
+    except AssertionError as e:
+        out['ok'] = False
+        out['paf_check'] = dict(error=str(e)[:300])
+        out['failures'].append('paf_check failed: ' + str(e)[:200])
+    return out
 
 
 def correctness_block(idx, opt, batch, args, members, twin_of, counts, sampled, n_check=16384, n_paf_reads=2048):
@@ -182,11 +348,9 @@ def correctness_block(idx, opt, batch, args, members, twin_of, counts, sampled, 
             out['failures'].append(what)
 
     n = min(n_check, batch.n)
-    end = int(batch.off[n - 1] + batch.lens[n - 1])
-    sub = mapper.PackedReads.from_arrays(batch.names[:n], np.concatenate([batch.buf[:end], np.full(16, ord('A'), dtype=np.uint8)]),
-                                         batch.off[:n], batch.lens[:n])
+    sub = sub_batch(batch, n)
     t0 = time.time()
-    paf, c = mapper.map_batch_ex(idx, opt, sub, want_paf=True, want_cols=True, use_device=False)
+    paf, c = map_text_and_cols(idx, opt, sub)
     map_s = time.time() - t0
     # (1) truth: the first line of a read is its primary; it must lie on the genome the read was sampled from (or on that
     # genome's 99 % strain twin, which is an equally good locus) and overlap the sampled interval, for reads >= 1 kb
@@ -251,10 +415,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--genomes', type=int, default=5000)
+    ap.add_argument('--config', default='c3', choices=['c3', 'strain', 'big', 'parts', 'c2'],
+                    help='c3 = BASELINE configs[2] (the headline); strain = the same with 100 assemblies of every community species in the '
+                         'index; big = the largest one-piece index (36 Gbp); parts = the 20 Gbp target set as two index parts merged like '
+                         'minimap2 --split-prefix; c2 = BASELINE configs[1] (100k reads vs a repeat-rich human-like genome + decoys, -N 5 -p 0.8, '
+                         'human/decoy classification)')
+    ap.add_argument('--genomes', type=int, default=None)
     ap.add_argument('--genome-len', type=int, default=4000000)
     ap.add_argument('--strain-pairs', type=int, default=10)
-    ap.add_argument('--reads-per-step', type=int, default=262144)
+    ap.add_argument('--reads-per-step', type=int, default=None)
     ap.add_argument('--mean-len', type=int, default=8000)
     ap.add_argument('--distinct-batches', type=int, default=3)
     ap.add_argument('--pcie-steps', type=int, default=10, help='extra steps fed from host buffers (PCIe-inclusive rate, never `value`)')
@@ -262,6 +431,11 @@ def main():
     ap.add_argument('--no-correctness', action='store_true')
     ap.add_argument('--cpu-index-genomes', type=int, default=250, help='genomes of the CPU baseline\'s index (250 x 4 Mbp = 1 Gbp)')
     args = ap.parse_args()
+    cfg_defaults = {'c3': (5000, 262144), 'strain': (5000, 16384), 'big': (9000, 262144), 'parts': (5000, 262144), 'c2': (0, 100000)}
+    if args.genomes is None:
+        args.genomes = cfg_defaults[args.config][0]
+    if args.reads_per_step is None:
+        args.reads_per_step = cfg_defaults[args.config][1]
 
     env_world = os.environ.get('WORLD_SIZE')
     if args.gpus > 1 and env_world is None:
@@ -291,36 +465,11 @@ def main():
     if rank == 0:
         log(f'torch + libmpn ready; generating {args.genomes} x {args.genome_len} bp on the GPU')
 
-    # ---- targets: generated in HBM, indexed from HBM ------------------------------------------------------------
-    n = args.genomes
-    members, weights = community(n, args.strain_pairs)
-    twin_of = np.full(n, -1, dtype=np.int64)       # strain copy -> the genome it was copied from
-    twin_of[n - args.strain_pairs:] = np.arange(args.strain_pairs)
-    names, flat, lens = synth.make_genomes_device(20240901, n, args.genome_len, args.strain_pairs, device)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    idx = mapper.Index.from_device(names, flat.data_ptr(), lens)
-    index_s = time.time() - t0
-    if rank == 0:
-        log(f'index built in {index_s:.1f} s: {idx.n_minimizers} minimizers, {idx.n_keys} keys')
-    tax = Taxonomy(np.arange(n, dtype=np.int32), n, np.arange(n, dtype=np.int32), n)  # every genome its own name / species
-    opt_kw = dict(best_n=50, pri_ratio=1.0)  # megapath_nano.py:1270  -N 50 -p 1 -x map-ont
-    opt = mapper.default_opt(**opt_kw)
-    opt.mid_occ = idx.mid_occ()
-
-    # ---- reads: a few distinct batches, generated in HBM, rotated over the steps ---------------------------------
-    n_distinct = max(1, min(args.distinct_batches, args.warmup + args.steps))
-    batches = [make_batch(flat, weights, args, 1000 * (rank + 1) + s, device) for s in range(n_distinct)]
-    # host copies of the genomes the CPU baseline indexes (the community + fillers), then the ASCII targets leave HBM
-    cpu_genomes = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        want = max(len(members), min(n, args.cpu_index_genomes))
-        ms = set(members)
-        pick = sorted(members + [g for g in range(n) if g not in ms][:want - len(members)])
-        view = flat.view(n, args.genome_len)
-        cpu_genomes = [(names[g], view[g].cpu().numpy()) for g in pick]
-    del flat
-    torch.cuda.empty_cache()
+    # ---- targets + reads of the chosen workload: generated in HBM, indexed from HBM ----------------------------------------
+    W = build_workload(args, device, rank, world)
+    idx, tax, opt, opt_kw, batches, members, twin_of, n = W['idx'], W['tax'], W['opt'], W['opt_kw'], W['batches'], W['members'], W['twin_of'], W['n']
+    index_s, n_distinct, cpu_genomes = W['index_s'], len(W['batches']), W['cpu_genomes']
+    idx0 = idx[0] if isinstance(idx, (list, tuple)) else idx
     if rank == 0:
         log(f'{n_distinct} read batches of {args.reads_per_step} reads ready ({batches[0].bases} bp each); mid_occ = {opt.mid_occ}')
 
@@ -328,6 +477,8 @@ def main():
     rnd = random.Random(12345)  # the same stream on every rank: tiebreakers are drawn in global row order (pipeline.sharded_tiebreak)
 
     def run(b, use_device=True):
+        if args.config == 'c2':
+            return human_decoy_step(idx, opt, b, W['kind'], rnd, use_device)
         return align_and_assign(idx, opt, b, tax, allreduce=allreduce, rng=rnd, shard=(rank, world), use_device=use_device)
 
     for s in range(args.warmup):
@@ -363,8 +514,9 @@ def main():
     if thr0 is not None and rank == 0:
         for name, (cnt, sec) in thread_cpu.diff(thr0, thread_cpu.snapshot())[:12]:
             log(f'threads {name!r} x{cnt}: {sec / max(1, args.steps):.3f} CPU-s per step')
-    for s in range(args.steps):
-        sampled += np.bincount(batches[(args.warmup + s) % n_distinct].truth['genome'], minlength=n)
+    if args.config != 'c2':
+        for s in range(args.steps):
+            sampled += np.bincount(batches[(args.warmup + s) % n_distinct].truth['genome'], minlength=n)
     host_cpu_max = host_cpu_s
     if world > 1:
         import torch.distributed as dist
@@ -375,7 +527,8 @@ def main():
         bt = torch.tensor([bases], dtype=torch.int64, device=rd)
         dist.all_reduce(bt, op=dist.ReduceOp.SUM)
         bases = int(bt.item())
-        allreduce(sampled)   # counts are already global (align_and_assign all-reduces them)
+        if args.config != 'c2':
+            allreduce(sampled)   # counts are already global (align_and_assign all-reduces them)
     # PCIe-inclusive rate (never `value`): the same steps fed from the host buffers, read H2D inside the timed call
     pcie = None
     if args.pcie_steps > 0:
@@ -459,13 +612,10 @@ def main():
         'dtype': 'int32',
         'data': 'synthetic',
         'config': {
-            'workload': f'configs[2] (1M-read 10-species community vs full RefSeq bacterial, reassignment on) at N_g = {args.genomes} synthetic genomes x '
-                        f'{args.genome_len} bp = {args.genomes * args.genome_len / 1e9:.1f} Gbp of targets incl. {args.strain_pairs} 99%-identity strain '
-                        f'copies, resident on every GPU (built on the GPU in {index_s:.1f} s); {args.reads_per_step} synthetic ONT-like reads/step/GPU '
-                        f'(Gamma lengths, mean {args.mean_len} bp, 12% errors; in-repo stand-in for badread, generated on the GPU; {n_distinct} distinct '
-                        f'batches rotated over the steps), -N 50 -p 1 -x map-ont -c',
-            'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': args.genomes, 'index_bp': args.genomes * args.genome_len,
-            'index_build_s': round(index_s, 2), 'index_minimizers': int(idx.n_minimizers), 'mid_occ': int(opt.mid_occ),
+            'workload': W['workload'] + f' (index built on the GPU in {index_s:.1f} s)', 'name': args.config,
+            'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': W['n_index_genomes'], 'index_bp': W['index_bp'],
+            'index_build_s': round(index_s, 2), 'mid_occ': int(opt.mid_occ),
+            'index_minimizers': int(sum(i.n_minimizers for i in (idx if isinstance(idx, (list, tuple)) else [idx]))),
             'parallelism': f'reads sharded over {world} GPU(s), index replicated', 'host_cpus': os.cpu_count(), 'cpu_quota': cpu_quota(),
             'ranks_on_node': int(os.environ.get('MPN_RANKS_ON_NODE', '1')),
         },
@@ -491,11 +641,17 @@ def main():
         'per_step': {k: (round(v / 1e6, 2) if k.endswith('_ns') else int(v)) for k, v in st.items()},
         'reads_per_name_top': sorted(((int(c), int(i)) for i, c in enumerate(counts) if c), reverse=True)[:5],
     }
-    if not args.no_correctness:
+    if args.config == 'c2':
+        line['reads_per_class'] = dict(zip(('microbe', 'human', 'decoy'), (int(x) for x in counts)))
+        line.pop('reads_per_name_top', None)
+        if not args.no_correctness:
+            line['correctness'] = c2_correctness(idx, opt, batches[0], W['kind'], rnd)
+            log(f'correctness: ok={line["correctness"]["ok"]} {line["correctness"]["failures"]}')
+    elif not args.no_correctness:
         log('checking the output of this run (truth hit rate, paf_check, counts)')
         line['correctness'] = correctness_block(idx, opt, batches[0], args, members, twin_of, counts, sampled)
         log(f'correctness: ok={line["correctness"]["ok"]} {line["correctness"]["failures"]}')
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and cpu_genomes is not None:
         log('timing the CPU oracle on a sample')
         line['cpu_baseline'] = cpu_baseline(cpu_genomes, batches[0], opt_kw)
     print(json.dumps(line), flush=True)

@@ -1342,6 +1342,8 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     rep_len.assign((size_t)n, 0);
     std::atomic<int> next(0), failed(0);
     std::mutex mu;
+    std::deque<int> retry;          // sub-batches given back by a worker that ran out of device memory (guarded by mu)
+    int live_workers = n_workers, live_workers_busy = 0;   // (guarded by mu)
     int64_t tot_stats[MPN_NSTATS] = {0};
     std::string err;
     const bool dbg_workers = getenv("MPN_DEBUG_WORKERS") != nullptr;
@@ -1362,13 +1364,45 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         tl_worker_id = wid;
         memset(g_stats, 0, sizeof(g_stats));
         for (;;) {
-            const int sb = next.fetch_add(1);
-            if (sb >= n_sub || failed) break;
+            int sb = -1;
+            { std::lock_guard<std::mutex> g(mu); if (!retry.empty()) { sb = retry.front(); retry.pop_front(); } }
+            if (sb < 0) sb = next.fetch_add(1);
+            if (sb >= n_sub || failed) {
+                // (a sub-batch may still come back from a worker that is shedding: wait for those before leaving)
+                std::unique_lock<std::mutex> lk(mu);
+                if (failed || (retry.empty() && live_workers_busy == 0)) break;
+                lk.unlock();
+                timespec ts{0, 200000};
+                nanosleep(&ts, nullptr);
+                continue;
+            }
+            { std::lock_guard<std::mutex> g(mu); ++live_workers_busy; }
+            struct Busy { std::mutex &m; int &c; ~Busy() { std::lock_guard<std::mutex> g(m); --c; } } busy_{mu, live_workers_busy};
             S.arena.reset();
+            int64_t stats_before[MPN_NSTATS];
+            memcpy(stats_before, g_stats, sizeof(stats_before));
             const double t_in = since();
             struct Out { bool on; int wid, sb; double t_in; decltype(since) &f; ~Out() { if (on) fprintf(stderr, "[worker %d] sub-batch %d: %.1f -> %.1f ms\n", wid, sb, t_in, f()); } } out_{dbg_workers, wid, sb, t_in, since};
             if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1], n_threads, S.st, rs, rep_len)) {
                 std::lock_guard<std::mutex> g(mu);
+                // Out of device memory: the workers' scratch grows with what the target set throws at them (a strain-rich index
+                // yields tens of times the anchors of a random one), and the up-front estimate can be too low.  This worker gives
+                // its memory back and leaves; its sub-batch goes to the others.  The last worker standing reports the failure.
+                if (strstr(get_error(), "out of memory") && live_workers > 1) {
+                    --live_workers;
+                    memcpy(g_stats, stats_before, sizeof(stats_before));
+                    (void)hipGetLastError();
+                    (void)hipStreamSynchronize(S.st);
+                    for (auto &c : S.arena.chunks) (void)hipFree(c.p);
+                    S.arena.chunks.clear(); S.arena.cur = S.arena.off = S.arena.used = 0;
+                    for (PoolBuf *pb : {&S.pool_jobs, &S.pool_P, &S.pool_P2, &S.pool_OFF, &S.pool_order, &S.pool_state, &S.pool_CIG, &S.pool_res, &S.pool_redo,
+                                        &S.pool_compact, &S.pool_redo_ids, &S.pool_sregs, &S.pool_souts, &S.pool_fin_jobs, &S.pool_fin_out, &S.pool_fin_cig,
+                                        &S.pool_sizes, &S.pool_pregs, &S.pool_psum, &S.pool_job_anchor, &S.pin_anchors})
+                        pb->release();
+                    retry.push_back(sb);
+                    if (dbg_workers) fprintf(stderr, "[worker %d] out of device memory at sub-batch %d: leaving, %d workers go on\n", wid, sb, live_workers);
+                    break;
+                }
                 err = get_error();
                 failed = 1;
                 break;

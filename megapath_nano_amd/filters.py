@@ -75,3 +75,24 @@ def human_and_decoy_classify(align_list, human_assembly_list, decoy_assembly_lis
     return dict(human_best_align_list=align_list.iloc[human_rows], human_read_id_list=id_table(human_rows),
                 decoy_best_align_list=align_list.iloc[decoy_rows], decoy_read_id_list=id_table(decoy_rows),
                 microbe_best_align_list=align_list.iloc[microbe_rows], microbe_read_id_list=reads[keep][['read_id', 'read_length']])
+
+
+def classify_codes(read_idx, kind, score, tiebreak, read_length, n_reads, human_min_alignment_score=1000,
+                   human_min_alignment_score_percent=100, decoy_min_alignment_score=1000, decoy_min_alignment_score_percent=100):
+    """The same rules on integer columns only (what bench.py --config c2 times after the mapping call): read_idx[row] in
+    [0, n_reads), kind[row] = 0 human target / 1 decoy target / anything else other, read_length[read].
+    -> int8[n_reads]: 0 microbe (aligned or not), 1 human, 2 decoy."""
+    read_idx = np.asarray(read_idx)
+    score, tiebreak, kind = np.asarray(score), np.asarray(tiebreak), np.asarray(kind)
+    row_len = np.asarray(read_length)[read_idx]
+    out = np.zeros(n_reads, dtype=np.int8)
+
+    def caught(mask, min_score, min_percent):
+        best = _best_rows(read_idx, score, tiebreak, mask)
+        best = best[_passes(score[best], row_len[best], min_score, min_percent)]
+        return read_idx[best]
+
+    out[caught(kind == 0, human_min_alignment_score, human_min_alignment_score_percent)] = 1
+    remaining = out[read_idx] == 0
+    out[caught((kind == 1) & remaining, decoy_min_alignment_score, decoy_min_alignment_score_percent)] = 2
+    return out

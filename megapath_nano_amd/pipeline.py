@@ -57,7 +57,18 @@ def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_thre
                      allreduce=None, rng=None, reassign=True, shard=(0, 1), use_device=True):
     """One step of the hot path for one batch of reads.  Returns dict(read_count, aligned_bp, n_rows, n_relations).
     With shard=(rank, world) and an all-reduce, `rng` must be seeded identically on every rank (see sharded_tiebreak)."""
-    _, c = mapper.map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=use_device)
+    if isinstance(idx, (list, tuple)):
+        # a target set held as several index parts (minimap2 -I): every part is mapped, the hits are merged per read like
+        # minimap2 --split-prefix merges them (mapper.Hits); column `rid` indexes the concatenated target list
+        hits = mapper.Hits(packed)
+        try:
+            for part in idx:
+                hits.add_part(part, opt, use_device=use_device)
+            _, _, c = hits.finish(opt, want_paf=False, want_cols=True)
+        finally:
+            hits.close()
+    else:
+        _, c = mapper.map_batch_ex(idx, opt, packed, want_paf=False, want_cols=True, use_device=use_device)
     keep = c['as_'] >= min_alignment_score                                   # aligner.py:311-312
     read_idx = c['read_idx'][keep]
     rid = c['rid'][keep]

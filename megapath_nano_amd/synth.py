@@ -103,12 +103,17 @@ def make_reads(seed, genomes, n_reads, mean_len=8000, min_len=200, max_len=None,
 
 # ---- the same generators on the GPU (torch): bench.py's workload is tens of Gbp of targets and ~1 Gbp of reads per batch,
 # which numpy cannot produce inside the bench's time budget.  Same distributions as above (not the same random streams).
-def make_genomes_device(seed, n_genomes, length, strain_pairs, device, repeats=True, chunk=64):
-    """-> (names, uint8 tensor [n_genomes * length] of concatenated ASCII on `device`, int32 lens)."""
+def make_genomes_device(seed, n_genomes, length, strain_pairs, device, repeats=True, chunk=64, families=None):
+    """-> (names, uint8 tensor [n_genomes * length] of concatenated ASCII on `device`, int32 lens).
+    families = (n_fam, copies, id_lo, id_hi): a strain-RICH target set -- the last n_fam * copies genomes (strain_pairs must be
+    0) are `copies` assemblies of each of the genomes 0 .. n_fam-1, every copy mutated on its own at an identity drawn
+    uniformly from [id_lo, id_hi] (RefSeq holds hundreds of near-identical assemblies of the common species)."""
     import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
-    n_base = n_genomes - strain_pairs
+    n_fam_copies = families[0] * families[1] if families else 0
+    assert not (families and strain_pairs), 'families replace the strain pairs'
+    n_base = n_genomes - strain_pairs - n_fam_copies
     out = torch.empty(n_genomes * length, dtype=torch.uint8, device=device)
     alpha = torch.tensor(list(b'ACGT'), dtype=torch.uint8, device=device)
     view = out.view(n_genomes, length)
@@ -134,7 +139,132 @@ def make_genomes_device(seed, n_genomes, length, strain_pairs, device, repeats=T
         g[pos] = alpha[(cur + torch.randint(1, 4, (n_mut,), generator=gen, device=device)) % 4]
         view[n_base + i] = g
     names = [f'NZ_SYN{i:05d}.1' for i in range(n_base)] + [f'NZ_STR{i:05d}.1' for i in range(strain_pairs)]
+    if families:
+        n_fam, copies, lo, hi = families
+        for f in range(n_fam):
+            base = view[f]
+            cur = (base == alpha[1]).long() + 2 * (base == alpha[2]).long() + 3 * (base == alpha[3]).long()
+            for c in range(copies):
+                ident = lo + (hi - lo) * float(torch.rand(1, generator=gen, device=device))
+                mut = torch.rand(length, generator=gen, device=device) < (1.0 - ident)
+                shift = torch.randint(1, 4, (length,), generator=gen, device=device)
+                view[n_base + f * copies + c] = torch.where(mut, alpha[(cur + shift) % 4], base)
+                names.append(f'NZ_FAM{f:02d}_{c:03d}.1')
     return names, out, np.full(n_genomes, length, dtype=np.int32)
+
+
+def make_humanlike_device(seed, n_chrom, chrom_len, device, repeat_frac=0.45, n_decoys=8):
+    """configs[1]'s target set: a repeat-rich "human-like" genome -- n_chrom chromosomes of random sequence in
+    which `repeat_frac` of the bases are diverged copies of a few interspersed repeat families (a short high-copy family and
+    longer low-copy ones, 5-20 % divergence per copy) -- followed by n_decoys plasmid-like decoys of 50-200 kb.
+    -> (names, uint8 tensor of the concatenated ASCII, int32 lens, kind) with kind[i] = 0 human-like, 1 decoy."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    alpha = torch.tensor(list(b'ACGT'), dtype=torch.uint8, device=device)
+    fams = [(300, 0.5), (1200, 0.2), (3000, 0.15), (6000, 0.15)]            # (length, share of the repeat bases)
+    cons = [torch.randint(0, 4, (L,), generator=gen, device=device) for L, _ in fams]
+    dec_lens = [int(x) for x in torch.randint(50000, 200001, (n_decoys,), generator=gen, device=device).cpu()]
+    lens = [chrom_len] * n_chrom + dec_lens
+    out = torch.empty(sum(lens), dtype=torch.uint8, device=device)
+    off = 0
+    for c in range(n_chrom):
+        code = torch.randint(0, 4, (chrom_len,), generator=gen, device=device)
+        for (L, share), con in zip(fams, cons):
+            n_copies = int(repeat_frac * share * chrom_len / L)
+            for k0 in range(0, n_copies, 20000):                             # bounded temporaries
+                k1 = min(n_copies, k0 + 20000)
+                div = torch.rand(k1 - k0, 1, generator=gen, device=device) * 0.15 + 0.05
+                copy = con.unsqueeze(0).expand(k1 - k0, L)
+                mut = torch.rand(k1 - k0, L, generator=gen, device=device) < div
+                copy = torch.where(mut, (copy + torch.randint(1, 4, (k1 - k0, L), generator=gen, device=device)) % 4, copy)
+                start = torch.randint(0, chrom_len - L, (k1 - k0, 1), generator=gen, device=device)
+                code.scatter_(0, (start + torch.arange(L, device=device)).reshape(-1), copy.reshape(-1))
+        out[off:off + chrom_len] = alpha[code]
+        off += chrom_len
+        del code
+    for L in dec_lens:
+        out[off:off + L] = alpha[torch.randint(0, 4, (L,), generator=gen, device=device)]
+        off += L
+    names = [f'chrH{c + 1:02d}' for c in range(n_chrom)] + [f'decoy{d:02d}' for d in range(n_decoys)]
+    kind = np.array([0] * n_chrom + [1] * n_decoys, dtype=np.int32)
+    return names, out, np.array(lens, dtype=np.int32), kind
+
+
+def make_reads_from_targets_device(seed, flat, lens, n_reads, weights, device, **kw):
+    """Like make_reads_device for targets of unequal lengths: reads are sampled from target t with probability weights[t] at a
+    uniform start (the sampled length is clipped to the target).  -> (buf, offsets, lengths, truth)."""
+    import torch
+    lens = np.asarray(lens, dtype=np.int64)
+    offs = np.zeros(len(lens), dtype=np.int64)
+    offs[1:] = np.cumsum(lens[:-1])
+    # reuse the equal-length sampler on a virtual genome length: sample target and start here, then gather per read
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    mean_len, min_len = kw.get('mean_len', 8000), kw.get('min_len', 200)
+    torch.manual_seed(int(seed) * 2654435761 % (1 << 31) + 17)
+    gamma = torch.distributions.Gamma(torch.tensor(1.6, device=device), torch.tensor(1.6 / mean_len, device=device))
+    L = gamma.sample((n_reads,)).clamp_(min=min_len).long()
+    w = torch.as_tensor(np.asarray(weights, dtype=np.float64) / float(np.sum(weights)), device=device, dtype=torch.float32)
+    ti = torch.multinomial(w, n_reads, replacement=True, generator=gen)
+    tl = torch.as_tensor(lens, device=device)[ti]
+    L = torch.minimum(L, tl)
+    start = (torch.rand(n_reads, generator=gen, device=device, dtype=torch.float64) * (tl - L + 1).double()).long()
+    g0 = torch.as_tensor(offs, device=device)[ti] + start
+    return _reads_from_spans(gen, flat, g0, L, n_reads, device, dict(genome=ti, start=start, end=start + L), **kw)
+
+
+def _reads_from_spans(gen, genomes_flat, g0_all, L, n_reads, device, truth_t, sub=0.04, ins=0.03, dele=0.05, chunk_reads=8192, **_):
+    """ONT-like errors on the spans [g0, g0 + L) of the concatenated targets (strand chosen here)."""
+    import torch
+    rev = torch.rand(n_reads, generator=gen, device=device) < 0.5
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b'ACGT', b'TGCA'):
+        comp[a] = b
+    alpha = torch.tensor(list(b'ACGT'), dtype=torch.uint8, device=device)
+    code_of = torch.zeros(256, dtype=torch.long, device=device)
+    for k, a in enumerate(b'ACGT'):
+        code_of[a] = k
+    pieces, out_lens = [], []
+    for r0 in range(0, n_reads, chunk_reads):
+        r1 = min(n_reads, r0 + chunk_reads)
+        Lc = L[r0:r1]
+        off = torch.cumsum(Lc, 0) - Lc
+        T = int(Lc.sum())
+        rid = torch.repeat_interleave(torch.arange(r1 - r0, device=device), Lc)
+        p = torch.arange(T, device=device) - off[rid]
+        g0 = g0_all[r0:r1]
+        rv = rev[r0:r1][rid]
+        src = torch.where(rv, (g0 + Lc - 1)[rid] - p, g0[rid] + p)
+        frag = genomes_flat[src]
+        frag = torch.where(rv, comp[frag.long()], frag)
+        del src, p
+        r = torch.rand(T, generator=gen, device=device)
+        keep = r >= dele
+        subm = keep & (r < dele + sub)
+        n_sub = int(subm.sum())
+        frag[subm] = alpha[(code_of[frag[subm].long()] + torch.randint(1, 4, (n_sub,), generator=gen, device=device)) % 4]
+        n_ins = torch.where(torch.rand(T, generator=gen, device=device) < ins,
+                            torch.empty(T, device=device).geometric_(0.6, generator=gen).long(), torch.zeros((), dtype=torch.long, device=device))
+        counts = keep.long() + torch.where(keep, n_ins, torch.zeros((), dtype=torch.long, device=device))
+        out = torch.repeat_interleave(frag, counts)
+        cstart = torch.cumsum(counts, 0) - counts
+        first = torch.zeros(out.numel(), dtype=torch.bool, device=device)
+        first[cstart[counts > 0]] = True
+        n_insd = int((~first).sum())
+        out[~first] = alpha[torch.randint(0, 4, (n_insd,), generator=gen, device=device)]
+        csum = torch.cumsum(counts, 0)
+        tot_at_end = csum[off + Lc - 1]
+        new_len = tot_at_end - torch.cat([torch.zeros(1, dtype=torch.long, device=device), tot_at_end[:-1]])
+        pieces.append(out)
+        out_lens.append(new_len)
+        del rid, rv, frag, r, keep, subm, n_ins, counts, cstart, first, csum
+    lens_o = torch.cat(out_lens)
+    buf = torch.cat(pieces + [torch.full((16,), ord('A'), dtype=torch.uint8, device=device)])
+    offs_o = torch.cumsum(lens_o, 0) - lens_o
+    truth = {k: v.cpu().numpy() for k, v in truth_t.items()}
+    truth['rev'] = rev.cpu().numpy()
+    return buf, offs_o.contiguous(), lens_o.to(torch.int32).contiguous(), truth
 
 
 def make_reads_device(seed, genomes_flat, genome_len, n_reads, weights, device, mean_len=8000, min_len=200,

@@ -279,3 +279,31 @@ def test_bench_refuses_more_ranks_than_gpus():
     env['WORLD_SIZE'] = '4'
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and 'WORLD_SIZE=4' in out.stderr
+
+
+def test_classify_codes_equals_the_dataframe_classification():
+    """filters.classify_codes (integer columns, bench.py --config c2) against filters.human_and_decoy_classify (the mirror of
+    megapath_nano.py:1135-1200) on random tables."""
+    import pandas as pd
+    from megapath_nano_amd.filters import classify_codes, human_and_decoy_classify
+    rng = np.random.default_rng(21)
+    for trial in range(8):
+        n_reads = int(rng.integers(5, 200))
+        lens = rng.integers(300, 9000, size=n_reads)
+        rows = []
+        for r in range(n_reads):
+            for _ in range(int(rng.integers(0, 4))):
+                rows.append((r, int(rng.integers(0, 3)), int(rng.integers(100, 3000)), float(rng.random())))
+        if not rows:
+            continue
+        ri, kind, sc, tb = (np.array(x) for x in zip(*rows))
+        got = classify_codes(ri, kind, sc, tb, lens, n_reads)
+        al = pd.DataFrame({'read_id': [f'r{r:04d}' for r in ri], 'read_length': lens[ri], 'assembly_id': [['H', 'D', 'M'][k] for k in kind],
+                           'alignment_score': sc, 'alignment_score_tiebreaker': tb})
+        out = human_and_decoy_classify(al, pd.DataFrame({'assembly_id': ['H']}), pd.DataFrame({'assembly_id': ['D']}),
+                                       pd.DataFrame({'read_id': [f'r{r:04d}' for r in range(n_reads)], 'read_length': lens}))
+        want = np.zeros(n_reads, dtype=np.int8)
+        want[[int(x[1:]) for x in out['human_read_id_list']['read_id']]] = 1
+        want[[int(x[1:]) for x in out['decoy_read_id_list']['read_id']]] = 2
+        assert np.array_equal(got, want), trial
+        assert len(out['microbe_read_id_list']) == int((want == 0).sum())
