@@ -697,10 +697,10 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     int out_v = 0, out_x = 0, qsh = 24;
     int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
     const s16x2 MQA = {(short)(-8 * qe + 3), (short)(-8 * qe2 + 1)}, MQB = {(short)(-8 * qe + 2), (short)(-8 * qe2)};
-    const s16x2 Qp = {(short)(8 * q), (short)(8 * q2)}, ZERO = {0, 0};
+    const s16x2 EP = {(short)(8 * e), (short)(8 * e2)}, ZERO = {0, 0};   // x(t, j+1) = max(0, a - (z - q)) with a = (x + v) - (q + e): the state is kept as x + (q + e)
     const uint32_t EIGHT = 0x00080008u;
     const uint32_t RANK_CLR = 0xfff8fff8u;
-    const int mch8 = 8 * prm.sc_mch;
+    const s16x2 MCH7 = {(short)(8 * prm.sc_mch + 7), (short)(8 * prm.sc_mch + 7)};
     const bool head = gl == 0;
     for (int step = 0; step < max_steps; ++step) {
         // query bases and bottom-row states move one lane to the right; the first lane of a group takes the boundary
@@ -718,15 +718,22 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
             for (int k = 0; k < S; ++k) {
                 const int sc8 = __builtin_amdgcn_sbfe((int)TB[k], qsh, 6) * 8 + 4;
                 const s16x2 Up = UL[k];
-                s16x2 A = Xp + Vp + MQA, B = YL[k] + Up + MQB;   // 8 (a | a2) + (3 | 1), 8 (b | b2) + (2 | 0)
+                // clean sums first (multiples of 8), the rank-tagged candidates from them: the new gap states are taken from the
+                // clean sums, so no rank bits have to be masked out of them
+                const s16x2 Ac = Xp + Vp, Bc = YL[k] + Up;
+                s16x2 A = Ac + MQA, B = Bc + MQB;                // 8 (a | a2) + (3 | 1), 8 (b | b2) + (2 | 0)
                 const s16x2 M = __builtin_elementwise_max(A, B);
-                const int z8 = max(max((int)M.x, (int)M.y), sc8);
-                int d = z8 & 7;            // rank of the winner; the traceback reads the operand index as 4 - rank
-                // both halves = min(z, match score), rank bits cleared: one byte permute + one mask
-                const s16x2 Zp = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)min(z8, mch8 + 7), 0u, 0x05040504u) & RANK_CLR);
-                const s16x2 nu = Zp - Vp, nv = Zp - Up, ZQ = Zp - Qp;
-                A = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, __builtin_elementwise_max(A - ZQ, ZERO)) & RANK_CLR);
-                B = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, __builtin_elementwise_max(B - ZQ, ZERO)) & RANK_CLR);
+                // max of M's two halves and the score in ONE instruction: 16-bit three-operand max with the high half of M
+                // selected as its second operand (the result is the low 16 bits; everything after it reads those only)
+                uint32_t z16;
+                asm("v_max3_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(z16) : "v"(__builtin_bit_cast(uint32_t, M)), "v"(sc8));
+                const int d = (int)(z16 & 7);            // rank of the winner; the traceback reads the operand index as 4 - rank
+                // both halves = min(z, match score), rank bits cleared: one byte permute, one packed min, one mask
+                const s16x2 Zp = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, __builtin_elementwise_min(
+                                     __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(z16, 0u, 0x05040504u)), MCH7)) & RANK_CLR);
+                const s16x2 nu = Zp - Vp, nv = Zp - Up, ZE = Zp + EP;
+                A = __builtin_elementwise_max(Ac - ZE, ZERO);
+                B = __builtin_elementwise_max(Bc - ZE, ZERO);
                 // Continuation flags (x > 0) of the four gap states, which are multiples of 8: min(x, 8) as unsigned leaves bit 3
                 // of each half (written as the instruction: the compiler turns the expression into compares and selects).
                 // F: bit 3 a, 4 b, 19 a2, 20 b2; the byte is rank | F | F >> 14 -- its bits above 7 are dropped by the byte
