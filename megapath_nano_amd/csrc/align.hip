@@ -690,22 +690,22 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     Slot &SL = *tl_slot;
     const int strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi) ? 1 : 0;
     const size_t order_cap = (size_t)nj + (size_t)N_STRIP * 4 + 16;
-    if (SL.pool_sizes.ensure((size_t)nj * sizeof(JobSizes) + 16) || SL.pool_buckets.ensure((size_t)2 * N_BUCKETS * 4 + 16) ||
-        SL.pool_tot.ensure(sizeof(LayoutTotals) + 16) || SL.pool_order.ensure(order_cap * 4) || SL.pin_res.ensure(sizeof(LayoutTotals) + 64) ||
+    if (SL.pool_sizes.ensure((size_t)nj * sizeof(JobSizes) + 16) || SL.pool_buckets.ensure((size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals) + 16) ||
+        SL.pool_order.ensure(order_cap * 4) || SL.pin_res.ensure(sizeof(LayoutTotals) + 64) ||
         SL.pool_redo_ids.ensure((size_t)nj * 4 + 16))
         return -1;
     struct { ExtJob *p; } d_jobs{dv.jobs};
     JobSizes *d_sizes = SL.pool_sizes.as<JobSizes>();
     int32_t *d_bcnt = SL.pool_buckets.as<int32_t>(), *d_bcur = d_bcnt + N_BUCKETS;
-    LayoutTotals *d_tot = SL.pool_tot.as<LayoutTotals>();
+    LayoutTotals *d_tot = reinterpret_cast<LayoutTotals *>(d_bcnt + 2 * N_BUCKETS);
     struct { int32_t *p; } d_order{SL.pool_order.as<int32_t>()};
-    MPN_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)2 * N_BUCKETS * 4, st));
-    MPN_HIP_CHECK(hipMemsetAsync(d_tot, 0, sizeof(LayoutTotals), st));
-    MPN_HIP_CHECK(hipMemsetAsync(d_order.p, 0xff, order_cap * 4, st));   // -1: the padding of the strip lists
+    // (bucket counters and the totals block are neighbours in one pool: one fill clears both; the padding of the strip lists
+    // is written by the scan kernel)
+    MPN_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals), st));
     const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256));   // (a block per CU: every block flushes its counters once)
     EvTimer evl(st);
     hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, g_force_kernel, d_sizes, d_bcnt, d_tot);
-    hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, d_nj, (const int32_t *)d_bcnt, d_bcur, d_tot);
+    hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, d_nj, (const int32_t *)d_bcnt, d_bcur, d_tot, d_order.p);
     hipLaunchKernelGGL(job_layout_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, (const JobSizes *)d_sizes, d_bcur, d_order.p);
     MPN_HIP_CHECK(hipGetLastError());
     LayoutTotals *h_tot = SL.pin_res.as<LayoutTotals>();

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
 // (bucket_cur = first slot of every bucket in the flat order array, strip lists padded to whole waves) and the list table
 __global__ __launch_bounds__(1024) void job_scan_kernel(JobSizes *__restrict__ sizes, const unsigned long long *__restrict__ nj_p,
                                                         const int32_t *__restrict__ bucket_cnt, int32_t *__restrict__ bucket_cur,
-                                                        LayoutTotals *__restrict__ tot) {
+                                                        LayoutTotals *__restrict__ tot, int32_t *__restrict__ order) {
     __shared__ long long part[1024][4];
     __shared__ int list_cnt[N_LISTS], list_base[N_LISTS + 1];
     const int nj = (int)*nj_p;
@@ -396,6 +396,8 @@ __global__ __launch_bounds__(1024) void job_scan_kernel(JobSizes *__restrict__ s
         int pos = list_base[t];
         for (int b = 0; b < nb; ++b) { bucket_cur[b0 + b] = pos; pos += bucket_cnt[b0 + b]; }
         tot->cnt[t] = list_cnt[t]; tot->base[t] = list_base[t];
+        // the padding of a strip list up to whole waves: entries of -1 (the scatter fills the slots before them)
+        for (int k = list_base[t] + list_cnt[t]; k < list_base[t + 1]; ++k) order[k] = -1;
     }
     if (t == 0) tot->base[N_LISTS] = list_base[N_LISTS];
 }
