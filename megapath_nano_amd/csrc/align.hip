@@ -13,6 +13,7 @@
 #include "plan_kernels.h"
 #include "mapper_internal.h"
 #include "../../include/mpn_map.h"
+#include "../../include/mpn_ssw.h"
 
 #include <algorithm>
 #include <condition_variable>
@@ -52,6 +53,7 @@ struct Reg {
     int32_t has_p = 0, dp_score = 0, dp_max = 0, dp_max2 = 0, n_ambi = 0;
     std::vector<uint32_t> cigar;
     int32_t aligned = 0;  // base-level extension already done (or not needed)
+    int32_t fin_qs = 0, fin_rs = 0, fin_ql = 0, fin_tl = 0;   // an inversion hit before its extension: the window to extend
     int32_t fin_idx = -1;  // >= 0: stitched this round (its index among the round's hits): CIGAR fix-up and statistics are due
 };
 
@@ -377,6 +379,7 @@ static bool apply_stitch(int qlen, Reg &r, Reg &r2, const u128 *a, const StitchO
         const int old_cnt = r.cnt;
         split_reg(r, r2, so.split_n, qlen, a);
         has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
+        if (so.split_inv) r2.split_inv = 1;
     }
     r.rs = so.rs1; r.re = so.re1;
     if (r.rev) { r.qs = qlen - so.qe1; r.qe = qlen - so.qs1; }
@@ -636,7 +639,7 @@ struct Slot {
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
-    PoolBuf pool_sizes, pool_buckets, pool_tot, pool_pregs, pool_psum, pool_njobs, pool_joboff, pool_job_anchor;
+    PoolBuf pool_probes, pool_sizes, pool_buckets, pool_tot, pool_pregs, pool_psum, pool_njobs, pool_joboff, pool_job_anchor;
     PoolBuf pin_anchors{nullptr, 0, true}, pin_pregs{nullptr, 0, true};
     PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
@@ -655,14 +658,65 @@ static void parallel_chunks(int64_t n, int n_threads, const std::function<void(i
 
 // the second pass of a gap fill whose CIGAR failed the z-drop test: exact maximum, band (or anti-diagonal) layout
 __global__ void ext_redo_patch_kernel(ExtJob *jobs, const int32_t *ids, const int32_t *layout, const int32_t *qstride,
-                                      const int64_t *p_off, int n) {
+                                      const int64_t *p_off, const int32_t *inv, int zdrop_inv, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     ExtJob &jb = jobs[ids[k]];
     jb.flag &= ~EZ_APPROX_MAX;
+    if (inv[k]) { jb.flag |= EZ_INV; jb.zdrop = zdrop_inv; }   // (mm_align1: second pass with zdrop_inv when mm_test_zdrop returned 2)
     jb.layout = layout[k];
     jb.qstride = qstride[k];
     jb.p_off = p_off[k];
+}
+
+// 0..4 codes of a target interval / of a read interval on a strand, for the rare host-side steps (inversion probes)
+__global__ void ref_codes_kernel(RefView rv, int64_t g0, int n, int8_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int8_t)ref_code(rv, g0 + i);
+}
+static int fetch_ref_codes(const RefView &rv, int64_t seq_off_rid, int start, int n, int8_t *out, hipStream_t st) {
+    if (n <= 0) return 0;
+    DevBuf<int8_t> d;
+    if (d.alloc((size_t)n)) return -1;
+    hipLaunchKernelGGL(ref_codes_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rv, seq_off_rid + start, n, d.p);
+    MPN_HIP_CHECK(hipGetLastError());
+    MPN_HIP_CHECK(hipMemcpyAsync(out, d.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(stream_sync(st));
+    return 0;
+}
+static inline int8_t host_code(char c) { c |= 0x20; return c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4; }
+// base x of read `seq` (length rlen) on strand rev, as a 0..4 code
+static inline int8_t host_qbase(const char *seq, int rlen, int rev, int x) {
+    if (!rev) return host_code(seq[x]);
+    const int8_t c = host_code(seq[rlen - 1 - x]);
+    return c < 4 ? (int8_t)(3 - c) : (int8_t)4;
+}
+// local alignment scores (ksw_ll_i16 of minimap2's inversion code) of a few pairs on the GPU: the SSW kernels of this
+// library compute the same recurrences with the same tie rules for the end (first reference column with a strictly larger
+// column maximum, smallest read index in it); a gap of length L costs q + L * e = SSW's (q + e) + (L - 1) * e
+struct LocalHit { int score, qe, te; };
+static int local_scores(const mpn_map_opt *opt, const std::vector<std::vector<int8_t>> &qs, const std::vector<std::vector<int8_t>> &ts, std::vector<LocalHit> &out) {
+    const int n = (int)qs.size();
+    out.assign((size_t)n, LocalHit{0, -1, -1});
+    if (n == 0) return 0;
+    std::vector<int8_t> qb, tb;
+    std::vector<int64_t> qo(n), to(n), coff(n);
+    std::vector<int32_t> ql(n), tl(n), mask(n, 15), rb(n), re(n), qb1(n), qe1(n), re2(n), clen(n), status(n);
+    std::vector<uint16_t> s1(n), s2(n);
+    for (int i = 0; i < n; ++i) {
+        qo[i] = (int64_t)qb.size(); ql[i] = (int32_t)qs[i].size(); qb.insert(qb.end(), qs[i].begin(), qs[i].end());
+        to[i] = (int64_t)tb.size(); tl[i] = (int32_t)ts[i].size(); tb.insert(tb.end(), ts[i].begin(), ts[i].end());
+    }
+    int8_t mat[25];
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (int8_t)(i == j ? opt->a : -opt->b); mat[i * 5 + 4] = (int8_t)-opt->sc_ambi; }
+    for (int i = 0; i < 5; ++i) mat[20 + i] = (int8_t)-opt->sc_ambi;
+    uint32_t dummy_cig[4];
+    const int rc = mpn_ssw_align_batch(n, qb.data(), qo.data(), ql.data(), tb.data(), to.data(), tl.data(), mat, 5, 2, (uint8_t)(opt->q + opt->e), (uint8_t)opt->e,
+                                       0, 0, 0, mask.data(), s1.data(), s2.data(), rb.data(), re.data(), qb1.data(), qe1.data(), re2.data(), dummy_cig, 4,
+                                       coff.data(), clen.data(), status.data());
+    if (rc) return -1;
+    for (int i = 0; i < n; ++i) if (status[i] == 0) out[(size_t)i] = LocalHit{(int)s1[i], qe1[i], re[i]};
+    return 0;
 }
 
 // Device-resident state of a round's DP windows: the job records, one result record per window, and the pool of compacted
@@ -681,8 +735,12 @@ struct DevRound {
 // them): kernel choice, direction-matrix layout and launch lists are made on the device (plan_kernels.h) and a block of counters
 // comes back; then the DP kernels, the traceback, the z-drop test and the rare exact second pass.  budget > 0: returns 1
 // without launching any DP if the direction matrices need more than that (the caller then cuts the range).
+// host views the rare host-side steps need (inversion probes): the sub-batch's reads and the targets' offsets; null for the
+// stage test, which then skips the probes
+struct HostSeqs { const char *seqs; const int64_t *seq_off; const int32_t *seq_len; const int64_t *tseq_off; };
+
 static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, const unsigned long long *d_nj, DevRound &dv, const uint8_t *d_reads,
-                         const int64_t *d_read_off, const int32_t *d_read_len, int64_t budget, hipStream_t st) {
+                         const int64_t *d_read_off, const int32_t *d_read_len, int64_t budget, const HostSeqs *hs, hipStream_t st) {
     // nj_cap: an upper bound of the number of windows (the count itself is on the device, *d_nj: the planning kernel wrote it)
     if (nj_cap == 0) return 0;
     int nj = nj_cap;
@@ -692,7 +750,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     const size_t order_cap = (size_t)nj + (size_t)N_STRIP * 4 + 16;
     if (SL.pool_sizes.ensure((size_t)nj * sizeof(JobSizes) + 16) || SL.pool_buckets.ensure((size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals) + 16) ||
         SL.pool_order.ensure(order_cap * 4) || SL.pin_res.ensure(sizeof(LayoutTotals) + 64) ||
-        SL.pool_redo_ids.ensure((size_t)nj * 4 + 16))
+        SL.pool_redo_ids.ensure((size_t)nj * 4 + 16) || SL.pool_probes.ensure((size_t)nj * sizeof(InvProbe) + 16))
         return -1;
     struct { ExtJob *p; } d_jobs{dv.jobs};
     JobSizes *d_sizes = SL.pool_sizes.as<JobSizes>();
@@ -745,10 +803,13 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     uint32_t *d_compact = dv.compact;
     unsigned long long *d_used = dv.used;   // [0] operations in the compact pool (the whole round), [1] windows listed for the second pass (this group)
     int32_t *d_redo_ids = SL.pool_redo_ids.as<int32_t>();
+    InvProbe *d_probes = SL.pool_probes.as<InvProbe>();
     MPN_HIP_CHECK(hipMemsetAsync(d_used + 1, 0, 8, st));
+    MPN_HIP_CHECK(hipMemsetAsync(d_used + 5, 0, 8, st));
     ExtParams prm;
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
+    prm.zdrop_inv = opt->zdrop_inv; prm.max_gap = opt->max_gap;
     // one launch of launch list `l` over ord[0..n)
     auto launch_list = [&](int l, const int32_t *ord, int n, hipStream_t s) -> int {
         if (n == 0) return 0;
@@ -817,7 +878,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
         for (int k = 0; k < 2; ++k) {
             const int n = hi[k] - lo[k];
             if (n > 0) hipLaunchKernelGGL(ext_ztest_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, prm, d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p,
-                                          d_redo_ids, d_used + 1);
+                                          d_redo_ids, d_used + 1, d_probes, d_used + 5);
         }
         MPN_HIP_CHECK(hipGetLastError());
         if (timed) ev.mark(26);
@@ -839,63 +900,96 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     if (bt_ztest(main_lo, main_hi, st, true)) return -1;
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
     unsigned long long *h_used = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(SL.pin_res.p) + ((sizeof(LayoutTotals) + 15) & ~(size_t)15));
-    MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 16, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 48, hipMemcpyDeviceToHost, st));
     wt.stop_into(g_stats[28]);
     MPN_HIP_CHECK(stream_sync(st));
     wt.stop_into(g_stats[29]);
-    // second pass: the windows whose CIGAR failed the z-drop test were listed by the test kernel (in no particular order)
+    // second pass: the windows whose CIGAR failed the z-drop test were listed by the test kernel (in no particular order), and
+    // the windows whose largest drop may hide an inversion (mm_test_zdrop's probe: rare; decided here)
     std::vector<int32_t> redo((size_t)h_used[1]);
-    g_stats[8] += (int64_t)redo.size();
-    if (!redo.empty()) {
-        const int nr = (int)redo.size();
+    const int n_probe = (int)h_used[5];
+    if (!redo.empty() || n_probe) {
         // (rare: the job records of the group come to the host for it)
         std::vector<ExtJob> jobs((size_t)nj);
+        std::vector<InvProbe> probes((size_t)n_probe);
         if (SL.pin_order.ensure(redo.size() * 4 + 16)) return -1;
-        MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_order.p, d_redo_ids, redo.size() * 4, hipMemcpyDeviceToHost, st));
+        if (!redo.empty()) MPN_HIP_CHECK(hipMemcpyAsync(SL.pin_order.p, d_redo_ids, redo.size() * 4, hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(hipMemcpyAsync(jobs.data(), d_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyDeviceToHost, st));
+        if (n_probe) MPN_HIP_CHECK(hipMemcpyAsync(probes.data(), d_probes, (size_t)n_probe * sizeof(InvProbe), hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(stream_sync(st));
-        memcpy(redo.data(), SL.pin_order.p, redo.size() * 4);
+        if (!redo.empty()) memcpy(redo.data(), SL.pin_order.p, redo.size() * 4);
+        std::vector<uint8_t> is_inv((size_t)nj, 0);
+        if (n_probe) {
+            std::sort(probes.begin(), probes.end(), [](const InvProbe &x, const InvProbe &y) { return x.jid < y.jid; });
+            std::vector<LocalHit> hits((size_t)n_probe, LocalHit{0, -1, -1});
+            if (hs) {
+                // the drop's query region on the opposite strand against the drop's target region (ksw_ll_i16 in minimap2)
+                std::vector<std::vector<int8_t>> qv((size_t)n_probe), tv((size_t)n_probe);
+                for (int k = 0; k < n_probe; ++k) {
+                    const InvProbe &pb = probes[(size_t)k];
+                    const ExtJob &jb = jobs[(size_t)pb.jid];
+                    const int q_len = pb.q1 - pb.q0, t_len = pb.t1 - pb.t0, rlen = hs->seq_len[jb.read];
+                    const char *rd = hs->seqs + hs->seq_off[jb.read];
+                    qv[(size_t)k].resize((size_t)q_len);
+                    for (int x = 0; x < q_len; ++x) { const int8_t c = host_qbase(rd, rlen, jb.rev, jb.qs + pb.q1 - x - 1); qv[(size_t)k][(size_t)x] = c >= 4 ? (int8_t)4 : (int8_t)(3 - c); }
+                    tv[(size_t)k].resize((size_t)t_len);
+                    if (fetch_ref_codes(rv, hs->tseq_off[jb.rid], jb.ts + pb.t0, t_len, tv[(size_t)k].data(), st)) return -1;
+                }
+                if (local_scores(opt, qv, tv, hits)) return -1;
+            }
+            for (int k = 0; k < n_probe; ++k) {
+                const InvProbe &pb = probes[(size_t)k];
+                const bool inv = hits[(size_t)k].score >= opt->min_chain_score * opt->a && hits[(size_t)k].score >= opt->min_dp_max;
+                if (inv) is_inv[(size_t)pb.jid] = 1;
+                if (inv || pb.over) redo.push_back(pb.jid);
+            }
+        }
+        g_stats[8] += (int64_t)redo.size();
+        const int nr = (int)redo.size();
         auto list_of = [&](int j) { return jobs[(size_t)j].cls & 0xff; };
         auto redo_list_of = [&](int j) { return jobs[(size_t)j].cls >> 8 & 0xff; };
         auto band_of = [&](int j) { return (jobs[(size_t)j].cls >> 16 & 0xff) - 1; };
         std::sort(redo.begin(), redo.end(), [&](int x, int y) { return redo_list_of(x) != redo_list_of(y) ? redo_list_of(x) < redo_list_of(y) : x < y; });
-        // [ids | layout | qstride | p_off (int64)]: a strip window's second pass needs a band / anti-diagonal matrix, which
-        // comes from a pool of its own (offsets are relative to the main pool's base: one flat address space)
-        std::vector<int32_t> pack((size_t)nr * 5 + 2);
-        int64_t *pack_off = reinterpret_cast<int64_t *>(pack.data() + (((size_t)nr * 3 + 1) & ~(size_t)1));
+        // [ids | layout | qstride | inversion flag | p_off (int64)]: a strip window's second pass needs a band / anti-diagonal
+        // matrix, which comes from a pool of its own (offsets are relative to the main pool's base: one flat address space)
+        std::vector<int32_t> pack((size_t)nr * 6 + 2);
+        const size_t off_p = ((size_t)nr * 4 + 1) & ~(size_t)1;
+        int64_t *pack_off = reinterpret_cast<int64_t *>(pack.data() + off_p);
         int64_t p2_tot = 0;
         for (int k = 0; k < nr; ++k) {
             const int j = redo[k];
             const ExtJob &jb = jobs[(size_t)j];
             const int bv = band_of(j);
-            pack[k] = j; pack[nr + k] = bv >= 0 ? 2 : 0; pack[2 * nr + k] = 128 << std::max(bv, 0);
+            pack[k] = j; pack[nr + k] = bv >= 0 ? 2 : 0; pack[2 * nr + k] = 128 << std::max(bv, 0); pack[3 * nr + k] = is_inv[(size_t)j];
             if (list_of(j) >= L_STRIP && list_of(j) < L_BAND) {
                 const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
                 pack_off[k] = -1 - p2_tot;  // resolved below, once the pool address is known
                 p2_tot += ((bv >= 0 ? n_r * (128 << bv) : n_r * jb.n_col) + 15) & ~(int64_t)15;
             } else pack_off[k] = jb.p_off;
         }
-        if (SL.pool_P2.ensure((size_t)p2_tot + 16)) return -1;
-        const int64_t p2_base = (int64_t)(SL.pool_P2.as<uint8_t>() - P.p);
-        for (int k = 0; k < nr; ++k) if (pack_off[k] < 0) pack_off[k] = p2_base + (-1 - pack_off[k]);
-        if (SL.pool_redo.ensure(pack.size() * 4)) return -1;
-        struct { int32_t *p; } d_redo{SL.pool_redo.as<int32_t>()};
-        MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(ext_redo_patch_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, d_jobs.p, d_redo.p, d_redo.p + nr, d_redo.p + 2 * nr,
-                           reinterpret_cast<const int64_t *>(d_redo.p + (((size_t)nr * 3 + 1) & ~(size_t)1)), nr);
-        MPN_HIP_CHECK(hipGetLastError());
-        ev.skip();
-        for (int lo = 0; lo < nr;) {
-            int hi = lo;
-            while (hi < nr && redo_list_of(redo[hi]) == redo_list_of(redo[lo])) ++hi;
-            if (launch_list(redo_list_of(redo[lo]), d_redo.p + lo, hi - lo, st)) return -1;
-            lo = hi;
+        if (nr > 0) {
+            if (SL.pool_P2.ensure((size_t)p2_tot + 16)) return -1;
+            const int64_t p2_base = (int64_t)(SL.pool_P2.as<uint8_t>() - P.p);
+            for (int k = 0; k < nr; ++k) if (pack_off[k] < 0) pack_off[k] = p2_base + (-1 - pack_off[k]);
+            if (SL.pool_redo.ensure(pack.size() * 4)) return -1;
+            struct { int32_t *p; } d_redo{SL.pool_redo.as<int32_t>()};
+            MPN_HIP_CHECK(hipMemcpyAsync(d_redo.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(ext_redo_patch_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, d_jobs.p, d_redo.p, d_redo.p + nr, d_redo.p + 2 * nr,
+                               reinterpret_cast<const int64_t *>(d_redo.p + off_p), d_redo.p + 3 * nr, opt->zdrop_inv, nr);
+            MPN_HIP_CHECK(hipGetLastError());
+            ev.skip();
+            for (int lo = 0; lo < nr;) {
+                int hi = lo;
+                while (hi < nr && redo_list_of(redo[hi]) == redo_list_of(redo[lo])) ++hi;
+                if (launch_list(redo_list_of(redo[lo]), d_redo.p + lo, hi - lo, st)) return -1;
+                lo = hi;
+            }
+            ev.mark(15);
+            hipLaunchKernelGGL(ext_bt_kernel, dim3((nr + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p, nr, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
+            MPN_HIP_CHECK(hipGetLastError());
+            ev.mark(25);
+            MPN_HIP_CHECK(stream_sync(st));
         }
-        ev.mark(15);
-        hipLaunchKernelGGL(ext_bt_kernel, dim3((nr + 63) / 64), dim3(64), 0, st, d_jobs.p, d_redo.p, nr, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
-        MPN_HIP_CHECK(hipGetLastError());
-        ev.mark(25);
-        MPN_HIP_CHECK(stream_sync(st));
     }
     ev.resolve();
     wt.stop_into(g_stats[30]);
@@ -906,14 +1000,14 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
 // whose direction scratch stays under the budget (MPN_DP_BUDGET bytes, for tests).  The job records, results and compacted
 // CIGARs of ALL groups stay in the worker's device pools (out); a group only borrows the direction-matrix scratch.
 static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj_cap, const uint8_t *d_reads, const int64_t *d_read_off,
-                    const int32_t *d_read_len, DevRound &out, hipStream_t st) {
+                    const int32_t *d_read_len, DevRound &out, const HostSeqs *hs, hipStream_t st) {
     static const int64_t budget = []() { const char *e = getenv("MPN_DP_BUDGET"); return e ? std::max<int64_t>(1 << 20, atoll(e)) : (int64_t)40 << 30; }();
     Slot &SL = *tl_slot;
-    if (SL.pool_res.ensure((size_t)nj_cap * sizeof(ExtRes) + 16) || SL.pool_used.ensure(64)) return -1;
+    if (SL.pool_res.ensure((size_t)nj_cap * sizeof(ExtRes) + 16) || SL.pool_used.ensure(128)) return -1;
     out.jobs = SL.pool_jobs.as<ExtJob>(); out.res = SL.pool_res.as<ExtRes>(); out.compact = nullptr;
     out.used = SL.pool_used.as<unsigned long long>();   // [0] compacted ops, [1] second-pass windows, [2] stitched ops, [3] windows of the round, [4] of a sub-range
     MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 24, st));
-    const int rc = run_job_group(rv, opt, nj_cap, out.used + 3, out, d_reads, d_read_off, d_read_len, budget, st);
+    const int rc = run_job_group(rv, opt, nj_cap, out.used + 3, out, d_reads, d_read_off, d_read_len, budget, hs, st);
     if (rc != 1) return rc;
     // over the budget: cut the range where the direction matrices (their offsets are in the size table) fill it
     const int nj = out.n_jobs;
@@ -927,7 +1021,7 @@ static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj_cap, const
         dv.jobs += cuts[g]; dv.res += cuts[g];
         const unsigned long long cnt = (unsigned long long)(cuts[g + 1] - cuts[g]);
         MPN_HIP_CHECK(hipMemcpy(out.used + 4, &cnt, 8, hipMemcpyHostToDevice));
-        const int r2 = run_job_group(rv, opt, (int)cnt, out.used + 4, dv, d_reads, d_read_off, d_read_len, 0, st);
+        const int r2 = run_job_group(rv, opt, (int)cnt, out.used + 4, dv, d_reads, d_read_off, d_read_len, 0, hs, st);
         if (r2) return r2 < 0 ? r2 : -1;
     }
     out.n_jobs = nj;
@@ -1140,6 +1234,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         po.min_cnt = opt->min_cnt; po.a = opt->a; po.q = opt->q; po.e = opt->e; po.zdrop = opt->zdrop; po.zdrop_inv = opt->zdrop_inv;
         po.end_bonus = opt->end_bonus; po.min_ksw_len = opt->min_ksw_len; po.k = idx->k; po.pad = 0; po.max_sw_mat = opt->max_sw_mat;
         const RefView rv{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
+        const HostSeqs hseqs{seqs, seq_off, seq_len, idx->seq_off.data()};
         std::vector<int32_t> sr_base((size_t)n + 1, 0);
         for (int round = 0; round < 64; ++round) {
             wt.stop_into(g_stats[23]);
@@ -1160,7 +1255,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             if (n_sr == 0) { wt.stop_into(g_stats[20]); break; }
             std::vector<int64_t> cap_t((size_t)std::max(1, n_threads), 0);
             if (SL.pin_pregs.ensure((size_t)n_sr * sizeof(PlanReg) + 64) || SL.pool_pregs.ensure((size_t)n_sr * sizeof(PlanReg) + 16) ||
-                SL.pool_psum.ensure((size_t)n_sr * sizeof(PlanSum) + 16) || SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pool_used.ensure(64))
+                SL.pool_psum.ensure((size_t)n_sr * sizeof(PlanSum) + 16) || SL.pool_sregs.ensure((size_t)n_sr * sizeof(StitchReg) + 16) || SL.pool_used.ensure(128))
                 return -1;
             PlanReg *h_pr = SL.pin_pregs.as<PlanReg>();
             parallel_for(n, n_threads, [&](int i, int slot) {
@@ -1192,7 +1287,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             wt.stop_into(g_stats[20]);
             ++g_stats[7];
             DevRound dv;
-            if (run_jobs(rv, opt, nj_cap, d_seqs.p, d_off.p, d_len.p, dv, st)) return -1;
+            if (run_jobs(rv, opt, nj_cap, d_seqs.p, d_off.p, d_len.p, dv, &hseqs, st)) return -1;
             evp.resolve();
             if (!dv.compact) {   // (a round without any window: the stitching kernel still sets the hits' coordinates)
                 if (SL.pool_compact.ensure(64)) return -1;
@@ -1202,6 +1297,91 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             const RoundDev rd{d_sr, d_pr, d_ps, d_janchor, d_a.p};
             if (stitch_and_finish(idx, opt, rs, n, seq_len, dv, rd, sr_base, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
             wt.stop_into(g_stats[22]);
+        }
+        // ---- inversions (mm_align1_inv): where a hit was cut at an inversion, the read's gap between the two pieces is aligned
+        // to the target's gap on the opposite strand.  Rare; the candidates are gathered on the host, the local alignment that
+        // locates the inverted segment runs on the SSW kernels, its extension is one more (tiny) round of the DP pipeline.
+        struct InvCand { int read, at, ql, tl, rev, qstart, tstart, rid; };
+        std::vector<InvCand> cand;
+        for (int i = 0; i < n; ++i) {
+            const std::vector<Reg> &R = rs[i].regs;
+            for (int k = 1; k < (int)R.size(); ++k) {
+                if (!R[(size_t)k].split_inv) continue;
+                const Reg &r1 = R[(size_t)k - 1], &r2 = R[(size_t)k];
+                if (!(r1.split & 1) || !(r2.split & 2)) continue;
+                if (r1.id != r1.parent && r1.parent != PARENT_TMP_PRI) continue;
+                if (r2.id != r2.parent && r2.parent != PARENT_TMP_PRI) continue;
+                if (r1.rid != r2.rid || r1.rev != r2.rev) continue;
+                const int ql = r1.rev ? r1.qs - r2.qe : r2.qs - r1.qe, tl = r2.rs - r1.re;
+                if (ql < opt->min_chain_score || ql > opt->max_gap || tl < opt->min_chain_score || tl > opt->max_gap) continue;
+                // the read's gap on the strand opposite to the hit: forward coordinates from r2.qe if the hit is on the reverse
+                // strand, reverse-strand coordinates from qlen - r2.qs otherwise
+                cand.push_back(InvCand{i, k, ql, tl, r1.rev ? 0 : 1, r1.rev ? r2.qe : seq_len[i] - r2.qs, r1.re, r1.rid});
+            }
+        }
+        if (!cand.empty()) {
+            const int nc = (int)cand.size();
+            std::vector<std::vector<int8_t>> qv((size_t)nc), tv((size_t)nc);
+            for (int c = 0; c < nc; ++c) {   // both sequences reversed: the best local alignment's END there is its START here
+                const InvCand &ic = cand[(size_t)c];
+                const char *rd_ = seqs + seq_off[ic.read];
+                qv[(size_t)c].resize((size_t)ic.ql);
+                for (int x = 0; x < ic.ql; ++x) qv[(size_t)c][(size_t)x] = host_qbase(rd_, seq_len[ic.read], ic.rev, ic.qstart + ic.ql - 1 - x);
+                std::vector<int8_t> t((size_t)ic.tl);
+                if (fetch_ref_codes(rv, idx->seq_off[(size_t)ic.rid], ic.tstart, ic.tl, t.data(), st)) return -1;
+                tv[(size_t)c].assign(t.rbegin(), t.rend());
+            }
+            std::vector<LocalHit> lh;
+            if (local_scores(opt, qv, tv, lh)) return -1;
+            std::vector<ExtJob> jobs;
+            std::vector<StitchReg> sregs;
+            for (int i = 0; i < n; ++i) rs[i].pending.clear();
+            // placeholders go in from the back of every read's list, so that the positions of the earlier candidates stay valid
+            for (int c = nc - 1; c >= 0; --c) {
+                const InvCand &ic = cand[(size_t)c];
+                if (lh[(size_t)c].score < opt->min_dp_max) continue;
+                const int q_off = ic.ql - (lh[(size_t)c].qe + 1), t_off = ic.tl - (lh[(size_t)c].te + 1);
+                Reg ri;
+                ri.id = -1; ri.parent = PARENT_UNSET; ri.inv = 1; ri.rev = (uint32_t)ic.rev; ri.rid = ic.rid; ri.cnt = 0; ri.aligned = 0;
+                ri.fin_qs = ic.qstart + q_off; ri.fin_rs = ic.tstart + t_off; ri.fin_ql = ic.ql - q_off; ri.fin_tl = ic.tl - t_off;
+                rs[ic.read].regs.insert(rs[ic.read].regs.begin() + ic.at + 1, ri);
+            }
+            for (int i = 0; i < n; ++i) {
+                std::vector<Reg> &R = rs[i].regs;
+                for (int k = 0; k < (int)R.size(); ++k) {
+                    Reg &r = R[(size_t)k];
+                    if (!r.inv || r.aligned) continue;
+                    rs[i].pending.push_back(k);
+                    ExtJob j;
+                    memset(&j, 0, sizeof(j));
+                    j.read = i; j.rid = r.rid; j.rev = (int32_t)r.rev; j.qs = r.fin_qs; j.qlen = r.fin_ql; j.ts = r.fin_rs; j.tlen = r.fin_tl; j.reversed = 0;
+                    j.w = (int)(opt->bw * 1.5); j.zdrop = opt->zdrop; j.end_bonus = -1; j.flag = EZ_EXTZ_ONLY; j.strip_s = 1; j.cls = -1;
+                    sregs.push_back(StitchReg{(int32_t)jobs.size(), 1, j.qs, j.ts, j.qs, j.ts, j.qs, j.qs + j.qlen, i, r.rid, (int32_t)r.rev, 0});
+                    jobs.push_back(j);
+                }
+            }
+            if (!jobs.empty()) {
+                const int nj = (int)jobs.size();
+                for (int i = 0; i < n; ++i) sr_base[(size_t)i + 1] = sr_base[(size_t)i] + (int32_t)rs[i].pending.size();
+                if (SL.pool_jobs.ensure((size_t)nj * sizeof(ExtJob) + 16) || SL.pool_sregs.ensure((size_t)nj * sizeof(StitchReg) + 16) ||
+                    SL.pool_pregs.ensure(64) || SL.pool_psum.ensure(64) || SL.pool_job_anchor.ensure(64) || SL.pool_used.ensure(128))
+                    return -1;
+                const unsigned long long cnt = (unsigned long long)nj;
+                MPN_HIP_CHECK(hipMemcpyAsync(SL.pool_jobs.p, jobs.data(), (size_t)nj * sizeof(ExtJob), hipMemcpyHostToDevice, st));
+                MPN_HIP_CHECK(hipMemcpyAsync(SL.pool_sregs.p, sregs.data(), (size_t)nj * sizeof(StitchReg), hipMemcpyHostToDevice, st));
+                MPN_HIP_CHECK(hipMemcpyAsync(SL.pool_used.as<unsigned long long>() + 3, &cnt, 8, hipMemcpyHostToDevice, st));
+                MPN_HIP_CHECK(stream_sync(st));
+                DevRound dv;
+                if (run_jobs(rv, opt, nj, d_seqs.p, d_off.p, d_len.p, dv, &hseqs, st)) return -1;
+                if (!dv.compact) { if (SL.pool_compact.ensure(64)) return -1; dv.compact = SL.pool_compact.as<uint32_t>(); }
+                const RoundDev rd{SL.pool_sregs.as<StitchReg>(), SL.pool_pregs.as<PlanReg>(), SL.pool_psum.as<PlanSum>(), SL.pool_job_anchor.as<int32_t>(), d_a.p};
+                if (stitch_and_finish(idx, opt, rs, n, seq_len, dv, rd, sr_base, d_seqs.p, d_off.p, d_len.p, n_threads, st)) return -1;
+            }
+            // an extension that produced nothing yields no inversion hit (mm_align1_inv returns 0)
+            for (int i = 0; i < n; ++i) {
+                std::vector<Reg> &R = rs[i].regs;
+                R.erase(std::remove_if(R.begin(), R.end(), [](const Reg &r) { return r.inv && !r.has_p; }), R.end());
+            }
         }
     }
     wt.stop_into(g_stats[23]);
@@ -1733,7 +1913,7 @@ extern "C" int mpn_ext_dp_batch(const mpn_map_opt *opt, int32_t n, const uint8_t
         if (tl_slot->pool_used.ensure(64)) return -1;
         MPN_HIP_CHECK(hipMemcpy(tl_slot->pool_used.as<unsigned long long>() + 3, &cnt, 8, hipMemcpyHostToDevice));
     }
-    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, n, d_reads.p, d_qoff.p, d_qlen.p, dv, st);
+    const int rc = run_jobs(RefView{d_ref.p, d_toff.p, d_ns.p, d_ne.p, (int32_t)ns.size()}, &o2, n, d_reads.p, d_qoff.p, d_qlen.p, dv, nullptr, st);
     g_force_kernel = 0;
     if (rc) return rc;
     // (the product keeps these on the device for the stitching kernel; the stage test reads them back)

@@ -45,7 +45,12 @@ struct ExtRes {
 struct ExtParams {
     int8_t sc_mch, sc_mis, sc_n, q, e, q2, e2;
     int32_t zdrop_thres;  // opt->zdrop for the path test
+    int32_t zdrop_inv, max_gap;   // inversion probe of the path test (mm_test_zdrop): a drop above zdrop_inv over a region shorter than max_gap
 };
+
+// a gap fill whose largest score drop may hide an inversion: the region of the drop [t0, t1) x [q0, q1) in window coordinates
+// (the host runs the local alignment of the region's reverse complement, rare) and whether the drop also exceeds zdrop
+struct InvProbe { int32_t jid, t0, q0, t1, q1, over; };
 
 __device__ __forceinline__ uint8_t ext_qbase(const uint8_t *__restrict__ reads, int64_t roff, int32_t rlen, int rev, int x) {
     // base x of the read on the hit's strand, as a 0..4 code
@@ -894,7 +899,8 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
                                                        const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                                                        RefView rv,
                                                        const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res,
-                                                       int32_t *__restrict__ redo_ids, unsigned long long *__restrict__ n_redo) {
+                                                       int32_t *__restrict__ redo_ids, unsigned long long *__restrict__ n_redo,
+                                                       InvProbe *__restrict__ probes, unsigned long long *__restrict__ n_probe) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
     const int jid = order[k];
@@ -908,11 +914,12 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
         if (z) redo_ids[atomicAdd(n_redo, 1ULL)] = jid;
     };
     const ExtRes r = res[jid];
-    // No walk needed when a drop of more than zdrop is impossible: prefix scores satisfy S(i) <= a * (matches up to i)
-    // and S(j) >= F - a * (matches after j), so S(i) - S(j) <= a * min(qlen, tlen) - F for the window's final score F.
+    const int zmin = prm.zdrop_thres < prm.zdrop_inv ? prm.zdrop_thres : prm.zdrop_inv;
+    // No walk needed when a drop of more than the smaller threshold is impossible: prefix scores satisfy S(i) <= a * (matches up
+    // to i) and S(j) >= F - a * (matches after j), so S(i) - S(j) <= a * min(qlen, tlen) - F for the window's final score F.
     // (Only for the strip kernel, whose corner score is exact.)
     if (jb.layout == 1 && r.do_bt && !r.zdropped &&
-        (int64_t)prm.sc_mch * (jb.qlen < jb.tlen ? jb.qlen : jb.tlen) - r.score <= prm.zdrop_thres) {
+        (int64_t)prm.sc_mch * (jb.qlen < jb.tlen ? jb.qlen : jb.tlen) - r.score <= zmin) {
         report(0);
         return;
     }
@@ -921,9 +928,10 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     const int32_t rlen = read_len[jb.read];
     const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+    int32_t p00 = -1, p01 = -1, p10 = -1, p11 = -1;   // where the largest drop starts (the running maximum) and ends
     RefCursor tc(rv);
     ReadCursor qc(reads, roff, rlen, jb.rev);
-    for (int c = 0; c < r.n_cigar && max_zdrop <= prm.zdrop_thres; ++c) {  // (only "above the threshold or not" is reported)
+    for (int c = 0; c < r.n_cigar; ++c) {
         const uint32_t op = cig[c] & 0xf, len = cig[c] >> 4;
         if (op == 0) {
             for (uint32_t l = 0; l < len; ++l) {
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
                 if (score < mx) {
                     const int li = i + (int)l - max_i, lj = j + (int)l - max_j, diff = li > lj ? li - lj : lj - li;
                     const int z = mx - score - diff * prm.e;
-                    if (z > max_zdrop) max_zdrop = z;
+                    if (z > max_zdrop) { max_zdrop = z; p00 = max_i; p01 = max_j; p10 = i + (int)l; p11 = j + (int)l; }
                 } else { mx = score; max_i = i + l; max_j = j + l; }
             }
             i += len; j += len;
@@ -942,11 +950,19 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
             if (score < mx) {
                 const int li = i - max_i, lj = j - max_j, diff = li > lj ? li - lj : lj - li;
                 const int z = mx - score - diff * prm.e;
-                if (z > max_zdrop) max_zdrop = z;
+                if (z > max_zdrop) { max_zdrop = z; p00 = max_i; p01 = max_j; p10 = i; p11 = j; }
             } else { mx = score; max_i = i; max_j = j; }
         }
     }
-    report(max_zdrop > prm.zdrop_thres ? 1 : 0);
+    const int over = max_zdrop > prm.zdrop_thres ? 1 : 0;
+    const int q_len = p11 - p01, t_len = p10 - p00;
+    if (max_zdrop > prm.zdrop_inv && q_len < prm.max_gap && t_len < prm.max_gap && q_len > 0 && t_len > 0) {
+        // inversion candidate: the host decides between "nothing / plain z-drop" and "inversion" (second pass with zdrop_inv)
+        res[jid].zcode = over;
+        probes[atomicAdd(n_probe, 1ULL)] = InvProbe{jid, p00, p01, p10, p11, over};
+        return;
+    }
+    report(over);
 }
 
 }  // namespace mpn

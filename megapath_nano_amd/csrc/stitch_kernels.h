@@ -9,7 +9,7 @@ namespace mpn {
 
 // placeholder job of a window that gets no DP (refused by max_sw_mat, or empty): it keeps the job list of a hit complete
 // (left?, fills..., right?) and counts as z-dropped at its start, exactly like the `ez.zdropped = 1` of the host code it replaces
-enum { EZ_REFUSED = 0x100 };
+enum { EZ_REFUSED = 0x100, EZ_INV = 0x200 };   // EZ_INV: the z-drop test found an inversion in this fill (second pass with zdrop_inv)
 
 struct StitchReg {
     int32_t first_job, n_jobs;        // jobs [first_job, first_job + n_jobs): left extension (if any), gap fills in order, right extension (if any)
@@ -23,6 +23,7 @@ struct StitchOut {
     int32_t n_ops, dp_score, rs1, re1, qs1, qe1;
     int32_t has_p, dropped, drop_fill, drop_max_t, drop_max_q;   // drop_fill: index of the z-dropped gap fill among the hit's fills
     int32_t split_n;                  // > 0: a z-drop cuts the hit after its first split_n anchors (mm_align1's mm_split_reg call)
+    int32_t split_inv, pad;           // the cut is at an inversion: the remainder is marked (mm_align1: r2->split_inv = 1)
 };
 
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                 qs1 = sr.qs - (reach ? sr.qs - sr.qs0 : max_q + 1);
             }
             StitchOut o;
-            o.drop_fill = -1; o.drop_max_t = o.drop_max_q = -1; o.split_n = 0;
+            o.drop_fill = -1; o.drop_max_t = o.drop_max_q = -1; o.split_n = 0; o.split_inv = 0; o.pad = 0;
             if (dropped) {
                 const ExtJob &jb = jb0[k_stop];
                 int max_t = -1, max_q = -1;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                 int j;
                 for (j = job_anchor[sr.first_job + k_stop] - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= jb.ts + max_t) break;
                 if (j < 0) j = 0;
-                if (cnt1 - (j + 1) >= min_cnt) o.split_n = as1 + j + 1 - pregs[ri].as;
+                if (cnt1 - (j + 1) >= min_cnt) { o.split_n = as1 + j + 1 - pregs[ri].as; o.split_inv = (jb.flag & EZ_INV) ? 1 : 0; }
             } else if (n > 0 && (jb0[n - 1].flag & EZ_EXTZ_ONLY) && !jb0[n - 1].reversed) {
                 int reach = 0, max_t = -1, max_q = -1, mqe_t = -1;
                 if (!(jb0[n - 1].flag & EZ_REFUSED)) { const ExtRes &e = rs0[n - 1]; reach = e.reach_end; max_t = e.max_t; max_q = e.max_q; mqe_t = e.mqe_t; }

@@ -1157,33 +1157,74 @@ static void align_pair(const mmo_opt *opt, int qlen, const uint8_t *qseq, int tl
               (int8_t)opt->e, (int8_t)opt->q2, (int8_t)opt->e2, w, zdrop, end_bonus, flag, ez);
 }
 
-/* score drop along the alignment path (second, exact pass is run if it exceeds zdrop) */
+/* Local alignment score with affine gaps (a gap of length L costs q + L * e), as minimap2's ksw_ll_i16 computes it for the
+ * inversion code: plain recurrences; the reported end is the first target column (scanning left to right) whose column maximum
+ * exceeds everything before it, and in that column the smallest query index holding the maximum (ksw's own tie rule). */
+static int ll_local(int ql, const uint8_t *q, int tl, const uint8_t *t, const int8_t *mat, int gapo, int gape, int *qe, int *te)
+{
+    int i, j, gmax = 0, *H, *E;
+    *qe = *te = -1;
+    if (ql <= 0 || tl <= 0) return 0;
+    H = (int *)calloc((size_t)ql + 1, sizeof(int));
+    E = (int *)calloc((size_t)ql + 1, sizeof(int));
+    for (i = 0; i < tl; ++i) {
+        int f = 0, diag = 0, cmax = 0, cq = -1;
+        for (j = 0; j < ql; ++j) {
+            int h = diag + mat[t[i] * 5 + q[j]], e = E[j + 1];
+            diag = H[j + 1];
+            if (h < e) h = e;
+            if (h < f) h = f;
+            if (h < 0) h = 0;
+            H[j + 1] = h;
+            if (h > cmax) cmax = h, cq = j;
+            e -= gape; if (e < h - gapo - gape) e = h - gapo - gape; if (e < 0) e = 0;
+            f -= gape; if (f < h - gapo - gape) f = h - gapo - gape; if (f < 0) f = 0;
+            E[j + 1] = e;
+        }
+        if (cmax > gmax) gmax = cmax, *te = i, *qe = cq;
+    }
+    free(H); free(E);
+    return gmax;
+}
+
+/* score drop along the alignment path: 1 = exceeds zdrop (the exact second pass is run), 2 = the region of the largest drop
+ * aligns to its own reverse complement well enough to be an inversion (second pass with zdrop_inv, the remainder of the hit is
+ * marked split_inv) -- mm_test_zdrop */
 static int test_zdrop(const mmo_opt *opt, const uint8_t *qseq, const uint8_t *tseq, int n_cigar, const uint32_t *cigar,
                       const int8_t *mat)
 {
-    int k;
+    int k, pos[2][2] = {{-1, -1}, {-1, -1}}, q_len, t_len;
     int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+#define MMO_UPD(I, J) do { \
+        if (score < max) { \
+            int li = (I) - max_i, lj = (J) - max_j, diff = li > lj ? li - lj : lj - li; \
+            int z = max - score - diff * opt->e; \
+            if (z > max_zdrop) { max_zdrop = z; pos[0][0] = max_i, pos[0][1] = max_j, pos[1][0] = (I), pos[1][1] = (J); } \
+        } else max = score, max_i = (I), max_j = (J); \
+    } while (0)
     for (k = 0; k < n_cigar; ++k) {
         uint32_t l, op = cigar[k] & 0xf, len = cigar[k] >> 4;
         if (op == 0) {
             for (l = 0; l < len; ++l) {
                 score += mat[tseq[i + l] * 5 + qseq[j + l]];
-                if (score < max) {
-                    int li = i + (int)l - max_i, lj = j + (int)l - max_j, diff = li > lj ? li - lj : lj - li;
-                    int z = max - score - diff * opt->e;
-                    if (z > max_zdrop) max_zdrop = z;
-                } else max = score, max_i = i + l, max_j = j + l;
+                MMO_UPD(i + (int)l, j + (int)l);
             }
             i += len, j += len;
         } else if (op == 1 || op == 2) {
             score -= opt->q + opt->e * len;
             if (op == 1) j += len; else i += len;
-            if (score < max) {
-                int li = i - max_i, lj = j - max_j, diff = li > lj ? li - lj : lj - li;
-                int z = max - score - diff * opt->e;
-                if (z > max_zdrop) max_zdrop = z;
-            } else max = score, max_i = i, max_j = j;
+            MMO_UPD(i, j);
         }
+    }
+#undef MMO_UPD
+    q_len = pos[1][1] - pos[0][1], t_len = pos[1][0] - pos[0][0];
+    if (max_zdrop > opt->zdrop_inv && q_len < opt->max_gap && t_len < opt->max_gap && q_len > 0 && t_len > 0) {
+        uint8_t *qseq2 = (uint8_t *)malloc((size_t)q_len);
+        int q_off, t_off, sc;
+        for (k = 0; k < q_len; ++k) { int c = qseq[pos[1][1] - k - 1]; qseq2[k] = c >= 4 ? 4 : 3 - c; }
+        sc = ll_local(q_len, qseq2, t_len, tseq + pos[0][0], mat, opt->q, opt->e, &q_off, &t_off);
+        free(qseq2);
+        if (sc >= opt->min_chain_score * opt->a && sc >= opt->min_dp_max) return 2;
     }
     return max_zdrop > opt->zdrop ? 1 : 0;
 }
@@ -1286,9 +1327,10 @@ static void align1(const mmo_opt *opt, const mmo_idx *mi, int qlen, uint8_t *qse
             if (a[as1 + i].y & MMO_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
             qseq = &qseq0[rev][qs];
             getseq(mi, rid, rs, re, tseq);
+            int zdrop_code;
             align_pair(opt, qe - qs, qseq, re - rs, tseq, bw1, -1, opt->zdrop, MMO_EZ_APPROX_MAX, ez);
-            if (test_zdrop(opt, qseq, tseq, ez->n_cigar, ez->cigar, mat) != 0)
-                align_pair(opt, qe - qs, qseq, re - rs, tseq, bw1, -1, opt->zdrop, 0, ez);
+            if ((zdrop_code = test_zdrop(opt, qseq, tseq, ez->n_cigar, ez->cigar, mat)) != 0)
+                align_pair(opt, qe - qs, qseq, re - rs, tseq, bw1, -1, zdrop_code == 2 ? opt->zdrop_inv : opt->zdrop, 0, ez);
             if (ez->n_cigar > 0) append_cigar(r, ez->n_cigar, ez->cigar);
             if (ez->zdropped) { /* the alignment broke: keep the left part, hand the rest back as a new hit */
                 r->has_p = 1;
@@ -1298,7 +1340,10 @@ static void align1(const mmo_opt *opt, const mmo_idx *mi, int qlen, uint8_t *qse
                 r->dp_score += ez->max;
                 re1 = rs + (ez->max_t + 1);
                 qe1 = qs + (ez->max_q + 1);
-                if (cnt1 - (j + 1) >= opt->min_cnt) split_reg(r, r2, as1 + j + 1 - r->as, qlen, a);
+                if (cnt1 - (j + 1) >= opt->min_cnt) {
+                    split_reg(r, r2, as1 + j + 1 - r->as, qlen, a);
+                    if (zdrop_code == 2) r2->split_inv = 1;
+                }
                 break;
             } else r->dp_score += ez->score;
             rs = re, qs = qe;
@@ -1324,6 +1369,60 @@ static void align1(const mmo_opt *opt, const mmo_idx *mi, int qlen, uint8_t *qse
         update_extra(r, &qseq0[r->rev][qs1], tseq, mat, (int8_t)opt->q, (int8_t)opt->e);
     }
     free(tseq);
+}
+
+/* the inverted segment between the two halves of a hit that was split at an inversion (mm_align1_inv): a local alignment of
+ * the reverse strand of the read's gap against the target's gap locates its start, an extension from there gives the hit */
+static int align1_inv(const mmo_opt *opt, const mmo_idx *mi, int qlen, uint8_t *qseq0[2], const mmo_reg *r1, const mmo_reg *r2,
+                      mmo_reg *r_inv, mmo_ez *ez)
+{
+    int tl, ql, score, ret = 0, q_off, t_off, i;
+    uint8_t *tseq, *qseq;
+    int8_t mat[25];
+    memset(r_inv, 0, sizeof(mmo_reg));
+    if (!(r1->split & 1) || !(r2->split & 2)) return 0;
+    if (r1->id != r1->parent && r1->parent != PARENT_TMP_PRI) return 0;
+    if (r2->id != r2->parent && r2->parent != PARENT_TMP_PRI) return 0;
+    if (r1->rid != r2->rid || r1->rev != r2->rev) return 0;
+    ql = r1->rev ? r1->qs - r2->qe : r2->qs - r1->qe;
+    tl = r2->rs - r1->re;
+    if (ql < opt->min_chain_score || ql > opt->max_gap) return 0;
+    if (tl < opt->min_chain_score || tl > opt->max_gap) return 0;
+    for (i = 0; i < 4; ++i) { int j; for (j = 0; j < 4; ++j) mat[i * 5 + j] = i == j ? opt->a : -opt->b; mat[i * 5 + 4] = -opt->sc_ambi; }
+    for (i = 0; i < 5; ++i) mat[20 + i] = -opt->sc_ambi;
+    tseq = (uint8_t *)malloc((size_t)tl);
+    getseq(mi, r1->rid, r1->re, r2->rs, tseq);
+    qseq = r1->rev ? &qseq0[0][r2->qe] : &qseq0[1][qlen - r2->qs];
+    seq_rev(ql, qseq);
+    seq_rev(tl, tseq);
+    score = ll_local(ql, qseq, tl, tseq, mat, opt->q, opt->e, &q_off, &t_off);
+    seq_rev(ql, qseq);
+    seq_rev(tl, tseq);
+    if (score < opt->min_dp_max) goto end_inv;
+    q_off = ql - (q_off + 1), t_off = tl - (t_off + 1);
+    align_pair(opt, ql - q_off, qseq + q_off, tl - t_off, tseq + t_off, (int)(opt->bw * 1.5), -1, opt->zdrop, MMO_EZ_EXTZ_ONLY, ez);
+    if (ez->n_cigar == 0) goto end_inv;
+    append_cigar(r_inv, ez->n_cigar, ez->cigar);
+    r_inv->dp_score = ez->max;
+    r_inv->id = -1;
+    r_inv->parent = PARENT_UNSET;
+    r_inv->inv = 1;
+    r_inv->rev = !r1->rev;
+    r_inv->rid = r1->rid;
+    if (r_inv->rev == 0) {
+        r_inv->qs = r2->qe + q_off;
+        r_inv->qe = r_inv->qs + ez->max_q + 1;
+    } else {
+        r_inv->qe = r2->qs - q_off;
+        r_inv->qs = r_inv->qe - (ez->max_q + 1);
+    }
+    r_inv->rs = r1->re + t_off;
+    r_inv->re = r_inv->rs + ez->max_t + 1;
+    update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e);
+    ret = 1;
+end_inv:
+    free(tseq);
+    return ret;
 }
 
 static mmo_reg *insert_reg(const mmo_reg *r, int i, int *n_regs, mmo_reg *regs)
@@ -1353,6 +1452,12 @@ static mmo_reg *align_skeleton(const mmo_opt *opt, const mmo_idx *mi, int qlen, 
         mmo_reg r2;
         align1(opt, mi, qlen, qseq0, &regs[i], &r2, n_a, a, &ez);
         if (r2.cnt > 0) regs = insert_reg(&r2, i, &n_regs, regs);
+        if (i > 0 && regs[i].split_inv) {
+            if (align1_inv(opt, mi, qlen, qseq0, &regs[i - 1], &regs[i], &r2, &ez)) {
+                regs = insert_reg(&r2, i, &n_regs, regs);
+                ++i; /* skip the inserted INV alignment */
+            }
+        }
     }
     *n_regs_ = n_regs;
     free(qseq0[0]);

@@ -162,7 +162,9 @@ def check_paf(paf_text, reads, genomes, best_n=5, with_cigar=True, sc=None, stat
         assert tname in genomes and tlen == len(genomes[tname]) and 0 <= ts < te <= tlen and strand in '+-', line[:80]
         assert 0 <= mapq <= 60
         t = tags_of(f[12:])
-        assert t['tp'] in ('P', 'S', 'I', 'i') and t['cm'] >= 1 and t['s1'] > 0 and t['rl'] >= 0
+        assert t['tp'] in ('P', 'S', 'I', 'i') and t['rl'] >= 0
+        # (an inversion hit is made from a local alignment, not from a chain: it carries no minimizers and no chaining score)
+        assert (t['cm'] >= 1 and t['s1'] > 0) or (t['tp'] in 'Ii' and t['cm'] == 0 and t['s1'] == 0), line[:120]
         assert ('s2' in t) == (t['tp'] in 'PI'), 's2 is reported for primaries only'
         if with_cigar:
             # tag order relied on by the reference's awk: NM at column 13, AS at column 15 (bin/lib/aligner.py:271-273)

@@ -130,6 +130,16 @@ def test_hard_reads_match_oracle(world):
         text = ''.join(want)
         assert 'zd:i:' in text, 'no split hit in the hard set'
         assert st['dp_rounds'] >= 2 and st['second_pass_jobs'] >= 1, st
+        # the read with a 1.2 kb inverted segment: the z-drop test's inversion probe cuts the hit there (second pass with
+        # zdrop_inv, the remainder marked split_inv) and mm_align1_inv aligns the segment on the opposite strand: a tp:A:I line
+        # between the two pieces, on the same target, on the other strand
+        inv = [l.split('\t') for l in got[names.index('inversion')].splitlines()]
+        lines_i = [f for f in inv if 'tp:A:I' in f]
+        assert len(lines_i) == 1 and len([f for f in inv if 'tp:A:P' in f]) == 2, inv
+        fi, prim = lines_i[0], sorted((f for f in inv if 'tp:A:P' in f), key=lambda f: int(f[2]))
+        assert fi[4] != prim[0][4] and fi[5] == prim[0][5] == prim[1][5]
+        assert int(prim[0][3]) <= int(fi[2]) < int(fi[3]) <= int(prim[1][2]) and int(prim[0][8]) <= int(fi[7]) < int(fi[8]) <= int(prim[1][7])
+        assert 1000 <= int(fi[3]) - int(fi[2]) <= 1300 and int(fi[11]) == 0 and 'cm:i:0' in fi
     assert text.count('\n') >= len(reads)
 
 
