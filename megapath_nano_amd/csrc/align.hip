@@ -639,11 +639,11 @@ struct Slot {
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
-    PoolBuf pool_probes, pool_sizes, pool_buckets, pool_tot, pool_pregs, pool_psum, pool_njobs, pool_joboff, pool_job_anchor;
+    PoolBuf pool_probes, pool_sizes, pool_buckets, pool_pregs, pool_psum, pool_job_anchor;
     PoolBuf pin_anchors{nullptr, 0, true}, pin_pregs{nullptr, 0, true};
-    PoolBuf pin_jobs{nullptr, 0, true}, pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true}, pin_cig{nullptr, 0, true};
+    PoolBuf pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
-    PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_jobs{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
+    PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
 };
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
@@ -1605,7 +1605,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
             for (const auto &c : S.arena.chunks) arena += c.cap;
             const size_t pools = S.pool_jobs.cap + S.pool_P.cap + S.pool_P2.cap + S.pool_OFF.cap + S.pool_order.cap + S.pool_state.cap + S.pool_CIG.cap +
                                  S.pool_res.cap + S.pool_redo.cap + S.pool_compact.cap + S.pool_used.cap;
-            const size_t pinned = S.pin_jobs.cap + S.pin_order.cap + S.pin_res.cap + S.pin_cig.cap + S.pin_chain_u.cap + S.pin_chain_b.cap;
+            const size_t pinned = S.pin_order.cap + S.pin_res.cap + S.pin_chain_u.cap + S.pin_chain_b.cap + S.pin_anchors.cap + S.pin_pregs.cap + S.pin_fin_cig.cap + S.pin_fin_out.cap;
             fprintf(stderr, "[slot %d] arena %.2f GB, pools %.2f GB (P %.2f, CIG %.2f, compact %.2f), pinned host %.2f GB\n", wdx, arena / 1e9,
                     pools / 1e9, S.pool_P.cap / 1e9, S.pool_CIG.cap / 1e9, S.pool_compact.cap / 1e9, pinned / 1e9);
         }
