@@ -1425,7 +1425,7 @@ static int default_host_threads(const mpn_map_opt *opt) {
     if (const char *e = getenv("MPN_HOST_THREADS")) return std::max(1, atoi(e));
     if (opt->host_threads > 0) return opt->host_threads;
     static const int detected = []() {
-        int n = std::min(32, std::max(1, (int)std::thread::hardware_concurrency()));
+        long long cores = std::max(1, (int)std::thread::hardware_concurrency());
         long long quota = -1, period = 100000;
         if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             char q[64] = {0};
@@ -1436,15 +1436,15 @@ static int default_host_threads(const mpn_map_opt *opt) {
             fclose(g);
             if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
         }
-        // twice the quota: the pool's threads mostly serve short bursts between GPU waits, and with the stray-hit filter the
-        // step is short enough that a burst waiting for a free pool thread costs more than the quota's throttling (measured
-        // on a 16-CPU quota: 16 threads 84.7, 24: 86.4, 32: 88.2, 48: 84.1 Gbp/min)
-        if (quota > 0 && period > 0) n = std::min(n, 2 * std::max(1, (int)((quota + period - 1) / period)));
+        if (quota > 0 && period > 0) cores = std::min(cores, std::max(1LL, (quota + period - 1) / period));
         // one process per GPU: the ranks of a node share its cores (bench.py / the launcher export the rank count)
         int ranks = 1;
         if (const char *e = getenv("MPN_RANKS_ON_NODE")) ranks = std::max(1, atoi(e));
         else if (const char *e2 = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e2));
-        n = std::max(2, n / ranks);
+        // twice this rank's share of the cores, at most 32: the pool's threads mostly serve short bursts between GPU waits, and a
+        // burst waiting for a free pool thread costs more than the quota's throttling (measured on a 16-CPU quota, one rank:
+        // 16 threads 84.7, 24: 86.4, 32: 88.2, 48: 84.1 Gbp/min); never fewer than 4 (a rank's host phases need ~4 cores)
+        const int n = (int)std::max(4LL, std::min(32LL, 2 * cores / ranks));
         return n;
     }();
     return detected;
