@@ -831,8 +831,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
 #undef MPN_WG_LAUNCH
         } else if (l < L_BAND) {  // called once per lane-group class with the class's whole (padded) range: l = first list of the class
             const int glc = (l - L_STRIP) / 16, per = 4 >> glc;
-            const int stride = std::max(T.strip_lds[glc], 16);
-            const size_t lds = (size_t)stride * per;
+            const int stride = (std::max(T.strip_lds[glc], 16) + 3) & ~3;
+            const size_t lds = (size_t)stride * per + STRIP_TAB_BYTES;
             if (glc == 0) hipLaunchKernelGGL(ext_dp_strip_kernel<16>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
             else if (glc == 1) hipLaunchKernelGGL(ext_dp_strip_kernel<32>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
             else hipLaunchKernelGGL(ext_dp_strip_kernel<64>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);

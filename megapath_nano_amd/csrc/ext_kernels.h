@@ -618,9 +618,10 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
 // finished one step earlier (one DPP wave_shr per state); query bases ride the same shift.
 // This kernel runs at the VALU issue limit, so the cell is written for instruction count:
 //  * one exec mask per step (j in range) instead of a predicate per cell;
-//  * the substitution score is a bit-field extract: each row keeps its five scores (vs A,C,G,T,N) as 6-bit fields of one
-//    register and the query base travels as the field offset;
-//  * the gap states are stored without their -(q+e) offset, which folds into the three-operand adds of the next cell;
+//  * the substitution score is one byte permute: the query base travels as the word of its four scores (against A, C, G, T) and
+//    each row keeps the selector of its target base;
+//  * the constants of the recurrences (gap open/extend offsets, candidate ranks, a bias that keeps the candidates positive) are
+//    folded into the stored states, so a candidate is ONE packed add and a new gap state ONE saturating packed subtract;
 //  * the direction is "first operand that equals the maximum": the states are pre-scaled by 8 and the candidates carry their rank in
 //    the low bits, so one max gives value and direction (stored as the rank, decoded by the traceback); the continuation flags come
 //    from the new gap states;
@@ -628,9 +629,10 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
 // Same recurrences, boundary rules and direction codes as ext_dp_kernel.  Directions are stored step-major: cell
 // (t, j) lives at [j + t/S][t], so the S bytes a lane produces in one step are contiguous and the whole wave writes one
 // contiguous row of n_lanes*S bytes per step (row-major dword stores cost 7x their bytes in HBM writes, measured).
-__host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {  // 6-bit signed fields
-    return mch >= -32 && mch <= 31 && mis >= -32 && mis <= 31 && amb >= -32 && amb <= 31;
+__host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {  // 8 * score + 4 + 128 is a byte
+    return mch >= -16 && mch <= 15 && mis >= -16 && mis <= 15 && amb >= -16 && amb <= 15;
 }
+constexpr int STRIP_TAB_BYTES = 32;   // the query score words, behind the groups' queries in LDS
 
 template <int S, int GL>
 __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, const int first,
@@ -653,7 +655,14 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     }
     const bool ok = jid >= 0 && qlen > 0 && tlen > 0 && !(-prm.sc_mis > 2 * (q + e));
     if (!ok) { qlen = 0; tlen = 0; }
-    // queries -> LDS as 6 * base code (the bit offset of the score field), one region per group, staged by the whole wave
+    // Scores travel as BYTES sb(s) = 8 s + 4 + 128 (the candidate "diagonal" of a cell, rank 4, biased to be unsigned): a
+    // query base is the word of its four scores against target A, C, G, T (tab[base]; an ambiguous base scores sc_n against
+    // everything), and a row picks its byte with one v_perm whose selector is the row's constant.
+    const uint32_t sb_mch = (uint32_t)(8 * prm.sc_mch + 132) & 0xff, sb_mis = (uint32_t)(8 * prm.sc_mis + 132) & 0xff,
+                   sb_n = (uint32_t)(8 * prm.sc_n + 132) & 0xff;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem + NG * lds_stride);   // (lds_stride is a multiple of 4)
+    if (lane < 5) tab[lane] = lane == 4 ? sb_n * 0x01010101u : (sb_mis * 0x01010101u) ^ ((sb_mch ^ sb_mis) << (8 * lane));
+    // queries -> LDS as 4 * base code (the byte offset of the base's word in tab), one region per group, staged by the whole wave
 #pragma unroll
     for (int g2 = 0; g2 < NG; ++g2) {
         const int ql = __builtin_amdgcn_readlane(qlen, g2 * GL);
@@ -662,7 +671,7 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
                       qs2 = __builtin_amdgcn_readlane(qs, g2 * GL);
             const int64_t roff = read_off[r2];
             const int32_t rlen = read_len[r2];
-            for (int i = lane; i < ql; i += 64) smem[g2 * lds_stride + i] = (uint8_t)(6 * ext_qbase(reads, roff, rlen, rv2, qs2 + i));
+            for (int i = lane; i < ql; i += 64) smem[g2 * lds_stride + i] = (uint8_t)(4 * ext_qbase(reads, roff, rlen, rv2, qs2 + i));
         }
     }
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
@@ -673,25 +682,29 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     // (the direction) -- no compare/select chain.  Differences stay far below 2^12, so the 16-bit halves do not overflow.
 #define MPN_BND(R) (8 * ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2))
     // Difference states as pairs of 16-bit lanes of one register (they are small integers): the two gap types of a cell go
-    // through v_pk_add/sub/max/min_i16 together.  UL: u of the previous column, both halves equal; YL: (y + (q+e) | y2 + (q2+e2))
-    // of the previous column, both start at 0.  Vp: v of the row above, both halves equal; Xp: (x + (q+e) | x2 + (q2+e2)).
+    // through the packed 16-bit instructions together.  The candidates of the max all carry the bias BETA (so that they are
+    // positive: the new gap states max(0, c - z - e) are then ONE unsigned saturating subtraction each), and the constants of
+    // the recurrences are folded into the stored states:
+    //   UL: u of the previous column + CU, both halves the same u;   YL: (y + (q+e) | y2 + (q2+e2)) of the previous column
+    //   Vp: v of the row above + CV;                                 Xp: (x + (q+e) | x2 + (q2+e2)), both start at 0
+    // with CV = (-8(q+e) + 3 | -8(q2+e2) + 1) + BETA and CU = (-8(q+e) + 2 | -8(q2+e2) + 0) + BETA, so that the candidates
+    // are plain sums: 8 (a | a2) + rank + BETA = Xp + Vp and 8 (b | b2) + rank + BETA = YL + UL.
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     auto bcast = [](int x) { return s16x2{(short)x, (short)x}; };
+    constexpr int BETA = 0x2000 + 128;   // the score byte's 128 and the 0x20 the perm puts above it
+    const s16x2 CV = {(short)(-8 * qe + 3 + BETA), (short)(-8 * qe2 + 1 + BETA)}, CU = {(short)(-8 * qe + 2 + BETA), (short)(-8 * qe2 + BETA)};
     s16x2 UL[S], YL[S];
-    uint32_t TB[S];
+    uint32_t TSEL[S];
     const int64_t g0 = ok ? rv.seq_off[rid] + ts : 0;
     const int t0 = gl * S;
-    const uint32_t f_mch = (uint32_t)prm.sc_mch & 63, f_mis = (uint32_t)prm.sc_mis & 63, f_n = (uint32_t)prm.sc_n & 63;
+    const uint32_t KONST = sb_n | 0x2000u;   // byte 0: the score against an ambiguous target base; byte 1: the high byte of every score
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const int t = t0 + k;
         const int sq = t < tlen ? ref_code(rv, g0 + t) : 4;
-        uint32_t tab = f_n << 24;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tab |= (sq == 4 ? f_n : sq == c ? f_mch : f_mis) << (6 * c);
-        TB[k] = tab;
-        UL[k] = bcast(MPN_BND(t));   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
+        TSEL[k] = 0x0c0c0100u | (sq < 4 ? 4u + (uint32_t)sq : 0u);   // v_perm(QT, KONST): byte 0 = QT[sq] or KONST[0], byte 1 = KONST[1]
+        UL[k] = bcast(MPN_BND(t)) + CU;   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
         YL[k] = s16x2{0, 0};
     }
     __syncthreads();
@@ -699,67 +712,74 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     const int max_steps = wave_reduce_max(ok ? qlen + n_lanes - 1 : 0);
     const uint8_t *qrow = smem + g * lds_stride;
     uint8_t *prow = P + p_off + t0;
-    int out_v = 0, out_x = 0, qsh = 24;
+    int out_v = 0, out_x = 0;
+    uint32_t qt = 0;   // the score word of the query base this lane works on
     int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
-    const s16x2 MQA = {(short)(-8 * qe + 3), (short)(-8 * qe2 + 1)}, MQB = {(short)(-8 * qe + 2), (short)(-8 * qe2)};
-    const s16x2 EP = {(short)(8 * e), (short)(8 * e2)}, ZERO = {0, 0};   // x(t, j+1) = max(0, a - (z - q)) with a = (x + v) - (q + e): the state is kept as x + (q + e)
+    const s16x2 ZERO = {0, 0};
+    // z + CU + CV (what the new u and v are subtracted from), and z + e + the offset of the candidate a gap state comes from
+    const s16x2 KZZ = {(short)(-16 * qe + 5 + BETA), (short)(-16 * qe2 + 1 + BETA)};
+    const s16x2 KEA = {(short)(8 * e - 8 * qe + 3), (short)(8 * e2 - 8 * qe2 + 1)}, KEB = {(short)(8 * e - 8 * qe + 2), (short)(8 * e2 - 8 * qe2)};
     const uint32_t EIGHT = 0x00080008u;
     const uint32_t RANK_CLR = 0xfff8fff8u;
-    const s16x2 MCH7 = {(short)(8 * prm.sc_mch + 7), (short)(8 * prm.sc_mch + 7)};
+    const uint32_t MCH7 = (uint32_t)(8 * prm.sc_mch + 7 + BETA) * 0x00010001u;
     const bool head = gl == 0;
+    // the head lane's query words, fetched two steps ahead (base code, then its word): two dependent LDS reads off the critical path
+    auto qcode = [&](int s_) -> uint32_t { return s_ < qlen ? (uint32_t)qrow[s_] : 16u; };
+    uint32_t qt_next = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + qcode(0));
+    uint32_t qc_next = qcode(1);
     for (int step = 0; step < max_steps; ++step) {
         // query bases and bottom-row states move one lane to the right; the first lane of a group takes the boundary
-        const int q_in = step < qlen ? (int)qrow[step] : 24;
-        const int qsh_s = wave_shr1(qsh, 24);
+        const uint32_t q_in = qt_next;
+        qt_next = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + qc_next);
+        qc_next = qcode(step + 2);
+        const uint32_t qt_s = (uint32_t)wave_shr1((int)qt, 0);
         const int v_s = wave_shr1(out_v, 0), x_s = wave_shr1(out_x, 0);
         const int j = step - gl;
         const int bj = MPN_BND(step);  // first lane: j = step
-        qsh = head ? q_in : qsh_s;
-        s16x2 Vp = head ? bcast(bj) : __builtin_bit_cast(s16x2, v_s), Xp = head ? ZERO : __builtin_bit_cast(s16x2, x_s);
+        qt = head ? q_in : qt_s;
+        s16x2 Vp = head ? bcast(bj) + CV : __builtin_bit_cast(s16x2, v_s), Xp = head ? ZERO : __builtin_bit_cast(s16x2, x_s);
         if (j >= 0 && j < qlen && gl < n_lanes) {
-            uint32_t dw[(S + 3) / 4], dcell[4] = {0, 0, 0, 0};
+            uint32_t dw[(S + 3) / 4], ecell[4] = {0, 0, 0, 0};
             int nv0 = 0;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                const int sc8 = __builtin_amdgcn_sbfe((int)TB[k], qsh, 6) * 8 + 4;
+                const uint32_t sc16 = __builtin_amdgcn_perm(qt, KONST, TSEL[k]);   // 8 s + 4 + BETA in the low half
                 const s16x2 Up = UL[k];
-                // clean sums first (multiples of 8), the rank-tagged candidates from them: the new gap states are taken from the
-                // clean sums, so no rank bits have to be masked out of them
-                const s16x2 Ac = Xp + Vp, Bc = YL[k] + Up;
-                s16x2 A = Ac + MQA, B = Bc + MQB;                // 8 (a | a2) + (3 | 1), 8 (b | b2) + (2 | 0)
+                const s16x2 A = Xp + Vp, B = YL[k] + Up;         // 8 (a | a2) + (3 | 1) + BETA, 8 (b | b2) + (2 | 0) + BETA
                 const s16x2 M = __builtin_elementwise_max(A, B);
                 // max of M's two halves and the score in ONE instruction: 16-bit three-operand max with the high half of M
                 // selected as its second operand (the result is the low 16 bits; everything after it reads those only)
                 uint32_t z16;
-                asm("v_max3_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(z16) : "v"(__builtin_bit_cast(uint32_t, M)), "v"(sc8));
-                const int d = (int)(z16 & 7);            // rank of the winner; the traceback reads the operand index as 4 - rank
-                // both halves = min(z, match score), rank bits cleared: one byte permute, one packed min, one mask
-                const s16x2 Zp = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, __builtin_elementwise_min(
-                                     __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(z16, 0u, 0x05040504u)), MCH7)) & RANK_CLR);
-                const s16x2 nu = Zp - Vp, nv = Zp - Up, ZE = Zp + EP;
-                A = __builtin_elementwise_max(Ac - ZE, ZERO);
-                B = __builtin_elementwise_max(Bc - ZE, ZERO);
+                asm("v_max3_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(z16) : "v"(__builtin_bit_cast(uint32_t, M)), "v"(sc16));
+                // both halves = min(z, match score) (the packed min reads z's low half for both), rank bits cleared
+                uint32_t zc;
+                asm("v_pk_min_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(zc) : "v"(z16), "v"(MCH7));
+                const s16x2 Zc = __builtin_bit_cast(s16x2, zc & RANK_CLR);   // 8 z + BETA
+                const s16x2 ZZ = Zc + KZZ;
+                const s16x2 nu = ZZ - Vp, nv = ZZ - Up;
+                // new gap states max(0, candidate - z - e): the candidates and z + e (+ the candidate's offset) are positive
+                const u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
+                const u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
                 // Continuation flags (x > 0) of the four gap states, which are multiples of 8: min(x, 8) as unsigned leaves bit 3
                 // of each half (written as the instruction: the compiler turns the expression into compares and selects).
-                // F: bit 3 a, 4 b, 19 a2, 20 b2; the byte is rank | F | F >> 14 -- its bits above 7 are dropped by the byte
-                // permutes that assemble four cells into a word.
+                // F: bit 3 a, 4 b, 19 a2, 20 b2; the cell's byte is rank | F | F >> 14, assembled four cells at a time below.
                 uint32_t HA, HB;
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, A)), "v"(EIGHT));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, B)), "v"(EIGHT));
-                const uint32_t F = HA | HB << 1;
-                dcell[k & 3] = (uint32_t)d | F | F >> 14;
-                UL[k] = nu; YL[k] = B;
-                Vp = nv; Xp = A;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, An)), "v"(EIGHT));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, Bn)), "v"(EIGHT));
+                ecell[k & 3] = (z16 & 7u) | (HA | HB << 1);   // rank of the winner (the traceback reads the operand index as 4 - rank) and F
+                UL[k] = nu; YL[k] = __builtin_bit_cast(s16x2, Bn);
+                Vp = nv; Xp = __builtin_bit_cast(s16x2, An);
                 if ((k & 3) == 3 || k == S - 1) {
-                    // bytes 0 of up to four cells -> one word (0x0c selects a zero byte)
-                    const uint32_t lo = __builtin_amdgcn_perm((k & 3) >= 1 ? dcell[1] : 0u, dcell[0], 0x0c0c0400u);
-                    const uint32_t hi = (k & 3) >= 2 ? __builtin_amdgcn_perm((k & 3) == 3 ? dcell[3] : 0u, dcell[2], 0x04000c0cu) : 0u;
-                    dw[k >> 2] = lo | hi;
+                    // bytes 0 (rank, a, b) and bytes 2 (a2, b2) of up to four cells -> one word each, then hi << 2 joins lo
+                    const uint32_t e01 = (k & 3) >= 1 ? (ecell[1] << 8 | ecell[0]) : ecell[0];
+                    const uint32_t e23 = (k & 3) == 3 ? (ecell[3] << 8 | ecell[2]) : (k & 3) == 2 ? ecell[2] : 0u;
+                    const uint32_t lo = __builtin_amdgcn_perm(e23, e01, 0x05040100u), hi = __builtin_amdgcn_perm(e23, e01, 0x07060302u);
+                    dw[k >> 2] = lo | hi << 2;
                 }
                 if (k == 0) nv0 = (int)nv.x;
             }
             out_v = __builtin_bit_cast(int, Vp); out_x = __builtin_bit_cast(int, Xp);
-            row0 += nv0;
+            row0 += nv0 - (int)CV.x;
             uint8_t *dst = prow + (int64_t)step * W;  // p_off is 16-aligned, W and t0 are multiples of S
             if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
             else if constexpr (S == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(dw[0], dw[1]);
@@ -777,7 +797,7 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     // (the sums are of pre-scaled differences, exact multiples of 8)
     int32_t tot = head ? row0 - 8 * qe : 0;
 #pragma unroll
-    for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x : 0;
+    for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x - (int)CU.x : 0;
 #pragma unroll
     for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
     tot >>= 3;
