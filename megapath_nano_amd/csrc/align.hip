@@ -791,6 +791,24 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
         for (int l = 0; l < N_LISTS; ++l)
             if (cnt[l]) fprintf(stderr, "[jobs] %s list %-2d n=%d\n", fam[l < L_WG ? 0 : l < L_STRIP ? 1 : l < L_BAND ? 2 : 3], l, cnt[l]);
     }
+    if (const char *dump = getenv("MPN_DUMP_STRIPS")) {   // debug: the geometry of the strip launch lists, in launch order
+        const int n_ord = base[L_BAND] - base[L_STRIP];
+        std::vector<int32_t> ord(n_ord);
+        std::vector<ExtJob> hj(nj);
+        MPN_HIP_CHECK(hipMemcpy(ord.data(), d_order.p + base[L_STRIP], (size_t)n_ord * 4, hipMemcpyDeviceToHost));
+        MPN_HIP_CHECK(hipMemcpy(hj.data(), d_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyDeviceToHost));
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (FILE *f = fopen(dump, "ab")) {
+            for (int l = L_STRIP; l < L_BAND; ++l)
+                for (int k = base[l]; k < base[l + 1]; ++k) {
+                    const int jid = ord[k - base[L_STRIP]];
+                    const int32_t rec[4] = {(l - L_STRIP) / 16, jid >= 0 ? hj[jid].qlen : 0, jid >= 0 ? hj[jid].tlen : 0, jid >= 0 ? hj[jid].strip_s : 0};
+                    fwrite(rec, 4, 4, f);
+                }
+            fclose(f);
+        }
+    }
     if (SL.pool_P.ensure((size_t)T.p_tot + 16) || SL.pool_OFF.ensure((size_t)T.row_tot * 2 * 4 + 16) ||
         SL.pool_state.ensure((size_t)T.state_tot + 16) || SL.pool_CIG.ensure((size_t)T.cig_tot * 4 + 16))
         return -1;

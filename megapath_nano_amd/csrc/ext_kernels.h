@@ -766,15 +766,20 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
                 uint32_t HA, HB;
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, An)), "v"(EIGHT));
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, Bn)), "v"(EIGHT));
-                ecell[k & 3] = (z16 & 7u) | (HA | HB << 1);   // rank of the winner (the traceback reads the operand index as 4 - rank) and F
+                // rank of the winner (the traceback reads the operand index as 4 - rank) and F.  (Written as the two instructions:
+                // left to itself the compiler spreads the shifts of this and of the packing below over more of them.)
+                uint32_t Fw;
+                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(Fw) : "v"(HB), "v"(HA));
+                asm("v_and_or_b32 %0, %1, 7, %2" : "=v"(ecell[k & 3]) : "v"(z16), "v"(Fw));
                 UL[k] = nu; YL[k] = __builtin_bit_cast(s16x2, Bn);
                 Vp = nv; Xp = __builtin_bit_cast(s16x2, An);
                 if ((k & 3) == 3 || k == S - 1) {
                     // bytes 0 (rank, a, b) and bytes 2 (a2, b2) of up to four cells -> one word each, then hi << 2 joins lo
-                    const uint32_t e01 = (k & 3) >= 1 ? (ecell[1] << 8 | ecell[0]) : ecell[0];
-                    const uint32_t e23 = (k & 3) == 3 ? (ecell[3] << 8 | ecell[2]) : (k & 3) == 2 ? ecell[2] : 0u;
+                    uint32_t e01 = ecell[0], e23 = (k & 3) >= 2 ? ecell[2] : 0u;
+                    if ((k & 3) >= 1) asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(e01) : "v"(ecell[1]), "v"(ecell[0]));
+                    if ((k & 3) == 3) asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(e23) : "v"(ecell[3]), "v"(ecell[2]));
                     const uint32_t lo = __builtin_amdgcn_perm(e23, e01, 0x05040100u), hi = __builtin_amdgcn_perm(e23, e01, 0x07060302u);
-                    dw[k >> 2] = lo | hi << 2;
+                    asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(dw[k >> 2]) : "v"(hi), "v"(lo));
                 }
                 if (k == 0) nv0 = (int)nv.x;
             }
