@@ -747,6 +747,10 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     WallTimer wt;
     Slot &SL = *tl_slot;
     const int strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi) ? 1 : 0;
+    ExtParams prm;
+    prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
+    prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
+    prm.zdrop_inv = opt->zdrop_inv; prm.max_gap = opt->max_gap;
     const size_t order_cap = (size_t)nj + (size_t)N_STRIP * 4 + 16;
     if (SL.pool_sizes.ensure((size_t)nj * sizeof(JobSizes) + 16) || SL.pool_buckets.ensure((size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals) + 16) ||
         SL.pool_order.ensure(order_cap * 4) || SL.pin_res.ensure(sizeof(LayoutTotals) + 64) ||
@@ -762,7 +766,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     MPN_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals), st));
     const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256));   // (a block per CU: every block flushes its counters once)
     EvTimer evl(st);
-    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, g_force_kernel, d_sizes, d_bcnt, d_tot);
+    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, prm, g_force_kernel, d_sizes, d_bcnt, d_tot);
     hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, d_nj, (const int32_t *)d_bcnt, d_bcur, d_tot, d_order.p);
     hipLaunchKernelGGL(job_layout_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, (const JobSizes *)d_sizes, d_bcur, d_order.p);
     MPN_HIP_CHECK(hipGetLastError());
@@ -786,6 +790,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     const int *cnt = T.cnt, *base = T.base;
     g_stats[4] += nj; g_stats[5] += T.cells; g_stats[31] += T.strip_cells[0] + T.strip_cells[1] + T.strip_cells[2];
     for (int c = 0; c < 3; ++c) g_stats[41 + c] += T.strip_cells[c];
+    g_stats[58] += T.xstrip_cells;
     if (getenv("MPN_DEBUG_JOBS")) {
         static const char *const fam[] = {"lds", "wg", "strip", "band"};
         for (int l = 0; l < N_LISTS; ++l)
@@ -799,11 +804,19 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
         MPN_HIP_CHECK(hipMemcpy(hj.data(), d_jobs.p, (size_t)nj * sizeof(ExtJob), hipMemcpyDeviceToHost));
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
+        if (const char *all = getenv("MPN_DUMP_JOBS"))   // ... and every window of the group: list, sizes, band, flags
+            if (FILE *f = fopen(all, "ab")) {
+                for (int j = 0; j < nj; ++j) {
+                    const int32_t rec[6] = {hj[j].cls, hj[j].qlen, hj[j].tlen, hj[j].w, hj[j].flag, hj[j].n_col};
+                    fwrite(rec, 4, 6, f);
+                }
+                fclose(f);
+            }
         if (FILE *f = fopen(dump, "ab")) {
             for (int l = L_STRIP; l < L_BAND; ++l)
                 for (int k = base[l]; k < base[l + 1]; ++k) {
                     const int jid = ord[k - base[L_STRIP]];
-                    const int32_t rec[4] = {(l - L_STRIP) / 16, jid >= 0 ? hj[jid].qlen : 0, jid >= 0 ? hj[jid].tlen : 0, jid >= 0 ? hj[jid].strip_s : 0};
+                    const int32_t rec[4] = {strip_glc_of_list(l), jid >= 0 ? hj[jid].qlen : 0, jid >= 0 ? hj[jid].tlen : 0, jid >= 0 ? hj[jid].strip_s : 0};
                     fwrite(rec, 4, 4, f);
                 }
             fclose(f);
@@ -824,10 +837,6 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     InvProbe *d_probes = SL.pool_probes.as<InvProbe>();
     MPN_HIP_CHECK(hipMemsetAsync(d_used + 1, 0, 8, st));
     MPN_HIP_CHECK(hipMemsetAsync(d_used + 5, 0, 8, st));
-    ExtParams prm;
-    prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
-    prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
-    prm.zdrop_inv = opt->zdrop_inv; prm.max_gap = opt->max_gap;
     // one launch of launch list `l` over ord[0..n)
     auto launch_list = [&](int l, const int32_t *ord, int n, hipStream_t s) -> int {
         if (n == 0) return 0;
@@ -848,12 +857,21 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
 #undef MPN_WG_LAUNCH
         } else if (l < L_BAND) {  // called once per lane-group class with the class's whole (padded) range: l = first list of the class
-            const int glc = (l - L_STRIP) / 16, per = 4 >> glc;
-            const int stride = (std::max(T.strip_lds[glc], 16) + 3) & ~3;
-            const size_t lds = (size_t)stride * per + STRIP_TAB_BYTES;
-            if (glc == 0) hipLaunchKernelGGL(ext_dp_strip_kernel<16>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
-            else if (glc == 1) hipLaunchKernelGGL(ext_dp_strip_kernel<32>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
-            else hipLaunchKernelGGL(ext_dp_strip_kernel<64>, dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, d_res.p, stride);
+            const int sclass = (l - L_STRIP) / 16, glc = sclass % 3, variant = sclass / 3, per = 4 >> glc;
+            const int stride = (std::max(T.strip_lds[sclass], 16) + 3) & ~3;
+            // exact variants: a slot per anti-diagonal and the E4 table per window (+ 16: the rows that pad the last strip)
+            const int nr_stride = variant ? T.strip_nr[sclass] + 16 : 0;
+            const size_t lds = (size_t)stride * per + STRIP_TAB_BYTES + (size_t)per * 8 * nr_stride;
+#define MPN_STRIP_LAUNCH(GLN, EX, RT)                                                                                                \
+            do {                                                                                                                      \
+                if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_strip_kernel<GLN, EX, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL((ext_dp_strip_kernel<GLN, EX, RT>), dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, \
+                                   d_read_len, rv, P.p, d_res.p, stride, nr_stride);                                                  \
+            } while (0)
+#define MPN_STRIP_GL(EX, RT) do { if (glc == 0) MPN_STRIP_LAUNCH(16, EX, RT); else if (glc == 1) MPN_STRIP_LAUNCH(32, EX, RT); else MPN_STRIP_LAUNCH(64, EX, RT); } while (0)
+            if (variant == 0) MPN_STRIP_GL(false, false); else if (variant == 1) MPN_STRIP_GL(true, false); else MPN_STRIP_GL(true, true);
+#undef MPN_STRIP_GL
+#undef MPN_STRIP_LAUNCH
         } else {
             const int bvar = (l - L_BAND) / 4;
             const size_t lds = std::max<size_t>((size_t)T.band_lds[(l - L_BAND) % 4], 64);
@@ -910,7 +928,9 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
         if (l >= L_STRIP && l < L_BAND) {  // one launch per lane-group class: its 16 height lists are contiguous
             if ((l - L_STRIP) % 16 == 0) {
                 if (launch_list(l, d_order.p + base[l], base[l + 16] - base[l], st)) return -1;
-                ev.mark(9, 38 + (l - L_STRIP) / 16);  // every strip instantiation is timed on its own
+                const int sclass = (l - L_STRIP) / 16;
+                if (sclass < 3) ev.mark(9, 38 + sclass);  // every gap-fill strip instantiation is timed on its own
+                else ev.mark(57);                          // the exact variants (end extensions) together
             }
         } else if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
     }

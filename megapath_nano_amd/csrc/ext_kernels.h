@@ -633,13 +633,33 @@ __host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {
     return mch >= -16 && mch <= 15 && mis >= -16 && mis <= 15 && amb >= -16 && amb <= 15;
 }
 constexpr int STRIP_TAB_BYTES = 32;   // the query score words, behind the groups' queries in LDS
+// EXACT windows (end extensions, exact global fills): is 8 H + 32768 a 16-bit number for every cell (see the H bookkeeping in
+// ext_strip_pack)?  -(gap of t+1) - (gap of j+1) <= H(t, j) <= match * min(t+1, j+1); the tie-break key holds t in 10 bits.
+__host__ __device__ inline bool ext_strip_exact_ok(int mch, int q, int e, int q2, int e2, int qlen, int tlen) {
+    const int L = (qlen > tlen ? qlen : tlen) + 1;
+    const int c1 = q + e * L, c2 = q2 + e2 * L;
+    return tlen <= 1024 && 16 * (c1 < c2 ? c1 : c2) < 32000 && 8 * mch * L < 32000;
+}
 
-template <int S, int GL>
+// EXACT = the ksw2 "exact" bookkeeping of the end extensions (and exact global fills): the maximum of every anti-diagonal with
+// ksw2's tie order, the z-drop rule over the anti-diagonals in order, the best score of the last query column.  The systolic
+// array does not visit the cells in anti-diagonal order, so the rule is applied AFTER the matrix is done:
+//  * every cell carries its H (one packed add of the horizontal difference per cell; H(t, -1) is the closed form of the
+//    first-column boundary) and merges (H, tie-break key) into its anti-diagonal's slot in LDS with one ds_max_u32: the word is
+//    (8 H + 32768) << 10 | (8191 - key), key = ksw2's lane class << 10 | t, the band's last cell (which wins every tie) 8191;
+//  * the last query column is what the lane's H registers hold when it stops;
+//  * then the lanes of the group walk the anti-diagonals in chunks: running maximum by a prefix scan over the lanes, the first
+//    anti-diagonal that z-drops by a minimum over the lanes, the state before it by a second scan.  Cells past the z-drop were
+//    computed for nothing (an end-extension window is small); the traceback starts where ksw2's would.
+// RIGHT = right-aligned gaps (KSW_EZ_RIGHT, the left extension): the later operand wins a tie -- the ranks of the five
+// candidates are reversed (the traceback reads the operand index as the rank itself) -- and a gap continues when its state
+// is >= 0, not > 0: the new gap state is computed one unit (8) high, flagged, and brought down by a second saturating subtract.
+template <int S, int GL, bool EXACT, bool RIGHT>
 __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, const int first,
                                                const int n_list, const ExtParams &prm, const uint8_t *__restrict__ reads,
                                                const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                                                const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem,
-                                               const int lds_stride) {
+                                               const int lds_stride, const int nr_stride) {
     constexpr int NG = 64 / GL;  // windows per wave: each takes a group of GL lanes
     const int lane = threadIdx.x, g = lane / GL, gl = lane % GL;
     const int jid = first + g < n_list ? order[first + g] : -1;  // -1: padding at the end of a launch list
@@ -647,19 +667,23 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
     const int qe = q + e, qe2 = q2 + e2;
     // the group's window, one copy per lane
-    int qlen = 0, tlen = 0, W = 0, rd = 0, rid = 0, rev = 0, qs = 0, ts = 0;
+    int qlen = 0, tlen = 0, W = 0, rd = 0, rid = 0, rev = 0, qs = 0, ts = 0, back = 0, zdrop = -1, end_bonus = 0, jflag = 0;
     int64_t p_off = 0;
     if (jid >= 0) {
         const ExtJob &jb = jobs[jid];
         qlen = jb.qlen; tlen = jb.tlen; W = jb.qstride; rd = jb.read; rid = jb.rid; rev = jb.rev; qs = jb.qs; ts = jb.ts; p_off = jb.p_off;
+        back = jb.reversed; zdrop = jb.zdrop; end_bonus = jb.end_bonus; jflag = jb.flag;
     }
     const bool ok = jid >= 0 && qlen > 0 && tlen > 0 && !(-prm.sc_mis > 2 * (q + e));
     if (!ok) { qlen = 0; tlen = 0; }
-    // Scores travel as BYTES sb(s) = 8 s + 4 + 128 (the candidate "diagonal" of a cell, rank 4, biased to be unsigned): a
+    // ranks of the five candidates in the low three bits: the max then prefers the earlier operand (score, a, b, a2, b2) on a
+    // tie, or the later one for right-aligned gaps
+    constexpr int RS = RIGHT ? 0 : 4, RA = RIGHT ? 1 : 3, RB = 2, RA2 = RIGHT ? 3 : 1, RB2 = RIGHT ? 4 : 0;
+    // Scores travel as BYTES sb(s) = 8 s + rank + 128 (the candidate "diagonal" of a cell, biased to be unsigned): a
     // query base is the word of its four scores against target A, C, G, T (tab[base]; an ambiguous base scores sc_n against
     // everything), and a row picks its byte with one v_perm whose selector is the row's constant.
-    const uint32_t sb_mch = (uint32_t)(8 * prm.sc_mch + 132) & 0xff, sb_mis = (uint32_t)(8 * prm.sc_mis + 132) & 0xff,
-                   sb_n = (uint32_t)(8 * prm.sc_n + 132) & 0xff;
+    const uint32_t sb_mch = (uint32_t)(8 * prm.sc_mch + RS + 128) & 0xff, sb_mis = (uint32_t)(8 * prm.sc_mis + RS + 128) & 0xff,
+                   sb_n = (uint32_t)(8 * prm.sc_n + RS + 128) & 0xff;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem + NG * lds_stride);   // (lds_stride is a multiple of 4)
     if (lane < 5) tab[lane] = lane == 4 ? sb_n * 0x01010101u : (sb_mis * 0x01010101u) ^ ((sb_mch ^ sb_mis) << (8 * lane));
     // queries -> LDS as 4 * base code (the byte offset of the base's word in tab), one region per group, staged by the whole wave
@@ -668,18 +692,19 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         const int ql = __builtin_amdgcn_readlane(qlen, g2 * GL);
         if (ql > 0) {
             const int r2 = __builtin_amdgcn_readlane(rd, g2 * GL), rv2 = __builtin_amdgcn_readlane(rev, g2 * GL),
-                      qs2 = __builtin_amdgcn_readlane(qs, g2 * GL);
+                      qs2 = __builtin_amdgcn_readlane(qs, g2 * GL), bk2 = __builtin_amdgcn_readlane(back, g2 * GL);
             const int64_t roff = read_off[r2];
             const int32_t rlen = read_len[r2];
-            for (int i = lane; i < ql; i += 64) smem[g2 * lds_stride + i] = (uint8_t)(4 * ext_qbase(reads, roff, rlen, rv2, qs2 + i));
+            for (int i = lane; i < ql; i += 64)
+                smem[g2 * lds_stride + i] = (uint8_t)(4 * ext_qbase(reads, roff, rlen, rv2, qs2 + (bk2 ? ql - 1 - i : i)));
         }
     }
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-    // All states are kept PRE-SCALED by 8: the low three bits of the five candidates of a cell then carry their rank (score
-    // 4, a 3, b 2, a2 1, b2 0), so ONE max yields both the cell's value and "the first operand that equals the maximum"
-    // (the direction) -- no compare/select chain.  Differences stay far below 2^12, so the 16-bit halves do not overflow.
+    // All states are kept PRE-SCALED by 8: the low three bits of the five candidates of a cell then carry their rank, so ONE
+    // max yields both the cell's value and which operand won (the direction) -- no compare/select chain.  Differences stay
+    // far below 2^12, so the 16-bit halves do not overflow.
 #define MPN_BND(R) (8 * ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2))
     // Difference states as pairs of 16-bit lanes of one register (they are small integers): the two gap types of a cell go
     // through the packed 16-bit instructions together.  The candidates of the max all carry the bias BETA (so that they are
@@ -687,25 +712,45 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     // the recurrences are folded into the stored states:
     //   UL: u of the previous column + CU, both halves the same u;   YL: (y + (q+e) | y2 + (q2+e2)) of the previous column
     //   Vp: v of the row above + CV;                                 Xp: (x + (q+e) | x2 + (q2+e2)), both start at 0
-    // with CV = (-8(q+e) + 3 | -8(q2+e2) + 1) + BETA and CU = (-8(q+e) + 2 | -8(q2+e2) + 0) + BETA, so that the candidates
-    // are plain sums: 8 (a | a2) + rank + BETA = Xp + Vp and 8 (b | b2) + rank + BETA = YL + UL.
+    // with CV = (-8(q+e) + rank a | -8(q2+e2) + rank a2) + BETA and CU = (-8(q+e) + rank b | -8(q2+e2) + rank b2) + BETA, so that
+    // the candidates are plain sums: 8 (a | a2) + rank + BETA = Xp + Vp and 8 (b | b2) + rank + BETA = YL + UL.
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     auto bcast = [](int x) { return s16x2{(short)x, (short)x}; };
     constexpr int BETA = 0x2000 + 128;   // the score byte's 128 and the 0x20 the perm puts above it
-    const s16x2 CV = {(short)(-8 * qe + 3 + BETA), (short)(-8 * qe2 + 1 + BETA)}, CU = {(short)(-8 * qe + 2 + BETA), (short)(-8 * qe2 + BETA)};
+    const s16x2 CV = {(short)(-8 * qe + RA + BETA), (short)(-8 * qe2 + RA2 + BETA)}, CU = {(short)(-8 * qe + RB + BETA), (short)(-8 * qe2 + RB2 + BETA)};
     s16x2 UL[S], YL[S];
     uint32_t TSEL[S];
+    uint32_t Hh[EXACT ? S : 1];   // EXACT: low half = 8 H(t, j) + (j + 1) CV.lo of the lane's current column (mod 2^16)
     const int64_t g0 = ok ? rv.seq_off[rid] + ts : 0;
     const int t0 = gl * S;
     const uint32_t KONST = sb_n | 0x2000u;   // byte 0: the score against an ambiguous target base; byte 1: the high byte of every score
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const int t = t0 + k;
-        const int sq = t < tlen ? ref_code(rv, g0 + t) : 4;
+        const int sq = t < tlen ? ref_code(rv, g0 + (back ? tlen - 1 - t : t)) : 4;
         TSEL[k] = 0x0c0c0100u | (sq < 4 ? 4u + (uint32_t)sq : 0u);   // v_perm(QT, KONST): byte 0 = QT[sq] or KONST[0], byte 1 = KONST[1]
         UL[k] = bcast(MPN_BND(t)) + CU;   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
         YL[k] = s16x2{0, 0};
+        if constexpr (EXACT) {
+            // H(t, -1): the sum of the boundary differences above
+            const int h = t < long_thres ? -(q + e * (t + 1)) : -(q2 + e2 * (t + 1));
+            Hh[k] = (uint32_t)(8 * h) & 0xffffu;
+        }
+    }
+    // EXACT: per group, a slot per anti-diagonal (BEST) and the table E4[r] = (cells of anti-diagonal r - 1) & ~3, the part of the
+    // band ksw2 covers with whole 4-lane vectors; E4's space holds the last query column afterwards
+    uint32_t *BEST = nullptr, *E4T = nullptr;
+    const int n_r = ok ? qlen + tlen - 1 : 0;
+    if constexpr (EXACT) {
+        BEST = reinterpret_cast<uint32_t *>(smem + NG * lds_stride + STRIP_TAB_BYTES) + (size_t)g * 2 * nr_stride;
+        E4T = BEST + nr_stride;
+        const int mn = (qlen < tlen ? qlen : tlen) - 1;
+        for (int r = gl; r < nr_stride; r += GL) {
+            const int c = min(min(r, n_r - 1 - r), mn);
+            BEST[r] = 0;
+            E4T[r] = c > 0 ? (uint32_t)c & ~3u : 0u;
+        }
     }
     __syncthreads();
     const int n_lanes = (tlen + S - 1) / S;
@@ -717,12 +762,16 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
     const s16x2 ZERO = {0, 0};
     // z + CU + CV (what the new u and v are subtracted from), and z + e + the offset of the candidate a gap state comes from
-    const s16x2 KZZ = {(short)(-16 * qe + 5 + BETA), (short)(-16 * qe2 + 1 + BETA)};
-    const s16x2 KEA = {(short)(8 * e - 8 * qe + 3), (short)(8 * e2 - 8 * qe2 + 1)}, KEB = {(short)(8 * e - 8 * qe + 2), (short)(8 * e2 - 8 * qe2)};
+    // (right-aligned gaps: one unit lower, so that the flag sees state >= 0)
+    constexpr int RU = RIGHT ? 8 : 0;
+    const s16x2 KZZ = {(short)(-16 * qe + RA + RB + BETA), (short)(-16 * qe2 + RA2 + RB2 + BETA)};
+    const s16x2 KEA = {(short)(8 * e - 8 * qe + RA - RU), (short)(8 * e2 - 8 * qe2 + RA2 - RU)},
+                KEB = {(short)(8 * e - 8 * qe + RB - RU), (short)(8 * e2 - 8 * qe2 + RB2 - RU)};
     const uint32_t EIGHT = 0x00080008u;
     const uint32_t RANK_CLR = 0xfff8fff8u;
     const uint32_t MCH7 = (uint32_t)(8 * prm.sc_mch + 7 + BETA) * 0x00010001u;
     const bool head = gl == 0;
+    const int tlm1 = tlen - 1;
     // the head lane's query words, fetched two steps ahead (base code, then its word): two dependent LDS reads off the critical path
     auto qcode = [&](int s_) -> uint32_t { return s_ < qlen ? (uint32_t)qrow[s_] : 16u; };
     uint32_t qt_next = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + qcode(0));
@@ -741,11 +790,16 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         if (j >= 0 && j < qlen && gl < n_lanes) {
             uint32_t dw[(S + 3) / 4], ecell[4] = {0, 0, 0, 0};
             int nv0 = 0;
+            // EXACT: what turns a lane's H register into 8 H + 32768 in this column, t - st of the rows below the query's end,
+            // the anti-diagonal slots of the lane's first row
+            const uint32_t offj = (uint32_t)((j + 1) * (int)CV.x - 32768);
+            const int qm1j = qlen - 1 - j;
+            uint32_t *bslot = EXACT ? BEST + (t0 + j) : nullptr;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                const uint32_t sc16 = __builtin_amdgcn_perm(qt, KONST, TSEL[k]);   // 8 s + 4 + BETA in the low half
+                const uint32_t sc16 = __builtin_amdgcn_perm(qt, KONST, TSEL[k]);   // 8 s + rank + BETA in the low half
                 const s16x2 Up = UL[k];
-                const s16x2 A = Xp + Vp, B = YL[k] + Up;         // 8 (a | a2) + (3 | 1) + BETA, 8 (b | b2) + (2 | 0) + BETA
+                const s16x2 A = Xp + Vp, B = YL[k] + Up;         // 8 (a | a2) + ranks + BETA, 8 (b | b2) + ranks + BETA
                 const s16x2 M = __builtin_elementwise_max(A, B);
                 // max of M's two halves and the score in ONE instruction: 16-bit three-operand max with the high half of M
                 // selected as its second operand (the result is the low 16 bits; everything after it reads those only)
@@ -758,21 +812,35 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
                 const s16x2 ZZ = Zc + KZZ;
                 const s16x2 nu = ZZ - Vp, nv = ZZ - Up;
                 // new gap states max(0, candidate - z - e): the candidates and z + e (+ the candidate's offset) are positive
-                const u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
-                const u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
-                // Continuation flags (x > 0) of the four gap states, which are multiples of 8: min(x, 8) as unsigned leaves bit 3
+                u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
+                u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
+                // Continuation flags (x > 0, or x >= 0 for right-aligned gaps: there An, Bn are still one unit high) of the four
+                // gap states, which are multiples of 8: min(x, 8) as unsigned leaves bit 3
                 // of each half (written as the instruction: the compiler turns the expression into compares and selects).
                 // F: bit 3 a, 4 b, 19 a2, 20 b2; the cell's byte is rank | F | F >> 14, assembled four cells at a time below.
                 uint32_t HA, HB;
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, An)), "v"(EIGHT));
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, Bn)), "v"(EIGHT));
-                // rank of the winner (the traceback reads the operand index as 4 - rank) and F.  (Written as the two instructions:
-                // left to itself the compiler spreads the shifts of this and of the packing below over more of them.)
+                if constexpr (RIGHT) {
+                    An = __builtin_elementwise_sub_sat(An, __builtin_bit_cast(u16x2, EIGHT));
+                    Bn = __builtin_elementwise_sub_sat(Bn, __builtin_bit_cast(u16x2, EIGHT));
+                }
+                // rank of the winner (the traceback reads the operand index as 4 - rank, or as the rank for right-aligned gaps)
+                // and F.  (Written as the two instructions: left to itself the compiler spreads the shifts of this and of the
+                // packing below over more of them.)
                 uint32_t Fw;
                 asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(Fw) : "v"(HB), "v"(HA));
                 asm("v_and_or_b32 %0, %1, 7, %2" : "=v"(ecell[k & 3]) : "v"(z16), "v"(Fw));
                 UL[k] = nu; YL[k] = __builtin_bit_cast(s16x2, Bn);
                 Vp = nv; Xp = __builtin_bit_cast(s16x2, An);
+                if constexpr (EXACT) {
+                    Hh[k] += __builtin_bit_cast(uint32_t, nv);
+                    const uint32_t hb = (Hh[k] - offj) & 0xffffu;            // 8 H(t, j) + 32768
+                    const int t = t0 + k, m = min(t, qm1j);                  // m = t - (first cell of the anti-diagonal)
+                    uint32_t inv = (m < (int)E4T[t0 + j + k] ? ~((uint32_t)m << 10) & 0xc00u : (uint32_t)-1024) + (uint32_t)(4095 - t);
+                    inv = (j == 0 || t == tlm1) ? 8191u : inv;                // the band's last cell
+                    atomicMax(bslot + k, t <= tlm1 ? hb * 1024u + inv : 0u);  // (0: a row that pads the last strip)
+                }
                 if ((k & 3) == 3 || k == S - 1) {
                     // bytes 0 (rank, a, b) and bytes 2 (a2, b2) of up to four cells -> one word each, then hi << 2 joins lo
                     uint32_t e01 = ecell[0], e23 = (k & 3) >= 2 ? ecell[2] : 0u;
@@ -798,20 +866,95 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         }
     }
 #undef MPN_BND
-    // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1); a lane's UL froze at its last column
-    // (the sums are of pre-scaled differences, exact multiples of 8)
-    int32_t tot = head ? row0 - 8 * qe : 0;
+    if constexpr (!EXACT) {
+        // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1); a lane's UL froze at its last column
+        // (the sums are of pre-scaled differences, exact multiples of 8)
+        int32_t tot = head ? row0 - 8 * qe : 0;
 #pragma unroll
-    for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x - (int)CU.x : 0;
+        for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x - (int)CU.x : 0;
 #pragma unroll
-    for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
-    tot >>= 3;
-    if (head && jid >= 0) {
-        ExtRes out;
-        out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = ok ? tot : NEG_INF;
-        out.reach_end = 0; out.n_cigar = 0; out.r_done = ok ? qlen + tlen - 2 : -1; out.zcode = 0; out.cig_pos = 0;
-        out.do_bt = ok ? 1 : 0; out.bt_i = ok ? tlen - 1 : -1; out.bt_j = ok ? qlen - 1 : -1;
-        res[jid] = out;
+        for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
+        tot >>= 3;
+        if (head && jid >= 0) {
+            ExtRes out;
+            out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = ok ? tot : NEG_INF;
+            out.reach_end = 0; out.n_cigar = 0; out.r_done = ok ? qlen + tlen - 2 : -1; out.zcode = 0; out.cig_pos = 0;
+            out.do_bt = ok ? 1 : 0; out.bt_i = ok ? tlen - 1 : -1; out.bt_j = ok ? qlen - 1 : -1;
+            res[jid] = out;
+        }
+    } else {
+        // ---- the z-drop rule over the anti-diagonals, in order ----
+        __syncthreads();   // every slot has its maximum
+        // the last query column: a lane's H registers froze there.  HL[t] = H(t, qlen - 1) + 4096, over the E4 table
+        uint32_t *HL = E4T;
+        {
+            const uint32_t offl = (uint32_t)(qlen * (int)CV.x - 32768);
+#pragma unroll
+            for (int k = 0; k < S; ++k) if (t0 + k < tlen) HL[t0 + k] = ((Hh[k] - offl) & 0xffffu) >> 3;
+        }
+        __syncthreads();
+        struct Best { int m, t, r; };   // a maximum, its target position and its anti-diagonal (its place in walking order)
+        // first strict maximum in walking order over the lanes of the group: inclusive scan, the later lane wins only when greater
+        auto scan_first_max = [&](Best x) {
+#pragma unroll
+            for (int d = 1; d < GL; d <<= 1) {
+                const Best o{__shfl_up(x.m, d, GL), __shfl_up(x.t, d, GL), __shfl_up(x.r, d, GL)};
+                if (gl >= d && !(x.m > o.m)) x = o;
+            }
+            return x;
+        };
+        auto diag = [&](int r, int &H, int &mt) {
+            const uint32_t pv = BEST[r];
+            const uint32_t inv = pv & 8191u;
+            H = (int)(pv >> 13) - 4096;
+            mt = inv == 8191u ? min(tlm1, r) : (int)((8191u - inv) & 1023u);
+        };
+        const int C = (n_r + GL - 1) / GL, rlo = min(n_r, gl * C), rhi = min(n_r, rlo + C);
+        // (1) the running maximum that enters every lane's chunk
+        auto chunk_best = [&](int lim) {
+            Best b{NEG_INF, -1, -1};
+            for (int r = rlo; r < rhi && r <= lim; ++r) { int H, mt; diag(r, H, mt); if (H > b.m) b = Best{H, mt, r}; }
+            return b;
+        };
+        Best incl = scan_first_max(chunk_best(n_r));
+        Best in{__shfl_up(incl.m, 1, GL), __shfl_up(incl.t, 1, GL), __shfl_up(incl.r, 1, GL)};
+        ExtApply ez; ez.max = 0; ez.max_t = ez.max_q = -1; ez.zdropped = 0;
+        if (gl > 0 && in.m > 0) { ez.max = in.m; ez.max_t = in.t; ez.max_q = in.r - in.t; }
+        // (2) the first anti-diagonal that z-drops
+        int r_break = n_r;
+        for (int r = rlo; r < rhi; ++r) {
+            int H, mt; diag(r, H, mt);
+            if (ext_apply_zdrop(ez, H, r, mt, zdrop, e2)) { r_break = r; break; }
+        }
+#pragma unroll
+        for (int dlt = GL / 2; dlt; dlt >>= 1) r_break = min(r_break, __shfl_xor(r_break, dlt));
+        const bool dropped = r_break < n_r;
+        // (3) the state when the walk stops: maximum over the anti-diagonals up to there, best cell of the last query column
+        // (H(st, qlen - 1) of the anti-diagonals qlen - 1 .. r_break: target positions 0 .. r_break - qlen + 1)
+        Best fin = scan_first_max(chunk_best(r_break));
+        fin = Best{__shfl(fin.m, GL - 1, GL), __shfl(fin.t, GL - 1, GL), __shfl(fin.r, GL - 1, GL)};
+        const int t_lim = min(tlm1, r_break - (qlen - 1));
+        const int Ct = (tlen + GL - 1) / GL, tlo = min(tlen, gl * Ct), thi = min(tlen, tlo + Ct);
+        Best me{NEG_INF, -1, -1};
+        for (int t = tlo; t < thi && t <= t_lim; ++t) { const int h = (int)HL[t] - 4096; if (h > me.m) me = Best{h, t, t}; }
+        me = scan_first_max(me);
+        me = Best{__shfl(me.m, GL - 1, GL), __shfl(me.t, GL - 1, GL), 0};
+        if (head && jid >= 0) {
+            ExtRes out;
+            out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
+            out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
+            if (ok) {
+                if (fin.m > 0) { out.max = fin.m; out.max_t = fin.t; out.max_q = fin.r - fin.t; }
+                out.zdropped = dropped ? 1 : 0;
+                if (me.m > NEG_INF) { out.mqe = me.m; out.mqe_t = me.t; }
+                if (!dropped) out.score = (int)HL[tlm1] - 4096;
+                out.r_done = dropped ? r_break : n_r - 1;
+                if (!dropped && !(jflag & EZ_EXTZ_ONLY)) { out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1; }
+                else if (!dropped && (jflag & EZ_EXTZ_ONLY) && out.mqe + end_bonus > out.max) { out.reach_end = 1; out.do_bt = 1; out.bt_i = out.mqe_t; out.bt_j = qlen - 1; }
+                else if (out.max_t >= 0 && out.max_q >= 0) { out.do_bt = 1; out.bt_i = out.max_t; out.bt_j = out.max_q; }
+            }
+            res[jid] = out;
+        }
     }
 }
 
@@ -819,19 +962,20 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
 // 256 / 512 / 1024 rows: the ramp of the systolic array costs n_lanes - 1 steps per window, so a window should use as few
 // lanes -- as tall a strip, S <= 16 -- as it can.  The launch list is grouped by S and every group is padded to whole
 // waves, so S is uniform per wave (read from its first window).
-template <int GL>
+template <int GL, bool EXACT = false, bool RIGHT = false>
 __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_list,
                                                           ExtParams prm, const uint8_t *__restrict__ reads,
                                                           const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, int lds_stride) {
+                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, int lds_stride,
+                                                          int nr_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int first = blockIdx.x * (64 / GL);
     const int S = jobs[order[first]].strip_s;
-#define MPN_CASE(SS) case SS: ext_strip_pack<SS, GL>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride); break
+#define MPN_CASE(SS) case SS: ext_strip_pack<SS, GL, EXACT, RIGHT>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride, nr_stride); break
     switch (S) {
         MPN_CASE(1); MPN_CASE(2); MPN_CASE(3); MPN_CASE(4); MPN_CASE(5); MPN_CASE(6); MPN_CASE(7); MPN_CASE(8);
         MPN_CASE(9); MPN_CASE(10); MPN_CASE(11); MPN_CASE(12); MPN_CASE(13); MPN_CASE(14); MPN_CASE(15);
-        default: ext_strip_pack<16, GL>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride); break;
+        default: ext_strip_pack<16, GL, EXACT, RIGHT>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride, nr_stride); break;
     }
 #undef MPN_CASE
 }
@@ -855,6 +999,7 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     const uint8_t *p = P + jb.p_off;
     const int32_t *off = OFF + 2 * jb.row_off, *off_end = off + n_r;
     const bool rowmajor = jb.layout == 1;  // strip kernel: cell (t, j) at [j + t/S][t], band never clips
+    const bool rank_is_op = (jb.flag & EZ_RIGHT) != 0;
     const bool byslot = jb.layout == 2;    // band kernel: cell (t, r) at [r][t mod SL], band limits recomputed here
     const int bw = jb.w < 0 ? (jb.tlen > jb.qlen ? jb.tlen : jb.qlen) : jb.w;
     const bool rev_cigar = (jb.flag & EZ_REV_CIGAR) != 0;
@@ -870,7 +1015,10 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     while (i >= 0 && j >= 0) {
         const int rr = i + j;
         int force_state = -1, tmp;
-        if (rowmajor) { tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i]; tmp = (tmp & ~7) | (4 - (tmp & 7)); }  // (the strip kernel stores the winner's rank)
+        if (rowmajor) {  // (the strip kernel stores the winner's rank: 4 - operand, or the operand itself for right-aligned gaps)
+            tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i];
+            if (!rank_is_op) tmp = (tmp & ~7) | (4 - (tmp & 7));
+        }
         else if (byslot) {
             int st = 0, en = jb.tlen - 1;
             if (st < rr - jb.qlen + 1) st = rr - jb.qlen + 1;

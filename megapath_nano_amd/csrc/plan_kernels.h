@@ -230,18 +230,21 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanOpt o, const PlanReg *__re
 
 // ---- kernel choice and direction-matrix layout of every window --------------------------------------------------------------
 // launch lists: every DP window belongs to exactly one
-// (strip lists: lane-group class (16/32/64 lanes per window) x strip height 1..16; each is padded to whole waves)
-enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 48, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
+// (strip lists: kernel variant (gap fill with approximate maximum / exact / exact with right-aligned gaps) x lane-group class
+// (16/32/64 lanes per window) x strip height 1..16; each is padded to whole waves)
+constexpr int N_STRIP_CLASS = 9;   // variant * 3 + lane-group class
+enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 16 * N_STRIP_CLASS, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
 constexpr int STRIP_QB = 64;                                  // query-length buckets inside a strip list (longest first)
 constexpr int N_BUCKETS = N_LISTS + N_STRIP * (STRIP_QB - 1);  // scatter buckets: a strip list is STRIP_QB consecutive buckets
-__host__ __device__ inline int strip_windows_per_wave(int l) { return 4 >> ((l - L_STRIP) / 16); }
+__host__ __device__ inline int strip_glc_of_list(int l) { return ((l - L_STRIP) / 16) % 3; }
+__host__ __device__ inline int strip_windows_per_wave(int l) { return 4 >> strip_glc_of_list(l); }
 __host__ __device__ inline int bucket_of_list(int l) {       // first bucket of list l
     return l < L_STRIP ? l : l < L_BAND ? L_STRIP + (l - L_STRIP) * STRIP_QB : L_STRIP + N_STRIP * STRIP_QB + (l - L_BAND);
 }
 
 struct LayoutTotals {          // read back by the host after job_layout_kernel
-    long long p_tot, row_tot, cig_tot, state_tot, cells, strip_cells[3];
-    int lds_need[5], strip_lds[3], band_lds[4];
+    long long p_tot, row_tot, cig_tot, state_tot, cells, strip_cells[3], xstrip_cells;
+    int lds_need[5], strip_lds[N_STRIP_CLASS], band_lds[4], strip_nr[N_STRIP_CLASS];   // (strip_nr: anti-diagonals of the longest exact window)
     int too_large, tl_q, tl_t, n_jobs;
     int cnt[N_LISTS], base[N_LISTS + 1];   // launch lists in the flat order array (strip lists padded to whole waves)
 };
@@ -249,18 +252,19 @@ struct LayoutTotals {          // read back by the host after job_layout_kernel
 struct JobSizes { long long p, row, cig, st; };   // scratch needs of a window (scanned into offsets)
 
 __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ jobs, const unsigned long long *__restrict__ nj_p, int strip_scores,
-                                                           int force_kernel, JobSizes *__restrict__ sizes, int32_t *__restrict__ bucket_cnt,
+                                                           ExtParams prm, int force_kernel, JobSizes *__restrict__ sizes, int32_t *__restrict__ bucket_cnt,
                                                            LayoutTotals *__restrict__ tot) {
     const int nj = (int)*nj_p;   // (written by plan_kernel, or by the host for the stage test)
     const int lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     // counters and maxima are gathered per block in LDS and leave with one atomic per block and slot: a hundred thousand
     // windows adding to ONE global address serialise at the memory side (DESIGN.md lesson 4)
     __shared__ int s_bucket[N_BUCKETS];
-    __shared__ int s_max[12];   // lds_need[5] | strip_lds[3] | band_lds[4]
+    constexpr int M_STRIP = 5, M_BAND = M_STRIP + N_STRIP_CLASS, M_NR = M_BAND + 4, M_END = M_NR + N_STRIP_CLASS;
+    __shared__ int s_max[M_END];   // lds_need[5] | strip_lds[9] | band_lds[4] | strip_nr[9]
     for (int k = threadIdx.x; k < N_BUCKETS; k += blockDim.x) s_bucket[k] = 0;
-    if (threadIdx.x < 12) s_max[threadIdx.x] = 0;
+    if (threadIdx.x < M_END) s_max[threadIdx.x] = 0;
     __syncthreads();
-    long long cells = 0, scells[3] = {0, 0, 0};
+    long long cells = 0, scells[3] = {0, 0, 0}, xcells = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         ExtJob jb = jobs[j];
         JobSizes sz{0, 0, 0, 0};
@@ -272,20 +276,27 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         const long long n_r = (long long)jb.qlen + jb.tlen - 1;
         // strip kernel: lane-group class by target rows (16 x 16, 32 x 16, 64 x 16) and by what the queries of one wave may
         // take in LDS (1024 / 2048 / 4096 bases per window)
-        int glc = -1;
-        if ((jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed && w >= max(jb.qlen, jb.tlen) && strip_scores &&
-            (force_kernel == 0 || force_kernel == 4)) {
-            for (int c = 0; c < 3 && glc < 0; ++c)
+        // (the exact variants also take the end extensions and exact fills; they keep H in 16 bits: ext_strip_exact_ok)
+        int glc = -1, variant = 0;
+        if (w >= max(jb.qlen, jb.tlen) && strip_scores && (force_kernel == 0 || force_kernel == 4)) {
+            bool fits = false;
+            if (jb.flag & EZ_APPROX_MAX) fits = !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed;
+            else {
+                fits = ext_strip_exact_ok(prm.sc_mch, prm.q, prm.e, prm.q2, prm.e2, jb.qlen, jb.tlen);
+                variant = (jb.flag & EZ_RIGHT) ? 2 : 1;
+            }
+            for (int c = 0; c < 3 && fits && glc < 0; ++c)
                 if (jb.tlen <= (256 << c) && jb.qlen <= (1024 << c)) glc = c;
         }
         const bool strip = glc >= 0;
+        const int sclass = variant * 3 + max(glc, 0);
         const int seqb = ((jb.qlen + 3) & ~3) + ((jb.tlen + 3) & ~3);
         // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
         int bv = n_col <= 128 ? 0 : n_col <= 256 ? 1 : n_col <= 512 ? 2 : n_col <= 1024 ? 3 : -1;
         if (seqb > lds_cap[3] || !(force_kernel == 0 || force_kernel == 4 || force_kernel == 5)) bv = -1;
         int bc = 3;
         for (int c = 0; c < 4; ++c) if (seqb <= lds_cap[c]) { bc = c; break; }
-        if (bv >= 0) atomicMax(&s_max[8 + bc], seqb);
+        if (bv >= 0) atomicMax(&s_max[M_BAND + bc], seqb);
         jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
         const int strip_gl = 16 << max(glc, 0);
         jb.strip_s = max(1, min(16, (jb.tlen + strip_gl - 1) / strip_gl));   // strip height: the window's rows over its lane group
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         // (the rare exact second pass of a strip window gets its direction matrix from a pool of its own)
         sz.p = ((strip ? strip_bytes : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~15LL;
         cells += n_r * n_col;
-        if (strip) scells[glc] += (long long)jb.qlen * jb.tlen;
+        if (strip) { if (variant == 0) scells[glc] += (long long)jb.qlen * jb.tlen; else xcells += (long long)jb.qlen * jb.tlen; }
         const int stateb = ((6 * jb.tlen + 3) & ~3) + 4 * jb.tlen;
         int cls = 4;
         for (int c = 0; c < 4; ++c) if (seqb + stateb <= lds_cap[c]) { cls = c; break; }
@@ -304,7 +315,11 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         const int wg_nt = n_col - 1 <= 256 ? 0 : n_col - 1 <= 512 ? 1 : 2;
         const int redo_list = bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls;
         int lid;
-        if (strip) { lid = L_STRIP + glc * 16 + jb.strip_s - 1; atomicMax(&s_max[5 + glc], (jb.qlen + 15) & ~15); }
+        if (strip) {
+            lid = L_STRIP + sclass * 16 + jb.strip_s - 1;
+            atomicMax(&s_max[M_STRIP + sclass], (jb.qlen + 15) & ~15);
+            if (variant) atomicMax(&s_max[M_NR + sclass], (int)n_r);
+        }
         else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
         else lid = redo_list;
         if (bv < 0) {   // the LDS-state kernels may run this window (now or in the second pass)
@@ -326,15 +341,17 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
     }
     __syncthreads();
     for (int k = threadIdx.x; k < N_BUCKETS; k += blockDim.x) if (s_bucket[k]) atomicAdd(&bucket_cnt[k], s_bucket[k]);
-    if (threadIdx.x < 5) { if (s_max[threadIdx.x]) atomicMax(&tot->lds_need[threadIdx.x], s_max[threadIdx.x]); }
-    else if (threadIdx.x < 8) { if (s_max[threadIdx.x]) atomicMax(&tot->strip_lds[threadIdx.x - 5], s_max[threadIdx.x]); }
-    else if (threadIdx.x < 12) { if (s_max[threadIdx.x]) atomicMax(&tot->band_lds[threadIdx.x - 8], s_max[threadIdx.x]); }
+    if (threadIdx.x < M_END && s_max[threadIdx.x]) {
+        const int k = threadIdx.x;
+        atomicMax(k < M_STRIP ? &tot->lds_need[k] : k < M_BAND ? &tot->strip_lds[k - M_STRIP] : k < M_NR ? &tot->band_lds[k - M_BAND] : &tot->strip_nr[k - M_NR],
+                  s_max[k]);
+    }
     // (per-block reduction of the cell counters, one atomic per block)
-    __shared__ long long red[4];
-    if (threadIdx.x < 4) red[threadIdx.x] = 0;
+    __shared__ long long red[5];
+    if (threadIdx.x < 5) red[threadIdx.x] = 0;
     __syncthreads();
-    long long v[4] = {cells, scells[0], scells[1], scells[2]};
-    for (int q = 0; q < 4; ++q) {
+    long long v[5] = {cells, scells[0], scells[1], scells[2], xcells};
+    for (int q = 0; q < 5; ++q) {
         for (int d = 32; d; d >>= 1) v[q] += __shfl_xor(v[q], d);
         if ((threadIdx.x & 63) == 0 && v[q]) atomicAdd((unsigned long long *)&red[q], (unsigned long long)v[q]);
     }
@@ -342,6 +359,7 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
     if (threadIdx.x == 0) {
         if (red[0]) atomicAdd((unsigned long long *)&tot->cells, (unsigned long long)red[0]);
         for (int c = 0; c < 3; ++c) if (red[1 + c]) atomicAdd((unsigned long long *)&tot->strip_cells[c], (unsigned long long)red[1 + c]);
+        if (red[4]) atomicAdd((unsigned long long *)&tot->xstrip_cells, (unsigned long long)red[4]);
     }
 }
 
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(256) void job_layout_kernel(ExtJob *__restrict__ jo
         jb.p_off = z.p; jb.row_off = z.row; jb.cig_off = z.cig; jb.state_off = z.st;
         const int lid = jb.cls & 0xff;
         int b = bucket_of_list(lid);
-        if (lid >= L_STRIP && lid < L_BAND) b += STRIP_QB - 1 - min(STRIP_QB - 1, jb.qlen >> (4 + (lid - L_STRIP) / 16));
+        if (lid >= L_STRIP && lid < L_BAND) b += STRIP_QB - 1 - min(STRIP_QB - 1, jb.qlen >> (4 + strip_glc_of_list(lid)));
         order[atomicAdd(&bucket_cur[b], 1)] = j;
     }
 }

@@ -117,6 +117,34 @@ def test_extension_modes_with_zdrop(opt):
     check(opt, qs, ts, 751, 400, 10, EXTZ, [1, 3, 5])
 
 
+def test_exact_strip_windows(opt):
+    """The exact variants of the systolic strip kernel (kernel 4 where eligible: the band never clips, target up to 1024 rows):
+    end extensions to the right and to the left (right-aligned gaps, reversed CIGAR), exact global fills; z-drops in the
+    middle of a window, the end bonus, ambiguous bases, every lane-group class, ties between cells of an anti-diagonal
+    (low-complexity sequence)."""
+    rng = np.random.default_rng(41)
+    sizes = [1, 2, 3, 7, 16, 17, 33, 47, 64, 90, 128, 150, 200, 255, 256, 257, 300, 420, 511, 512, 600, 800, 1000]
+    qs, ts = make_pairs(41, sizes)
+    ts = [np.concatenate([t, rng.integers(0, 4, size=len(t) // 2 + 3).astype(np.uint8)])[:1024] for t in ts]   # target window ~1.5 x query
+    for flag in (EXTZ, EXTZ | RIGHT | REV, 0, RIGHT):
+        check(opt, qs, ts, 3000, 400, -1, flag, [4, 0])
+        check(opt, qs, ts, 3000, 60, 20, flag, [4])
+    qs, ts = make_pairs(42, [60, 130, 260, 500], tail=True)          # unrelated tails: the extension z-drops
+    qs, ts = [q[:1000] for q in qs], [t[:1024] for t in ts]
+    for flag in (EXTZ, EXTZ | RIGHT | REV):
+        check(opt, qs, ts, 3000, 100, -1, flag, [4, 1])
+        check(opt, qs, ts, 3000, 30, 5, flag, [4])
+    qs, ts = make_pairs(43, [80, 240, 480], ambig=True)
+    check(opt, qs, ts, 3000, 400, 10, EXTZ, [4])
+    check(opt, qs, ts, 3000, 400, 10, EXTZ | RIGHT | REV, [4])
+    # low complexity: many equal scores on an anti-diagonal (the tie order of the maximum decides where the alignment ends)
+    qs = [np.array(([0, 1] * 200)[:n], dtype=np.uint8) for n in (50, 150, 333)] + [np.zeros(120, dtype=np.uint8)]
+    ts = [np.array(([0, 1] * 300)[:n * 3 // 2], dtype=np.uint8) for n in (50, 150, 333)] + [np.zeros(200, dtype=np.uint8)]
+    for flag in (EXTZ, EXTZ | RIGHT | REV, 0):
+        check(opt, qs, ts, 3000, 400, -1, flag, [4, 1])
+        check(opt, qs, ts, 3000, 20, 3, flag, [4])
+
+
 def test_band_clipping_and_large_windows(opt):
     qs, ts = make_pairs(8, [600, 1500])
     check(opt, qs, ts, 100, 400, -1, 0, [1, 3, 5])       # narrow band: cells outside the previous band
