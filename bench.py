@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_CEIL_WAVE_INSTR = 580e9  # profiles/r02/valu_microbench.txt: v_pk_*_i16 / v_bfe / v_max issue rate of the whole chip
-STRIP_INSTR_PER_CELL = 29.3   # ISA count of the strip kernel's S = 16 body per cell and lane
+STRIP_INSTR_PER_CELL = 20.5   # ISA count of the strip kernel's S = 16 loop body (328 VALU instructions per 16-row step) per cell and lane
 T00 = time.time()
 
 
@@ -596,7 +596,7 @@ def main():
         'peak_wave_instr_per_s': VALU_CEIL_WAVE_INSTR,
         'frac': round(strip_cells * wi_per_cell / max(strip_ns, 1) * 1e9 / VALU_CEIL_WAVE_INSTR, 4),
         'note': 'peak = measured issue rate of v_pk_*_i16 / v_bfe_i32 / v_max (profiles/r02/valu_microbench.txt), not the 39 T lane-ops/s of SURVEY 8d; '
-                'wave-instructions = cells x 29.3 (ISA count per cell and lane) / 64',
+                'wave-instructions = cells x 20.5 (ISA count per cell and lane) / 64; the lane slots the systolic ramps and padding rows leave empty are not counted (profiles/r03: 0.87 of the slots hold a cell)',
     }
     line = {
         'metric': 'Gbp/min ONT reads aligned+species-assigned vs RefSeq, 1/2/4/8 MI355X',
