@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         const int redo_list = bv >= 0 ? L_BAND + bv * 4 + bc : use_wg ? L_WG + wg_nt * 5 + cls : L_LDS + cls;
         int lid;
         if (strip) {
-            lid = L_STRIP + sclass * 16 + jb.strip_s - 1;
+            lid = L_STRIP + sclass * 16 + (16 - jb.strip_s);   // tall strips (the waves with the most cells) first: they must not start last
             atomicMax(&s_max[M_STRIP + sclass], (jb.qlen + 15) & ~15);
             if (variant) atomicMax(&s_max[M_NR + sclass], (int)n_r);
         }
