@@ -424,11 +424,16 @@ __global__ __launch_bounds__(64) void seed_prefix_kernel(const u128 *__restrict_
 // The hits are walked like a load-balanced expand: a wave takes 64 consecutive minimizers of its read, whose hits are one
 // contiguous range of virtual slots, FLT_UNROLL 64-slot windows per step (as many independent gathers in flight per lane).
 // Pass 1 counts, pass 2 (after a barrier) gathers again, tests, and leaves one keep word per window + the block's total.
+// A read with many hits overfills its tables (24 kb: ~120 k hits on 82 k slots, a third of the strays pass): it gets a SECOND
+// ROUND over the survivors only -- fresh tables, count, test, the keep words rewritten.  Every member of a segment the
+// compaction keeps survived the first round together with the T-1 neighbours that share its bin, so it passes again: still a
+// superset, from tables that hold a third of the hits.
 constexpr int FLT_THREADS = 1024, FLT_WAVES = FLT_THREADS / 64, FLT_UNROLL = 4;  // windows of 64 slots per wave step
 constexpr int FLT_SLOTS = 81920, FLT_WORDS = FLT_SLOTS / 32;      // bits / words per bitmap; 4 tables x 3 levels = 120 KB
 constexpr int FLT_CHUNK = 4096;                                   // slots per start-bit chunk of a wave (64 words)
 constexpr size_t FLT_LDS_BYTES = (size_t)12 * FLT_WORDS * 4 + (size_t)FLT_WAVES * (64 * 8 + FLT_CHUNK / 8 + 64 * 4) + 16;
-struct FilterParams { int shift; uint32_t half; int level; };    // bin = pos >> shift; level = T - 1 (bitmap tested)
+struct FilterParams { int shift; uint32_t half; int level; int64_t second_round; };   // bin = pos >> shift; level = T - 1 (bitmap tested);
+                                                                  // second_round: reads with at least this many hits are counted twice
 
 __device__ __forceinline__ void flt_slots(uint32_t hi, uint32_t bin, uint32_t &s1, uint32_t &s2) {
     uint32_t k = hi * 0x9E3779B1u ^ (bin + 0x7F4A7C15u) * 0x85EBCA77u;
@@ -484,13 +489,15 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
         const int64_t v0 = full_off[read];
         if (full_off[read + 1] == v0) continue;                        // no hits: its blocks keep blk_kept = 0
         const int64_t nblk = (m1 - m0 + 63) / 64, gb0 = blk_base[read];
-        for (int k = tid; k < 12 * FLT_WORDS; k += FLT_THREADS) bm[k] = 0;
-        if (tid < 2) next_blk[tid] = 0;
-        __syncthreads();
-        for (int pass = 0; pass < 2; ++pass) {
+        const int n_pass = full_off[read + 1] - v0 >= fp.second_round ? 4 : 2;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const bool counting = !(pass & 1), again = pass >= 2;   // again: only the hits the first round kept take part
+            if (counting) for (int k = tid; k < 12 * FLT_WORDS; k += FLT_THREADS) bm[k] = 0;
+            if (tid == 0) next_blk[0] = 0;
+            __syncthreads();
             for (;;) {  // the waves take the read's blocks from a queue: the blocks differ in their hit counts
                 uint32_t bq = 0;
-                if (lane == 0) bq = atomicAdd(&next_blk[pass], 1u);
+                if (lane == 0) bq = atomicAdd(&next_blk[0], 1u);
                 const int64_t b = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)bq);
                 if (b >= nblk) break;
                 const int64_t m = m0 + b * 64 + lane;
@@ -525,14 +532,18 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                     for (uint32_t q0 = 0; q0 < c_end; q0 += 64 * FLT_UNROLL) {
                         uint64_t r[FLT_UNROLL];
                         uint32_t par[FLT_UNROLL];
+                        bool live[FLT_UNROLL];
 #pragma unroll
                         for (int u = 0; u < FLT_UNROLL; ++u) {
                             r[u] = 0; par[u] = 0;
                             const uint32_t w0 = q0 + u * 64;
+                            live[u] = false;
                             if (w0 < c_end) {                           // (uniform)
                                 const unsigned long long word = sb[w0 >> 6];
                                 const uint32_t p = c0 + w0 + lane;
-                                if (p < end_all) {
+                                live[u] = p < end_all;
+                                if (again) live[u] = live[u] && (keep[flt_word(vfirst, gb0 + b, (int64_t)((c0 + w0) >> 6))] >> lane & 1);
+                                if (live[u]) {
                                     const int own = before + __popcll(word & lane_le) - 1;   // last owner that starts at or before p
                                     const unsigned long long pv = ps[own];
                                     par[u] = (uint32_t)(pv >> 62) & 1;
@@ -547,14 +558,14 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                             if (w0 >= c_end) break;
                             const uint32_t p = c0 + w0 + lane;
                             bool keep_it = false;
-                            if (p < end_all) {
+                            if (live[u]) {
                                 const uint32_t hi = (uint32_t)(r[u] >> 32) | (((uint32_t)r[u] & 1) ^ par[u]) << 31;   // strand | target
                                 const uint32_t rpos = (uint32_t)r[u] >> 1;
                                 const uint32_t ba = (uint32_t)((uint64_t)rpos >> fp.shift), bb = (uint32_t)(((uint64_t)rpos + fp.half) >> fp.shift);
                                 uint32_t a1, a2, b1, b2;
                                 flt_slots(hi, ba, a1, a2);
                                 flt_slots(hi ^ 0x5bd1e995u, bb, b1, b2);
-                                if (pass == 0) {
+                                if (counting) {
                                     flt_add(bm, a1); flt_add(bm + 3 * FLT_WORDS, a2);
                                     flt_add(bm + 6 * FLT_WORDS, b1); flt_add(bm + 9 * FLT_WORDS, b2);
                                 } else {
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                                               (flt_test(bm + 6 * FLT_WORDS, b1, fp.level) && flt_test(bm + 9 * FLT_WORDS, b2, fp.level));
                                 }
                             }
-                            if (pass == 1) {
+                            if (!counting) {
                                 const unsigned long long km = __ballot(keep_it);
                                 if (lane == 0) keep[flt_word(vfirst, gb0 + b, (int64_t)((c0 + w0) >> 6))] = km;
                                 kept += __popcll(km);
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(FLT_THREADS) void seed_filter_kernel(const u128 *__
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-                if (pass == 1 && lane == 0) { blk_kept[gb0 + b] = kept; blk_read[gb0 + b] = read; }
+                if (!counting && lane == 0) { blk_kept[gb0 + b] = kept; blk_read[gb0 + b] = read; }
                 __builtin_amdgcn_wave_barrier();
             }
             __syncthreads();

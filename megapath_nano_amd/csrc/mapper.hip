@@ -240,6 +240,11 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             int sh = 1;
             while (sh < 32 && ((int64_t)1 << sh) < need) ++sh;
             fp.shift = sh; fp.half = (uint32_t)((uint64_t)1 << (sh - 1)); fp.level = T - 1;
+            // second round for the reads with at least MPN_FLT_ROUND2 hits.  Off by default: at 20000 it emits 660 M anchors per
+            // bench step instead of 1609 M, but the filter takes 30 % longer and the sort stage only 16 % less: 127 -> 121 Gbp/min
+            // (profiles/r03/r03_filter_round2.txt)
+            static const int64_t round2 = []() { const char *e = getenv("MPN_FLT_ROUND2"); return e ? atoll(e) : INT64_MAX; }();
+            fp.second_round = round2;
         }
         static std::once_flag flt_attr;
         std::call_once(flt_attr, [&]() {
