@@ -45,6 +45,22 @@ STRIP_INSTR_PER_CELL = 20.5   # ISA count of the strip kernel's S = 16 loop body
 T00 = time.time()
 
 
+def pmc_traffic(kernel, launches_per_step):
+    """HBM bytes per launch of `kernel` from the PMC summary committed under profiles/ (collected by scripts/collect_r03.sh on this
+    workload in separate --pmc passes, as MI355X_MICROARCH.md prescribes); None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r03', 'r03_pmc_summary.json')
+    try:
+        with open(path) as f:
+            ks = json.load(f)['kernels']
+    except (OSError, ValueError, KeyError):
+        return None, None
+    stem = kernel.split('<')[0]
+    rows = [v for k, v in ks.items() if k.split('<')[0] == stem and not k.startswith('setup:')
+            and not (stem == 'ext_dp_strip_kernel' and 'true' in k)]   # (the exact strip variants are not the gap-fill candidate)
+    b = sum(v.get('hbm_bytes_per_step', 0) for v in rows)
+    return (int(b / max(launches_per_step, 1)) if b else None), 'profiles/r03/r03_pmc_summary.json (bytes per step / launches per step)'
+
+
 def log(msg):
     print(f'[bench {time.time() - T00:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
@@ -573,14 +589,16 @@ def main():
         'anchor_window_sort_kernel': (st['k_sort_chunk_ns'], nsub, 32 * st['anchors_emitted']),
         'anchor_compact_kernel<count|write>': (st['k_compact_ns'], 2 * nsub, 32 * st['anchors_emitted'] + 16 * st['anchors_kept']),
         'chain_dp_kernel': (st['k_chain_dp_ns'], nsub, 32 * st['anchors_kept']),
-        'ext_dp_strip_kernel<16>': (st['k_strip16_ns'], rounds, st['strip16_cells']),
-        'ext_dp_strip_kernel<32>': (st['k_strip32_ns'], rounds, st['strip32_cells']),
-        'ext_dp_strip_kernel<64>': (st['k_strip64_ns'], rounds, st['strip64_cells']),
+        # (one launch per round: 16-, 32- and 64-lane groups are segments of its grid)
+        'ext_dp_strip_kernel<gap fill>': (st['k_strip16_ns'] + st['k_strip32_ns'] + st['k_strip64_ns'], rounds,
+                                          st['strip16_cells'] + st['strip32_cells'] + st['strip64_cells']),
         'aln_finish_wave_kernel': (st['k_finish_ns'], 4 * rounds, 8 * st['cigar_ops'] + 2 * st['bases']),
     }
+    strip_inst = {f'{g}-lane groups': {'cells_per_step': int(st[f'strip{g}_cells'])} for g in (16, 32, 64)}   # (one launch per round holds all three)
     dom = max(cand, key=lambda k: cand[k][0])
     ns, launches, abytes = cand[dom]
     achieved = abytes / max(ns, 1)  # bytes per ns == GB/s
+    traffic, traffic_src = pmc_traffic(dom, launches)
     hits_per_mz = st['anchors'] / max(st['minimizers'], 1)
     # VALU view of the DP: the strip kernels' cells and device time (HIP events; the launches of the 12
     # pipeline workers overlap, so the sum of their spans can exceed the wall time: both rates are given)
@@ -588,7 +606,7 @@ def main():
     strip_cells = st['strip16_cells'] + st['strip32_cells'] + st['strip64_cells']
     wi_per_cell = STRIP_INSTR_PER_CELL / 64.0
     valu = {
-        'kernel': 'ext_dp_strip_kernel<16|32|64>', 'cells_per_step': int(strip_cells), 'all_dp_cells_per_step': int(st['dp_cells']),
+        'kernel': 'ext_dp_strip_kernel<gap fill>', 'cells_per_step': int(strip_cells), 'all_dp_cells_per_step': int(st['dp_cells']),
         'wave_instr_per_cell': round(wi_per_cell, 4),
         'gcups_in_kernel': round(strip_cells / max(strip_ns, 1), 2),                      # cells per ns of the kernels' own spans
         'gcups_whole_step': round(st['dp_cells'] / (dt / K * 1e9), 2),                     # every DP cell of the step over the step's wall time
@@ -627,14 +645,16 @@ def main():
         'host_cpu_s_per_gbp': round(host_cpu_s / max(bases / world, 1) * 1e9, 3),
         'roofline': {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
             'launches_per_step': round(launches, 1), 'launch_ms_avg': round(ns / 1e6 / launches, 3),
             'algorithmic_bytes_per_launch': int(abytes / launches),
             'note': 'dominant kernel = largest device time of this run among the candidates below; durations are HIP-event spans around each '
-                    'launch on its own stream while the other pipeline workers share the GPU. traffic: PMC passes are separate rocprofv3 '
-                    'runs (profiles/r03), not measured inside this process.',
+                    'launch on its own stream while the other pipeline workers share the GPU. The strip DP is bound by VALU issue, not by '
+                    'HBM: see "valu" for it in that unit. traffic: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed PMC '
+                    'passes of the same workload (separate rocprofv3 runs), not measured inside this process.',
             'candidates': {k: {'ms_per_step': round(v[0] / 1e6, 2), 'launches_per_step': round(v[1], 1), 'alg_GB_per_step': round(v[2] / 1e9, 3),
                                'GBps': round(v[2] / max(v[0], 1), 1)} for k, v in cand.items()},
+            'strip_instantiations': strip_inst,
             'whole_path_alg_bytes_per_bp': round(9.73 + 13.1 * hits_per_mz + 1.75 * st['alignments'] / max(args.reads_per_step, 1), 2),
             'valu': valu,
         },

@@ -856,21 +856,32 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             } while (0)
             if (ntc == 0) MPN_WG_LAUNCH(256); else if (ntc == 1) MPN_WG_LAUNCH(512); else MPN_WG_LAUNCH(1024);
 #undef MPN_WG_LAUNCH
-        } else if (l < L_BAND) {  // called once per lane-group class with the class's whole (padded) range: l = first list of the class
-            const int sclass = (l - L_STRIP) / 16, glc = sclass % 3, variant = sclass / 3, per = 4 >> glc;
-            const int stride = (std::max(T.strip_lds[sclass], 16) + 3) & ~3;
-            // exact variants: a slot per anti-diagonal and the E4 table per window (+ 16: the rows that pad the last strip)
-            const int nr_stride = variant ? T.strip_nr[sclass] + 16 : 0;
-            const size_t lds = (size_t)stride * per + STRIP_TAB_BYTES + (size_t)per * 8 * nr_stride;
-#define MPN_STRIP_LAUNCH(GLN, EX, RT)                                                                                                \
+        } else if (l < L_BAND) {  // called once per variant family (l = its first list): all its lane-group classes in ONE launch
+            const int fam = (l - L_STRIP) / 48;   // 0: gap fills (approximate maximum); 1: exact (left- and right-aligned gaps)
+            StripSegs segs;
+            segs.n = 0;
+            int blocks = 0;
+            size_t lds = 0;
+            const int c_lo = fam == 0 ? 0 : 3, c_hi = fam == 0 ? 3 : N_STRIP_CLASS;
+            for (int glc = 2; glc >= 0; --glc)   // wide lane groups (the long windows) first
+                for (int sclass = c_lo + glc; sclass < c_hi; sclass += 3) {
+                    const int l0 = L_STRIP + 16 * sclass, nl = base[l0 + 16] - base[l0], per = 4 >> glc;
+                    if (nl == 0) continue;
+                    const int stride = (std::max(T.strip_lds[sclass], 16) + 3) & ~3;
+                    // exact variants: a slot per anti-diagonal and the E4 table per window (+ 16: the rows that pad the last strip)
+                    const int nr_stride = fam ? T.strip_nr[sclass] + 16 : 0;
+                    lds = std::max(lds, (size_t)stride * per + STRIP_TAB_BYTES + (size_t)per * 8 * nr_stride);
+                    segs.s[segs.n++] = StripSeg{blocks, nl, base[l0], stride, nr_stride, glc, sclass >= 6 ? 1 : 0, 0};
+                    blocks += nl / per;
+                }
+            if (blocks == 0) return 0;
+#define MPN_STRIP_LAUNCH(EX)                                                                                                          \
             do {                                                                                                                      \
-                if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_strip_kernel<GLN, EX, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((ext_dp_strip_kernel<GLN, EX, RT>), dim3(n / per), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, \
-                                   d_read_len, rv, P.p, d_res.p, stride, nr_stride);                                                  \
+                if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_strip_kernel<EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL(ext_dp_strip_kernel<EX>, dim3(blocks), dim3(64), lds, s, d_jobs.p, (const int32_t *)d_order.p, segs, prm, d_reads, \
+                                   d_read_off, d_read_len, rv, P.p, d_res.p);                                                         \
             } while (0)
-#define MPN_STRIP_GL(EX, RT) do { if (glc == 0) MPN_STRIP_LAUNCH(16, EX, RT); else if (glc == 1) MPN_STRIP_LAUNCH(32, EX, RT); else MPN_STRIP_LAUNCH(64, EX, RT); } while (0)
-            if (variant == 0) MPN_STRIP_GL(false, false); else if (variant == 1) MPN_STRIP_GL(true, false); else MPN_STRIP_GL(true, true);
-#undef MPN_STRIP_GL
+            if (fam == 0) MPN_STRIP_LAUNCH(false); else MPN_STRIP_LAUNCH(true);
 #undef MPN_STRIP_LAUNCH
         } else {
             const int bvar = (l - L_BAND) / 4;
@@ -925,13 +936,9 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     for (int l = N_LISTS - 1; l >= 0; --l) {  // wide before narrow, strips (the bulk) in the middle
         if (on_side(l)) continue;
         if (l == L_BAND - 1) ev.mark(15);  // the strip launches are timed on their own ([9]): the roofline kernel of bench.py
-        if (l >= L_STRIP && l < L_BAND) {  // one launch per lane-group class: its 16 height lists are contiguous
-            if ((l - L_STRIP) % 16 == 0) {
-                if (launch_list(l, d_order.p + base[l], base[l + 16] - base[l], st)) return -1;
-                const int sclass = (l - L_STRIP) / 16;
-                if (sclass < 3) ev.mark(9, 38 + sclass);  // every gap-fill strip instantiation is timed on its own
-                else ev.mark(57);                          // the exact variants (end extensions) together
-            }
+        if (l >= L_STRIP && l < L_BAND) {  // one launch per variant family: its lists are contiguous
+            if (l == L_STRIP + 48) { if (launch_list(l, nullptr, 1, st)) return -1; ev.mark(57); }        // the exact variants (end extensions)
+            else if (l == L_STRIP) { if (launch_list(l, nullptr, 1, st)) return -1; ev.mark(9, 38); }    // the gap fills: the roofline kernel of bench.py
         } else if (launch_list(l, d_order.p + base[l], cnt[l], st)) return -1;
     }
     ev.mark(15);

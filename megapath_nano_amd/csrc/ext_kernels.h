@@ -1,7 +1,7 @@
 // Base-level extension kernels (gfx950): banded dual-affine-gap DP with z-drop (the ksw2 formulation minimap2 uses
 // for `-c`), traceback, and the z-drop test of a finished CIGAR.  Integer VALU + LDS work: no MFMA.
 //
-//   ext_dp_strip_kernel<GL>   gap fills whose band never clips (the bulk of the cells): systolic, several windows per wave,
+//   ext_dp_strip_kernel<EXACT> windows whose band never clips (the bulk of the cells): systolic, several windows per wave,
 //                             all state in VGPRs, 1 B/cell of direction codes in a step-major matrix
 //   ext_dp_band_kernel<NW,T>  every other window whose band fits 1024 slots (end extensions with exact max + z-drop,
 //                             clipped fills, the exact second pass): band in registers, one barrier per anti-diagonal
@@ -962,14 +962,12 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
 // 256 / 512 / 1024 rows: the ramp of the systolic array costs n_lanes - 1 steps per window, so a window should use as few
 // lanes -- as tall a strip, S <= 16 -- as it can.  The launch list is grouped by S and every group is padded to whole
 // waves, so S is uniform per wave (read from its first window).
-template <int GL, bool EXACT = false, bool RIGHT = false>
-__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_list,
-                                                          ExtParams prm, const uint8_t *__restrict__ reads,
-                                                          const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, int lds_stride,
-                                                          int nr_stride) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int first = blockIdx.x * (64 / GL);
+template <int GL, bool EXACT, bool RIGHT>
+__device__ __forceinline__ void ext_strip_dispatch(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, const int first,
+                                                   const int n_list, const ExtParams &prm, const uint8_t *__restrict__ reads,
+                                                   const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                   const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem,
+                                                   const int lds_stride, const int nr_stride) {
     const int S = jobs[order[first]].strip_s;
 #define MPN_CASE(SS) case SS: ext_strip_pack<SS, GL, EXACT, RIGHT>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride, nr_stride); break
     switch (S) {
@@ -978,6 +976,29 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
         default: ext_strip_pack<16, GL, EXACT, RIGHT>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride, nr_stride); break;
     }
 #undef MPN_CASE
+}
+
+// ONE launch for all the lane-group classes of a variant family (every launch ends in a tail of half-empty CUs: three launches
+// per round had three).  Segments are ordered from the widest lane group to the narrowest and, inside a class, from the tallest
+// strips and the longest queries down, so the waves with the most cells start first.
+struct StripSeg { int32_t first_block, n_list, ord_off, lds_stride, nr_stride, glc, right, pad; };
+struct StripSegs { StripSeg s[6]; int32_t n; };
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, StripSegs segs,
+                                                          ExtParams prm, const uint8_t *__restrict__ reads,
+                                                          const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                          RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int k = 0;
+    while (k + 1 < segs.n && (int)blockIdx.x >= segs.s[k + 1].first_block) ++k;
+    const StripSeg sg = segs.s[k];
+    const int32_t *ord = order + sg.ord_off;
+    const int first = ((int)blockIdx.x - sg.first_block) * (4 >> sg.glc);
+#define MPN_GL(GLN, RT) ext_strip_dispatch<GLN, EXACT, RT>(jobs, ord, first, sg.n_list, prm, reads, read_off, read_len, rv, P, res, smem, sg.lds_stride, sg.nr_stride)
+    if (EXACT && sg.right) { if (sg.glc == 0) MPN_GL(16, true); else if (sg.glc == 1) MPN_GL(32, true); else MPN_GL(64, true); }
+    else { if (sg.glc == 0) MPN_GL(16, false); else if (sg.glc == 1) MPN_GL(32, false); else MPN_GL(64, false); }
+#undef MPN_GL
 }
 
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
