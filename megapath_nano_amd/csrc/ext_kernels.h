@@ -781,8 +781,8 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         const uint32_t q_in = qt_next;
         qt_next = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + qc_next);
         qc_next = qcode(step + 2);
-        const uint32_t qt_s = (uint32_t)wave_shr1((int)qt, 0);
-        const int v_s = wave_shr1(out_v, 0), x_s = wave_shr1(out_x, 0);
+        const uint32_t qt_s = (uint32_t)wave_shr1_zero((int)qt);
+        const int v_s = wave_shr1_zero(out_v), x_s = wave_shr1_zero(out_x);
         const int j = step - gl;
         const int bj = MPN_BND(step);  // first lane: j = step
         qt = head ? q_in : qt_s;

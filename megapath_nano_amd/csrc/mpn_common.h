@@ -108,6 +108,8 @@ __device__ __forceinline__ int dpp_mov(int old, int v) {
 
 // lane i receives lane i-1's value; lane 0 receives `fill`  (wave_shr:1)
 __device__ __forceinline__ int wave_shr1(int v, int fill) { return dpp_mov<0x138, 0xf>(fill, v); }
+// the same with lane 0 receiving 0: bound_ctrl supplies the zero, so no register has to be set up with the fill value
+__device__ __forceinline__ int wave_shr1_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 
 // inclusive prefix max over the 64 lanes: row_shr 1,2,4,8 then row_bcast15 / row_bcast31
 __device__ __forceinline__ int wave_scan_max(int v) {
