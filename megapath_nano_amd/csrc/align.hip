@@ -746,7 +746,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     int nj = nj_cap;
     WallTimer wt;
     Slot &SL = *tl_slot;
-    const int strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi) ? 1 : 0;
+    const int strip_scores = ext_strip_scores_ok(opt->a, -opt->b, -opt->sc_ambi, opt->q + opt->e, opt->q2 + opt->e2) ? 1 : 0;
     ExtParams prm;
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;

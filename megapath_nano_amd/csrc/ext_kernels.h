@@ -629,8 +629,9 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
 // Same recurrences, boundary rules and direction codes as ext_dp_kernel.  Directions are stored step-major: cell
 // (t, j) lives at [j + t/S][t], so the S bytes a lane produces in one step are contiguous and the whole wave writes one
 // contiguous row of n_lanes*S bytes per step (row-major dword stores cost 7x their bytes in HBM writes, measured).
-__host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb) {  // 8 * score + 4 + 128 is a byte
-    return mch >= -16 && mch <= 15 && mis >= -16 && mis <= 15 && amb >= -16 && amb <= 15;
+__host__ __device__ inline bool ext_strip_scores_ok(int mch, int mis, int amb, int qe, int qe2) {
+    // 8 * score + rank + 128 is a byte; with gap costs up to 127 every biased state and sum stays a positive 16-bit number
+    return mch >= -16 && mch <= 15 && mis >= -16 && mis <= 15 && amb >= -16 && amb <= 15 && qe >= 0 && qe <= 127 && qe2 >= 0 && qe2 <= 127;
 }
 constexpr int STRIP_TAB_BYTES = 32;   // the query score words, behind the groups' queries in LDS
 // EXACT windows (end extensions, exact global fills): is 8 H + 32768 a 16-bit number for every cell (see the H bookkeeping in
@@ -714,12 +715,19 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     //   Vp: v of the row above + CV;                                 Xp: (x + (q+e) | x2 + (q2+e2)), both start at 0
     // with CV = (-8(q+e) + rank a | -8(q2+e2) + rank a2) + BETA and CU = (-8(q+e) + rank b | -8(q2+e2) + rank b2) + BETA, so that
     // the candidates are plain sums: 8 (a | a2) + rank + BETA = Xp + Vp and 8 (b | b2) + rank + BETA = YL + UL.
+    // Every half of every state and candidate is a POSITIVE 16-bit number (the bias), and so is every sum or difference the
+    // recurrences form: a plain 32-bit add or subtract of two registers therefore adds or subtracts the halves exactly -- no carry
+    // or borrow crosses bit 16 -- and v_add_u32 / v_sub_u32 / v_and_b32 issue in 2.7 cycles per wave on gfx950 where the packed
+    // 16-bit and all three-operand instructions take 4.4 (profiles/r03/valu_microbench2.txt).  Only max, min and the saturating
+    // subtract, which need the halves kept apart, are packed instructions.  pk(lo, hi) is the register with the given halves,
+    // formed as a signed sum so that a negative constant in the low half borrows from the high one as the 32-bit add expects.
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    auto bcast = [](int x) { return s16x2{(short)x, (short)x}; };
+    auto pk = [](int lo, int hi) { return (uint32_t)(hi * 65536 + lo); };
     constexpr int BETA = 0x2000 + 128;   // the score byte's 128 and the 0x20 the perm puts above it
-    const s16x2 CV = {(short)(-8 * qe + RA + BETA), (short)(-8 * qe2 + RA2 + BETA)}, CU = {(short)(-8 * qe + RB + BETA), (short)(-8 * qe2 + RB2 + BETA)};
-    s16x2 UL[S], YL[S];
+    const int cv_lo = -8 * qe + RA + BETA, cv_hi = -8 * qe2 + RA2 + BETA, cu_lo = -8 * qe + RB + BETA, cu_hi = -8 * qe2 + RB2 + BETA;
+    const uint32_t CV = pk(cv_lo, cv_hi), CU = pk(cu_lo, cu_hi);
+    uint32_t UL[S], YL[S];
     uint32_t TSEL[S];
     uint32_t Hh[EXACT ? S : 1];   // EXACT: low half = 8 H(t, j) + (j + 1) CV.lo of the lane's current column (mod 2^16)
     const int64_t g0 = ok ? rv.seq_off[rid] + ts : 0;
@@ -730,8 +738,8 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         const int t = t0 + k;
         const int sq = t < tlen ? ref_code(rv, g0 + (back ? tlen - 1 - t : t)) : 4;
         TSEL[k] = 0x0c0c0100u | (sq < 4 ? 4u + (uint32_t)sq : 0u);   // v_perm(QT, KONST): byte 0 = QT[sq] or KONST[0], byte 1 = KONST[1]
-        UL[k] = bcast(MPN_BND(t)) + CU;   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
-        YL[k] = s16x2{0, 0};
+        UL[k] = pk(MPN_BND(t), MPN_BND(t)) + CU;   // left of column 0: the first-column boundary (u of anti-diagonal r = t)
+        YL[k] = 0;
         if constexpr (EXACT) {
             // H(t, -1): the sum of the boundary differences above
             const int h = t < long_thres ? -(q + e * (t + 1)) : -(q2 + e2 * (t + 1));
@@ -760,13 +768,11 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     int out_v = 0, out_x = 0;
     uint32_t qt = 0;   // the score word of the query base this lane works on
     int32_t row0 = 0;  // first lane of a group: sum of the horizontal differences of row 0
-    const s16x2 ZERO = {0, 0};
     // z + CU + CV (what the new u and v are subtracted from), and z + e + the offset of the candidate a gap state comes from
     // (right-aligned gaps: one unit lower, so that the flag sees state >= 0)
     constexpr int RU = RIGHT ? 8 : 0;
-    const s16x2 KZZ = {(short)(-16 * qe + RA + RB + BETA), (short)(-16 * qe2 + RA2 + RB2 + BETA)};
-    const s16x2 KEA = {(short)(8 * e - 8 * qe + RA - RU), (short)(8 * e2 - 8 * qe2 + RA2 - RU)},
-                KEB = {(short)(8 * e - 8 * qe + RB - RU), (short)(8 * e2 - 8 * qe2 + RB2 - RU)};
+    const uint32_t KZZ = pk(-16 * qe + RA + RB + BETA, -16 * qe2 + RA2 + RB2 + BETA);
+    const uint32_t KEA = pk(8 * e - 8 * qe + RA - RU, 8 * e2 - 8 * qe2 + RA2 - RU), KEB = pk(8 * e - 8 * qe + RB - RU, 8 * e2 - 8 * qe2 + RB2 - RU);
     const uint32_t EIGHT = 0x00080008u;
     const uint32_t RANK_CLR = 0xfff8fff8u;
     const uint32_t MCH7 = (uint32_t)(8 * prm.sc_mch + 7 + BETA) * 0x00010001u;
@@ -786,31 +792,32 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         const int j = step - gl;
         const int bj = MPN_BND(step);  // first lane: j = step
         qt = head ? q_in : qt_s;
-        s16x2 Vp = head ? bcast(bj) + CV : __builtin_bit_cast(s16x2, v_s), Xp = head ? ZERO : __builtin_bit_cast(s16x2, x_s);
+        uint32_t Vp = head ? pk(bj, bj) + CV : (uint32_t)v_s, Xp = head ? 0u : (uint32_t)x_s;
         if (j >= 0 && j < qlen && gl < n_lanes) {
             uint32_t dw[(S + 3) / 4], ecell[4] = {0, 0, 0, 0};
             int nv0 = 0;
             // EXACT: what turns a lane's H register into 8 H + 32768 in this column, t - st of the rows below the query's end,
             // the anti-diagonal slots of the lane's first row
-            const uint32_t offj = (uint32_t)((j + 1) * (int)CV.x - 32768);
+            const uint32_t offj = (uint32_t)((j + 1) * cv_lo - 32768);
             const int qm1j = qlen - 1 - j;
             uint32_t *bslot = EXACT ? BEST + (t0 + j) : nullptr;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 const uint32_t sc16 = __builtin_amdgcn_perm(qt, KONST, TSEL[k]);   // 8 s + rank + BETA in the low half
-                const s16x2 Up = UL[k];
-                const s16x2 A = Xp + Vp, B = YL[k] + Up;         // 8 (a | a2) + ranks + BETA, 8 (b | b2) + ranks + BETA
-                const s16x2 M = __builtin_elementwise_max(A, B);
-                // max of M's two halves and the score in ONE instruction: 16-bit three-operand max with the high half of M
-                // selected as its second operand (the result is the low 16 bits; everything after it reads those only)
-                uint32_t z16;
-                asm("v_max3_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(z16) : "v"(__builtin_bit_cast(uint32_t, M)), "v"(sc16));
+                const uint32_t Up = UL[k];
+                const uint32_t A = Xp + Vp, B = YL[k] + Up;      // 8 (a | a2) + ranks + BETA, 8 (b | b2) + ranks + BETA
+                const uint32_t M = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, A), __builtin_bit_cast(s16x2, B)));
+                // max of M's two halves (a packed max of M with its halves swapped) and the score (the two-operand 16-bit max is a
+                // fast instruction; the three-operand one takes 8.3 cycles); the result is the low 16 bits, everything after reads those
+                uint32_t m2, z16;
+                asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m2) : "v"(M));
+                asm("v_max_i16 %0, %1, %2" : "=v"(z16) : "v"(m2), "v"(sc16));
                 // both halves = min(z, match score) (the packed min reads z's low half for both), rank bits cleared
                 uint32_t zc;
                 asm("v_pk_min_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(zc) : "v"(z16), "v"(MCH7));
-                const s16x2 Zc = __builtin_bit_cast(s16x2, zc & RANK_CLR);   // 8 z + BETA
-                const s16x2 ZZ = Zc + KZZ;
-                const s16x2 nu = ZZ - Vp, nv = ZZ - Up;
+                const uint32_t Zc = zc & RANK_CLR;               // 8 z + BETA
+                const uint32_t ZZ = Zc + KZZ;
+                const uint32_t nu = ZZ - Vp, nv = ZZ - Up;
                 // new gap states max(0, candidate - z - e): the candidates and z + e (+ the candidate's offset) are positive
                 u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
                 u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
@@ -831,10 +838,10 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
                 uint32_t Fw;
                 asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(Fw) : "v"(HB), "v"(HA));
                 asm("v_and_or_b32 %0, %1, 7, %2" : "=v"(ecell[k & 3]) : "v"(z16), "v"(Fw));
-                UL[k] = nu; YL[k] = __builtin_bit_cast(s16x2, Bn);
-                Vp = nv; Xp = __builtin_bit_cast(s16x2, An);
+                UL[k] = nu; YL[k] = __builtin_bit_cast(uint32_t, Bn);
+                Vp = nv; Xp = __builtin_bit_cast(uint32_t, An);
                 if constexpr (EXACT) {
-                    Hh[k] += __builtin_bit_cast(uint32_t, nv);
+                    Hh[k] += nv;
                     const uint32_t hb = (Hh[k] - offj) & 0xffffu;            // 8 H(t, j) + 32768
                     const int t = t0 + k, m = min(t, qm1j);                  // m = t - (first cell of the anti-diagonal)
                     uint32_t inv = (m < (int)E4T[t0 + j + k] ? ~((uint32_t)m << 10) & 0xc00u : (uint32_t)-1024) + (uint32_t)(4095 - t);
@@ -849,10 +856,10 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
                     const uint32_t lo = __builtin_amdgcn_perm(e23, e01, 0x05040100u), hi = __builtin_amdgcn_perm(e23, e01, 0x07060302u);
                     asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(dw[k >> 2]) : "v"(hi), "v"(lo));
                 }
-                if (k == 0) nv0 = (int)nv.x;
+                if (k == 0) nv0 = (int)(nv & 0xffffu);
             }
-            out_v = __builtin_bit_cast(int, Vp); out_x = __builtin_bit_cast(int, Xp);
-            row0 += nv0 - (int)CV.x;
+            out_v = (int)Vp; out_x = (int)Xp;
+            row0 += nv0 - cv_lo;
             uint8_t *dst = prow + (int64_t)step * W;  // p_off is 16-aligned, W and t0 are multiples of S
             if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
             else if constexpr (S == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(dw[0], dw[1]);
@@ -871,7 +878,7 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         // (the sums are of pre-scaled differences, exact multiples of 8)
         int32_t tot = head ? row0 - 8 * qe : 0;
 #pragma unroll
-        for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)UL[k].x - (int)CU.x : 0;
+        for (int k = 0; k < S; ++k) tot += (t0 + k > 0 && t0 + k < tlen) ? (int)(UL[k] & 0xffffu) - cu_lo : 0;
 #pragma unroll
         for (int dlt = GL / 2; dlt; dlt >>= 1) tot += __shfl_xor(tot, dlt);
         tot >>= 3;
@@ -888,7 +895,7 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
         // the last query column: a lane's H registers froze there.  HL[t] = H(t, qlen - 1) + 4096, over the E4 table
         uint32_t *HL = E4T;
         {
-            const uint32_t offl = (uint32_t)(qlen * (int)CV.x - 32768);
+            const uint32_t offl = (uint32_t)(qlen * cv_lo - 32768);
 #pragma unroll
             for (int k = 0; k < S; ++k) if (t0 + k < tlen) HL[t0 + k] = ((Hh[k] - offl) & 0xffffu) >> 3;
         }
