@@ -817,7 +817,10 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
                 asm("v_pk_min_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(zc) : "v"(z16), "v"(MCH7));
                 const uint32_t Zc = zc & RANK_CLR;               // 8 z + BETA
                 const uint32_t ZZ = Zc + KZZ;
-                const uint32_t nu = ZZ - Vp, nv = ZZ - Up;
+                // new v = ZZ - (old u), new u = ZZ - (v from above), with the new u written over the old one (one asm statement
+                // says so: left alone, the compiler puts the new v there and copies all S new u back at the end of every step)
+                uint32_t nu = Up, nv;
+                asm("v_sub_u32 %1, %2, %0\n\tv_sub_u32 %0, %2, %3" : "+v"(nu), "=&v"(nv) : "v"(ZZ), "v"(Vp));
                 // new gap states max(0, candidate - z - e): the candidates and z + e (+ the candidate's offset) are positive
                 u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
                 u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
