@@ -40,8 +40,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_CEIL_WAVE_INSTR = 580e9  # profiles/r02/valu_microbench.txt: v_pk_*_i16 / v_bfe / v_max issue rate of the whole chip
-STRIP_INSTR_PER_CELL = 20.5   # ISA count of the strip kernel's S = 16 loop body (328 VALU instructions per 16-row step) per cell and lane
+# Issue rates of the strip cell's instruction types on gfx950 (profiles/r03/valu_microbench2.txt, 4 waves per SIMD): two-operand 32-bit
+# add / sub / and / or / mov and the 16-bit two-operand max take ~2.7 cycles per wave-instruction per SIMD, packed 16-bit, three-operand,
+# permute, DPP ones ~4.4.  The S = 16 loop body of the strip kernel is 344 VALU instructions per 16-row step (21.5 per cell and lane),
+# of which 9.5 per cell are of the fast kind: ~3.65 cycles per instruction on average -> the ceiling of THIS mix for the chip.
+STRIP_INSTR_PER_CELL = 21.5
+STRIP_FAST_PER_CELL = 9.5
+STRIP_CYCLES_PER_INSTR = (STRIP_FAST_PER_CELL * 2.7 + (STRIP_INSTR_PER_CELL - STRIP_FAST_PER_CELL) * 4.4) / STRIP_INSTR_PER_CELL
+VALU_CEIL_WAVE_INSTR = 1024 * 2.4e9 / STRIP_CYCLES_PER_INSTR   # 1024 SIMDs at 2.4 GHz
 T00 = time.time()
 
 
@@ -613,8 +619,8 @@ def main():
         'achieved_wave_instr_per_s': round(strip_cells * wi_per_cell / max(strip_ns, 1) * 1e9, 0),
         'peak_wave_instr_per_s': VALU_CEIL_WAVE_INSTR,
         'frac': round(strip_cells * wi_per_cell / max(strip_ns, 1) * 1e9 / VALU_CEIL_WAVE_INSTR, 4),
-        'note': 'peak = measured issue rate of v_pk_*_i16 / v_bfe_i32 / v_max (profiles/r02/valu_microbench.txt), not the 39 T lane-ops/s of SURVEY 8d; '
-                'wave-instructions = cells x 20.5 (ISA count per cell and lane) / 64; the lane slots the systolic ramps and padding rows leave empty are not counted (profiles/r03: 0.87 of the slots hold a cell)',
+        'note': 'peak = issue rate of the cell\'s own instruction mix (9.5 two-operand 32-bit instructions at 2.7 cycles and 12 packed / three-operand ones at 4.4 per cell: profiles/r03/valu_microbench2.txt), not the 39 T lane-ops/s of SURVEY 8d; '
+                'wave-instructions = cells x 21.5 (ISA count per cell and lane) / 64; the lane slots the systolic ramps and padding rows leave empty are not counted (profiles/r03: 0.87 of the slots hold a cell)',
     }
     line = {
         'metric': 'Gbp/min ONT reads aligned+species-assigned vs RefSeq, 1/2/4/8 MI355X',
