@@ -10,7 +10,7 @@
         int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
         const int b = seed | 0x00030001, c = 0x05040100;                                                                       \
         for (int i = 0; i < REP; ++i)                                                                                          \
-            asm volatile(TEXT : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); \
+            asm volatile(TEXT : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "v40", "v41", "v42", "v43", "v44", "v45", "s20", "s21"); \
         out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                            \
     }
 #define T8(F) F("0") F("1") F("2") F("3") F("4") F("5") F("6") F("7")
@@ -55,7 +55,22 @@
 KERNEL(k_add, T8(I_ADD)) KERNEL(k_sub, T8(I_SUB)) KERNEL(k_and, T8(I_AND)) KERNEL(k_lshlor, T8(I_LSHLOR)) KERNEL(k_andor, T8(I_ANDOR))
 KERNEL(k_perm, T8(I_PERM)) KERNEL(k_pkadd, T8(I_PKADD)) KERNEL(k_pksubsat, T8(I_PKSUBSAT)) KERNEL(k_pkminu, T8(I_PKMINU))
 KERNEL(k_pkmaxi, T8(I_PKMAXI)) KERNEL(k_pkminsel, T8(I_PKMINSEL)) KERNEL(k_max3, T8(I_MAX3)) KERNEL(k_dpp, T8(I_DPP))
-KERNEL(k_cnd, "v_cmp_gt_u32 vcc, %8, %9\n" T8(I_CNDMASK)) KERNEL(k_lshladd, T8(I_MOV64)) KERNEL(k_mad16, T8(I_MAD16)) KERNEL(k_bfi, T8(I_BITOP))
+KERNEL(k_cnd, "v_cmp_gt_u32 vcc, %8, %9\n" T8(I_CNDMASK)) KERNEL(k_cnd2, "s_mov_b64 vcc, 0x5555\n" T8(I_CNDMASK))
+#define I_CMP(r) "v_cmp_gt_u32 vcc, %" r ", %8\n"
+#define I_CMPS(r) "v_cmp_gt_u32 s[20:21], %" r ", %8\n"
+KERNEL(k_cmp, T8(I_CMP))
+#define I_MINI16(r) "v_min_i16 %" r ", %" r ", %8\n"
+#define I_MINU16(r) "v_min_u16 %" r ", %" r ", %8\n"
+#define I_ADDU16(r) "v_add_u16 %" r ", %" r ", %8\n"
+#define I_MOV64B(r) "v_mov_b64 v[40:41], v[42:43]\n"
+#define I_MAD64(r) "v_mad_u64_u32 v[40:41], s[20:21], %" r ", %8, 0\n"
+#define I_LSHLADD64(r) "v_lshl_add_u64 v[40:41], v[42:43], 3, v[44:45]\n"
+#define I_LSHR64(r) "v_lshrrev_b64 v[40:41], 5, v[42:43]\n"
+#define I_MOV64X(r) "v_mov_b64 v[40:41], v[42:43]\n"
+#define I_CVT(r) "v_cvt_f64_i32 v[40:41], %" r "\n"
+#define I_MULF64(r) "v_mul_f64 v[40:41], v[42:43], v[44:45]\n"
+KERNEL(k_mad64, T8(I_MAD64)) KERNEL(k_lshladd64, T8(I_LSHLADD64)) KERNEL(k_lshr64, T8(I_LSHR64)) KERNEL(k_mov64, T8(I_MOV64X)) KERNEL(k_cvt, T8(I_CVT)) KERNEL(k_mulf64, T8(I_MULF64))
+KERNEL(k_mini16, T8(I_MINI16)) KERNEL(k_minu16, T8(I_MINU16)) KERNEL(k_addu16, T8(I_ADDU16)) KERNEL(k_lshladd, T8(I_MOV64)) KERNEL(k_mad16, T8(I_MAD16)) KERNEL(k_bfi, T8(I_BITOP))
 KERNEL(k_or, T8(I_OR)) KERNEL(k_xor, T8(I_XOR)) KERNEL(k_lshl, T8(I_LSHL)) KERNEL(k_lshr, T8(I_LSHR)) KERNEL(k_minu, T8(I_MINU)) KERNEL(k_maxi, T8(I_MAXI))
 KERNEL(k_max3p, T8(I_MAX3P)) KERNEL(k_max3i32, T8(I_MAX3I32)) KERNEL(k_maxi16, T8(I_MAXI16)) KERNEL(k_pkmaxsel, T8(I_PKMAXSEL)) KERNEL(k_mov, T8(I_MOV))
 KERNEL(k_add3, T8(I_ADD3)) KERNEL(k_mad24, T8(I_MAD24)) KERNEL(k_mullo, T8(I_MULLO)) KERNEL(k_mulhi, T8(I_MULHI)) KERNEL(k_mul24, T8(I_MUL24))
@@ -89,6 +104,10 @@ int main() {
     run("v_or_b32", k_or, d_out); run("v_xor_b32", k_xor, d_out); run("v_lshlrev_b32", k_lshl, d_out); run("v_lshrrev_b32", k_lshr, d_out);
     run("v_min_u32", k_minu, d_out); run("v_max_i32", k_maxi, d_out); run("v_mov_b32", k_mov, d_out); run("v_add3_u32", k_add3, d_out); run("v_or3_b32", k_or3, d_out);
     run("v_mad_u32_u24", k_mad24, d_out); run("v_mul_u32_u24", k_mul24, d_out); run("v_mul_lo_u32", k_mullo, d_out); run("v_mul_hi_u32", k_mulhi, d_out);
+    run("v_cndmask_b32 (vcc by s_mov)", k_cnd2, d_out); run("v_cmp_gt_u32 -> vcc", k_cmp, d_out);
+    run("v_min_i16", k_mini16, d_out); run("v_min_u16", k_minu16, d_out); run("v_add_u16", k_addu16, d_out);
+    run("v_mad_u64_u32", k_mad64, d_out); run("v_lshl_add_u64", k_lshladd64, d_out); run("v_lshrrev_b64", k_lshr64, d_out); run("v_mov_b64", k_mov64, d_out);
+    run("v_cvt_f64_i32", k_cvt, d_out); run("v_mul_f64", k_mulf64, d_out);
     run("v_bfe_u32", k_bfe, d_out); run("v_bcnt_u32_b32", k_bcnt, d_out); run("v_add_u32_sdwa", k_sdwa, d_out); run("v_pk_lshlrev_b16", k_pklshl, d_out);
     return 0;
 }
