@@ -213,6 +213,8 @@ def build_workload(args, device, rank, world):
                           f'for badread, generated on the GPU; {n_distinct} distinct batches rotated over the steps), -N 50 -p 1 -x map-ont -c')
     torch.cuda.empty_cache()
     idx0 = W['idx'][0] if isinstance(W['idx'], (list, tuple)) else W['idx']
+    if getattr(args, 'mapping_only', False):
+        opt_kw = dict(opt_kw, with_cigar=0)
     opt = mapper.default_opt(**opt_kw)
     if not isinstance(W['idx'], (list, tuple)):
         opt.mid_occ = idx0.mid_occ()      # (index parts: every part applies its own -f cut-off, like minimap2)
@@ -451,8 +453,12 @@ def main():
     ap.add_argument('--pcie-steps', type=int, default=10, help='extra steps fed from host buffers (PCIe-inclusive rate, never `value`)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-correctness', action='store_true')
+    ap.add_argument('--mapping-only', action='store_true', help='diagnostic: no base-level extension (the reference\'s mapping_only mode); implies --no-correctness, not the metric')
     ap.add_argument('--cpu-index-genomes', type=int, default=250, help='genomes of the CPU baseline\'s index (250 x 4 Mbp = 1 Gbp)')
     args = ap.parse_args()
+    if args.mapping_only:
+        args.no_correctness = True
+        args.no_cpu_baseline = True
     cfg_defaults = {'c3': (5000, 262144), 'strain': (5000, 16384), 'big': (9000, 262144), 'parts': (5000, 262144), 'c2': (0, 100000)}
     if args.genomes is None:
         args.genomes = cfg_defaults[args.config][0]
