@@ -26,9 +26,14 @@ acc = collections.Counter()       # time by predicate
 alone = collections.Counter()     # time a kernel is resident while no strip kernel is
 conc_hist = collections.Counter()
 def is_strip(n): return 'ext_dp_strip_kernel' in n
+self_t = collections.Counter()     # time a kernel name is resident at all
+self_c = collections.Counter()     # integral of its simultaneous instances
 for t, d, n in ev:
     dt = t - prev
     if dt > 0:
+        for m, c in live.items():
+            if c:
+                self_t[m] += dt; self_c[m] += dt * c
         k = sum(live.values())
         strips = sum(c for m, c in live.items() if is_strip(m))
         acc['any'] += dt if k else 0
@@ -49,3 +54,6 @@ print('resident kernels -> share of time: ' + ', '.join(f'{k}{"+" if k == 16 els
 print('resident while NO strip kernel is (share of the window):', file=out)
 for m, v in alone.most_common(14):
     print(f'  {v / tot:.3f}  {m[:70]}', file=out)
+print('kernel: share of the window it is resident, simultaneous instances while resident:', file=out)
+for m, v in self_t.most_common(16):
+    print(f'  {v / tot:.3f}  x{self_c[m] / v:.2f}  {m[:70]}', file=out)
