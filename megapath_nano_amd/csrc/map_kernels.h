@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
                                                           const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
                                                           const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
                                                           int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base,
-                                                          int64_t *__restrict__ slow_list, unsigned long long *__restrict__ n_slow) {
+                                                          int64_t *__restrict__ slow_list, unsigned long long *__restrict__ n_slow,
+                                                          unsigned long long *__restrict__ emask, uint8_t *__restrict__ cfast) {
     // per wave: packed bases (2 bits each, first base in the top bits of a word), hashes of the k-mer end positions, strands
     constexpr int MAX_EXT = 256 + 3 * SKETCH_FAST_MAX_W + 28 + 1 + 16;
     typedef typename std::conditional<HASH64, uint64_t, uint32_t>::type hash_t;
@@ -121,8 +122,10 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
             // chunks that are irregular by their place in the sequence are on the host-built part of the list already;
             // one that holds an ambiguous base is appended here (rare, so the atomic on one counter does not matter)
             if (!FILL && in_range && lane == 0) slow_list[atomicAdd(n_slow, 1ULL)] = c;
+            if (!FILL && cfast && lane == 0) cfast[c] = 0;
             continue;
         }
+        if (!FILL && cfast && lane == 0) cfast[c] = 1;
         // hash and strand of the k-mers ending at p0 - (w-1) + q, q in [0, n_q)
         const int n_q = (p1 - p0) + 2 * (w - 1);
         for (int q0 = 0; q0 < n_q; q0 += 64) {
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
                 emit = L + R >= w - 1;
             }
             const unsigned long long em = __ballot(emit);
+            if (!FILL && emask && lane == 0) emask[c * 4 + (t0 >> 6)] = em;   // what the one-pass fill kernel below emits
             if (FILL && emit) {
                 const uint32_t pos = (uint32_t)(p0 + t);
                 const uint32_t zbit = (uint32_t)(zs[q >> 6] >> (q & 63) & 1);
@@ -181,6 +185,78 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
             run += __popcll(em);
         }
         if (!FILL && lane == 0) chunk_cnt[c] = run;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The second pass of the regular chunks without the window test: the count pass left the emit mask of every 64 positions
+// (emask) and whether it handled the chunk (cfast).  The wave packs the chunk's bases again, compacts the emitted positions
+// (~47 of 256) into a list and hashes only those -- one round of 64 lanes instead of five over all k-mers -- and stores the
+// records in order, 16 bytes per lane.
+template <bool HASH64>
+__global__ __launch_bounds__(256) void sketch_fill_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
+                                                          const int32_t *__restrict__ seq_len, int n,
+                                                          const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
+                                                          const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
+                                                          u128 *__restrict__ mz, uint32_t rid_base,
+                                                          const unsigned long long *__restrict__ emask, const uint8_t *__restrict__ cfast) {
+    constexpr int MAX_EXT = 256 + 3 * SKETCH_FAST_MAX_W + 28 + 1 + 16;
+    __shared__ uint32_t s_words[4][MAX_EXT / 16 + 2];
+    __shared__ uint16_t s_list[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *words = s_words[wv];
+    uint16_t *list = s_list[wv];
+    const uint64_t mask = (1ULL << 2 * k) - 1;
+    const unsigned long long lane_lt = (1ULL << lane) - 1;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wv; c < n_chunks; c += (int64_t)gridDim.x * 4) {
+        if (!cfast[c]) continue;   // the automaton kernel's chunk
+        int lo = 0, hi = n;  // last sequence with chunk_off[seq] <= c
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
+        const int i = lo;
+        const uint8_t *sq = seqs + seq_off[i];
+        const int len = seq_len[i];
+        const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
+        int a0, a1;
+        (void)sketch_chunk_in_range(p0, p1, len, w, k, &a0, &a1);
+        const int ext = a1 - a0;
+        const int qbase = w + 2;
+        for (int t0 = 0; t0 < ext; t0 += 64) {
+            const int t = t0 + lane;
+            const int code = t < ext ? nt4_code(sq[a0 + t]) : 0;
+            uint32_t v = (uint32_t)(code & 3) << (2 * (15 - (lane & 15)));
+            v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
+            if ((lane & 15) == 0) words[(t0 >> 4) + (lane >> 4)] = v;
+        }
+        int run = 0;
+        for (int t0 = 0; t0 < p1 - p0; t0 += 64) {
+            const unsigned long long em = emask[c * 4 + (t0 >> 6)];
+            if (em >> lane & 1) list[run + __popcll(em & lane_lt)] = (uint16_t)(t0 + lane);
+            run += __popcll(em);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        u128 *out = mz + mz_off[i] + chunk_rel[c];
+        for (int r0 = 0; r0 < run; r0 += 64) {
+            if (r0 + lane < run) {
+                const int t = list[r0 + lane];
+                const int q = t + (w - 1);   // index among the k-mers ending at p0 - (w-1) + q
+                const int wi = (qbase + q) >> 4, sh = 2 * ((qbase + q) & 15);
+                const uint64_t hi64 = (uint64_t)words[wi] << 32 | words[wi + 1];
+                uint64_t f;
+                if (sh + 2 * k <= 64) f = hi64 << sh >> (64 - 2 * k);
+                else f = ((hi64 << sh) | ((uint64_t)words[wi + 2] >> (32 - sh))) >> (64 - 2 * k);
+                uint64_t r = ~f & mask;
+                r = __builtin_bitreverse64(r);
+                r = ((r & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((r & 0x5555555555555555ULL) << 1);
+                r >>= 64 - 2 * k;
+                const bool z = !(f < r);
+                const uint64_t h = sketch_hash<HASH64>(z ? r : f, mask);
+                u128 rec;
+                rec.x = h << 8 | (uint64_t)k;
+                rec.y = (uint64_t)(rid_base + (uint32_t)i) << 32 | (uint32_t)(p0 + t) << 1 | (uint32_t)z;
+                out[r0 + lane] = rec;
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }

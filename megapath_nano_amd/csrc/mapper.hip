@@ -97,9 +97,11 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     const int64_t n_chunks = chunk_off[n];
     DevBuf<int64_t> cnt, d_chunk_off, slow_list;
     DevBuf<int32_t> chunk_cnt, chunk_rel;
-    DevBuf<unsigned long long> n_slow;
+    DevBuf<unsigned long long> n_slow, emask;
+    DevBuf<uint8_t> cfast;
     if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1) || d_chunk_off.upload(chunk_off.data(), (size_t)n + 1, st) ||
-        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1))
+        chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1) ||
+        emask.alloc((size_t)n_chunks * 4 + 4) || cfast.alloc((size_t)n_chunks + 1))
         return -1;
     {
         // the chunks that are irregular by their place in the sequence (its first chunk(s), its last one(s); all of them for
@@ -129,11 +131,18 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
         const int64_t *moff = fill ? (const int64_t *)mz_off.p : nullptr;
         const int32_t *crel = fill ? (const int32_t *)chunk_rel.p : nullptr;
         int32_t *ccnt = fill ? nullptr : chunk_cnt.p;
-#define MPN_FAST(F, H) hipLaunchKernelGGL((sketch_fast_kernel<F, H>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, \
-                       (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p)
-        if (fill) { if (hash64) MPN_FAST(true, true); else MPN_FAST(true, false); }
-        else { if (hash64) MPN_FAST(false, true); else MPN_FAST(false, false); }
-#undef MPN_FAST
+        // (the count pass leaves the emit masks; the second pass of the regular chunks hashes the emitted positions only)
+        if (fill) {
+            if (hash64) hipLaunchKernelGGL(sketch_fill_kernel<true>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, n_chunks, C,
+                                           w, k, moff, crel, out, rid_base, (const unsigned long long *)emask.p, (const uint8_t *)cfast.p);
+            else hipLaunchKernelGGL(sketch_fill_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, n_chunks, C,
+                                    w, k, moff, crel, out, rid_base, (const unsigned long long *)emask.p, (const uint8_t *)cfast.p);
+        } else {
+            if (hash64) hipLaunchKernelGGL((sketch_fast_kernel<false, true>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                           n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p, emask.p, cfast.p);
+            else hipLaunchKernelGGL((sketch_fast_kernel<false, false>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                    n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p, emask.p, cfast.p);
+        }
         if (fill) hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
                                      (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base);
         else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
