@@ -261,18 +261,23 @@ __global__ __launch_bounds__(256) void sketch_fill_kernel(const uint8_t *__restr
     }
 }
 
+constexpr int SKETCH_STAGE_CAP = 256;   // reports per staged chunk (= C: one per owned position at most)
+
 template <bool FILL>
 __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
                                                           const int64_t *__restrict__ chunk_off, const int64_t *__restrict__ slow_list,
                                                           const unsigned long long *__restrict__ n_slow, int C, int w, int k,
                                                           const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
-                                                          int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base) {
+                                                          int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base,
+                                                          u128 *__restrict__ stage, int64_t stage_chunks, int64_t li_begin) {
+    // stage (count pass): the reports of the first stage_chunks listed chunks are kept, SKETCH_STAGE_CAP slots per chunk, and a
+    // copy kernel puts them in place -- the automaton runs once for them; li_begin: the fill pass of the chunks beyond that
     extern __shared__ __attribute__((aligned(16))) uint64_t ring[];  // bx[w][64] then by[w][64]
     const int tid = threadIdx.x;
     uint64_t *bx = ring, *by = ring + (size_t)w * blockDim.x;
     const int64_t n_list = (int64_t)*n_slow;
-    for (int64_t li = (int64_t)blockIdx.x * blockDim.x + tid; li < n_list; li += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t li = li_begin + (int64_t)blockIdx.x * blockDim.x + tid; li < n_list; li += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = slow_list[li];
     int lo = 0, hi = n;  // last read with chunk_off[read] <= c
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
@@ -284,9 +289,9 @@ __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restr
     const int lsat = w + k;
     const uint32_t rid = rid_base + (uint32_t)i;
     int64_t cnt = 0;
-    u128 *out = FILL ? mz + mz_off[i] + chunk_rel[c] : nullptr;
-    // a report belongs to this chunk iff the reported position does
-#define MPN_PUSH(X, Y) do { const int pp_ = (int)((uint32_t)(Y) >> 1); if (pp_ >= p0 && pp_ < p1) { if (FILL) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } } while (0)
+    u128 *out = FILL ? mz + mz_off[i] + chunk_rel[c] : (stage && li < stage_chunks) ? stage + li * SKETCH_STAGE_CAP : nullptr;
+    // a report belongs to this chunk iff the reported position does (a position is reported at most once: <= C reports)
+#define MPN_PUSH(X, Y) do { const int pp_ = (int)((uint32_t)(Y) >> 1); if (pp_ >= p0 && pp_ < p1) { if (out) { out[cnt].x = (X); out[cnt].y = (Y); } ++cnt; } } while (0)
     int D = w + k + 8;
     for (;;) {
         const int ps = max(0, p0 - D);
@@ -357,6 +362,25 @@ __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restr
     }
 #undef MPN_PUSH
     if (!FILL) chunk_cnt[c] = (int32_t)cnt;
+    }
+}
+
+// the staged reports of the automaton kernel's count pass go to their places: a wave per listed chunk
+__global__ __launch_bounds__(256) void sketch_stage_copy_kernel(const int64_t *__restrict__ chunk_off, int n, const int64_t *__restrict__ slow_list,
+                                                                const unsigned long long *__restrict__ n_slow, int64_t stage_chunks,
+                                                                const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
+                                                                const int32_t *__restrict__ chunk_cnt, const u128 *__restrict__ stage,
+                                                                u128 *__restrict__ mz) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_list = min((int64_t)*n_slow, stage_chunks);
+    for (int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); li < n_list; li += (int64_t)gridDim.x * 4) {
+        const int64_t c = slow_list[li];
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
+        const int cnt = chunk_cnt[c];
+        u128 *out = mz + mz_off[lo] + chunk_rel[c];
+        const u128 *in = stage + li * SKETCH_STAGE_CAP;
+        for (int q = lane; q < cnt; q += 64) out[q] = in[q];
     }
 }
 

@@ -99,6 +99,8 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     DevBuf<int32_t> chunk_cnt, chunk_rel;
     DevBuf<unsigned long long> n_slow, emask;
     DevBuf<uint8_t> cfast;
+    DevBuf<u128> stage;
+    int64_t stage_chunks = 0;
     if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1) || d_chunk_off.upload(chunk_off.data(), (size_t)n + 1, st) ||
         chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1) ||
         emask.alloc((size_t)n_chunks * 4 + 4) || cfast.alloc((size_t)n_chunks + 1))
@@ -117,6 +119,10 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
             }
         }
         const unsigned long long ns = slow.size();
+        // staging for the automaton kernel's reports: the chunks listed here + some of those the fast kernel appends (ambiguous bases)
+        stage_chunks = (int64_t)std::min<unsigned long long>((unsigned long long)n_chunks, ns + 2048);
+        if (stage_chunks * SKETCH_STAGE_CAP * sizeof(u128) > ((size_t)1 << 30)) stage_chunks = ((size_t)1 << 30) / (SKETCH_STAGE_CAP * sizeof(u128));
+        if (stage.alloc((size_t)stage_chunks * SKETCH_STAGE_CAP + 1)) return -1;
         if (ns) MPN_HIP_CHECK(hipMemcpyAsync(slow_list.p, slow.data(), ns * 8, hipMemcpyHostToDevice, st));
         MPN_HIP_CHECK(hipMemcpyAsync(n_slow.p, &ns, 8, hipMemcpyHostToDevice, st));
         MPN_HIP_CHECK(stream_sync(st));  // (the host vectors leave scope)
@@ -143,10 +149,17 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
             else hipLaunchKernelGGL((sketch_fast_kernel<false, false>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
                                     n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p, emask.p, cfast.p);
         }
-        if (fill) hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
-                                     (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base);
-        else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
-                                (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base);
+        if (fill) {
+            // the staged chunks are copied into place; the automaton runs a second time only for the listed chunks beyond the staging
+            hipLaunchKernelGGL(sketch_stage_copy_kernel, dim3(slow_grid), dim3(256), 0, st, (const int64_t *)d_chunk_off.p, n, (const int64_t *)slow_list.p,
+                               (const unsigned long long *)n_slow.p, stage_chunks, moff, crel, (const int32_t *)chunk_cnt.p, (const u128 *)stage.p, out);
+            if (stage_chunks < n_chunks)
+                hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                   (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base,
+                                   (u128 *)nullptr, (int64_t)0, stage_chunks);
+        } else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                  (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base,
+                                  stage.p, stage_chunks, (int64_t)0);
     };
     if (ev) ev->skip();  // (host work above: the span of the count pass starts at its launch)
     pass(false, nullptr);
