@@ -582,7 +582,7 @@ def main():
     rounds = max(st['dp_rounds'], 1)
     # Candidate kernels for the roofline line: device ns from HIP events around each launch (rank 0, per step), launches per
     # step, and ALGORITHMIC bytes per step (DESIGN.md section 5 states the per-unit figures):
-    #   sketch (count + fill pass)   : 2 x 1 B per read base in + 16 B per minimizer out
+    #   sketch (count pass + fill)   : 2 x 1 B per read base in + 16 B per minimizer out
     #   seed lookup                  : 16 B per minimizer in + 12 B (count, first position) out
     #   stray-hit filter (2 passes)  : 2 x 8 B per index position gathered + 1 keep bit per position out
     #   anchor emission              : 8 B per EMITTED position gathered + 16 B per emitted anchor out
@@ -593,7 +593,7 @@ def main():
     #   strip DP <GL>                : 1 direction byte out per DP cell (qlen x tlen per window)
     #   alignment finishing          : 4 B per CIGAR op in + 4 B out, ~1 B per aligned query base + 0.25 B per target base in
     cand = {
-        'sketch_fast_kernel<count|fill>': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
+        'sketch_fast_kernel + sketch_fill_kernel': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
         'seed_lookup_kernel': (st['k_seed_lookup_ns'], nsub, 28 * st['minimizers']),
         'seed_filter_kernel': (st['k_seed_filter_ns'], nsub, 16 * st['anchors'] + st['anchors'] / 8),
         'seed_emit_kernel': (st['k_seed_fill_ns'], nsub, 24 * st['anchors_emitted']),

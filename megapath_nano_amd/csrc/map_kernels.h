@@ -45,7 +45,10 @@ __device__ __forceinline__ uint64_t hash64m(uint64_t key, uint64_t mask) {
 //    was reset there anyway; otherwise l saturated inside it (for even k, where symmetric k-mers do not advance l, D
 //    is doubled until that holds).  It then runs w window steps past the chunk, because a minimizer is reported when
 //    it is replaced or leaves the window, and keeps the reports whose position the chunk owns.
-// FILL = false counts (chunk_cnt), FILL = true writes at mz_off[seq] + chunk_rel[chunk].
+// Two passes: the first counts (chunk_cnt) and remembers what it found -- the fast kernel the emit mask of every 64 positions,
+// the automaton kernel its reports in a staging area; after the prefix sums the second writes at mz_off[seq] + chunk_rel[chunk]:
+// sketch_fill_kernel hashes the emitted positions of the regular chunks again (a fifth of the k-mers), sketch_stage_copy_kernel
+// moves the staged reports (the automaton runs a second time, FILL = true, only for chunks the staging area had no room for).
 constexpr int SKETCH_FAST_MAX_W = 32;
 
 template <bool HASH64>
@@ -76,24 +79,21 @@ __device__ __forceinline__ bool sketch_chunk_in_range(int p0, int p1, int len, i
     return (k & 1) && w <= SKETCH_FAST_MAX_W && *A0 >= 0 && *A1 <= len;
 }
 
-template <bool FILL, bool HASH64>
+template <bool HASH64>
 __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
                                                           const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
-                                                          const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
-                                                          int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base,
+                                                          int32_t *__restrict__ chunk_cnt,
                                                           int64_t *__restrict__ slow_list, unsigned long long *__restrict__ n_slow,
                                                           unsigned long long *__restrict__ emask, uint8_t *__restrict__ cfast) {
-    // per wave: packed bases (2 bits each, first base in the top bits of a word), hashes of the k-mer end positions, strands
+    // per wave: packed bases (2 bits each, first base in the top bits of a word), hashes of the k-mer end positions
     constexpr int MAX_EXT = 256 + 3 * SKETCH_FAST_MAX_W + 28 + 1 + 16;
     typedef typename std::conditional<HASH64, uint64_t, uint32_t>::type hash_t;
     __shared__ uint32_t s_words[4][MAX_EXT / 16 + 2];
     __shared__ hash_t s_hash[4][256 + 2 * (SKETCH_FAST_MAX_W - 1) + 2];
-    __shared__ unsigned long long s_z[4][(256 + 2 * (SKETCH_FAST_MAX_W - 1)) / 64 + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t *words = s_words[wv];
     hash_t *hs = s_hash[wv];
-    unsigned long long *zs = s_z[wv];
     const uint64_t mask = (1ULL << 2 * k) - 1;
     for (int64_t c = (int64_t)blockIdx.x * 4 + wv; c < n_chunks; c += (int64_t)gridDim.x * 4) {
         int lo = 0, hi = n;  // last sequence with chunk_off[seq] <= c
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
         if (!regular) {
             // chunks that are irregular by their place in the sequence are on the host-built part of the list already;
             // one that holds an ambiguous base is appended here (rare, so the atomic on one counter does not matter)
-            if (!FILL && in_range && lane == 0) slow_list[atomicAdd(n_slow, 1ULL)] = c;
-            if (!FILL && cfast && lane == 0) cfast[c] = 0;
+            if (in_range && lane == 0) slow_list[atomicAdd(n_slow, 1ULL)] = c;
+            if (lane == 0) cfast[c] = 0;
             continue;
         }
-        if (!FILL && cfast && lane == 0) cfast[c] = 1;
+        if (lane == 0) cfast[c] = 1;
         // hash and strand of the k-mers ending at p0 - (w-1) + q, q in [0, n_q)
         const int n_q = (p1 - p0) + 2 * (w - 1);
         for (int q0 = 0; q0 < n_q; q0 += 64) {
@@ -149,22 +149,17 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
                 h = sketch_hash<HASH64>(z ? r : f, mask);
             }
             if (q < n_q) hs[q] = (hash_t)h;
-            const unsigned long long zm = __ballot(z);
-            if (lane == 0) zs[q0 >> 6] = zm;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // window test of the owned positions p = p0 + t: q index of p is t + (w - 1)
         int run = 0;
-        u128 *out = FILL ? mz + mz_off[i] + chunk_rel[c] : nullptr;
         for (int t0 = 0; t0 < p1 - p0; t0 += 64) {
             const int t = t0 + lane;
             bool emit = false;
-            hash_t hp = 0;
-            int q = 0;
             if (t < p1 - p0) {
-                q = t + (w - 1);
-                hp = hs[q];
+                const int q = t + (w - 1);
+                const hash_t hp = hs[q];
                 int L = 0, R = 0;
                 bool go = true;
                 for (int d = 1; d < w; ++d) { go = go && hs[q - d] >= hp; L += go; }
@@ -173,18 +168,10 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
                 emit = L + R >= w - 1;
             }
             const unsigned long long em = __ballot(emit);
-            if (!FILL && emask && lane == 0) emask[c * 4 + (t0 >> 6)] = em;   // what the one-pass fill kernel below emits
-            if (FILL && emit) {
-                const uint32_t pos = (uint32_t)(p0 + t);
-                const uint32_t zbit = (uint32_t)(zs[q >> 6] >> (q & 63) & 1);
-                u128 rec;
-                rec.x = (uint64_t)hp << 8 | (uint64_t)k;
-                rec.y = (uint64_t)(rid_base + (uint32_t)i) << 32 | pos << 1 | zbit;
-                out[run + __popcll(em & ((1ULL << lane) - 1))] = rec;
-            }
+            if (lane == 0) emask[c * 4 + (t0 >> 6)] = em;   // what sketch_fill_kernel emits
             run += __popcll(em);
         }
-        if (!FILL && lane == 0) chunk_cnt[c] = run;
+        if (lane == 0) chunk_cnt[c] = run;
         __builtin_amdgcn_wave_barrier();
     }
 }

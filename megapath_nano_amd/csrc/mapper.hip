@@ -144,10 +144,10 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
             else hipLaunchKernelGGL(sketch_fill_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, n_chunks, C,
                                     w, k, moff, crel, out, rid_base, (const unsigned long long *)emask.p, (const uint8_t *)cfast.p);
         } else {
-            if (hash64) hipLaunchKernelGGL((sketch_fast_kernel<false, true>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
-                                           n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p, emask.p, cfast.p);
-            else hipLaunchKernelGGL((sketch_fast_kernel<false, false>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
-                                    n_chunks, C, w, k, moff, crel, ccnt, out, rid_base, slow_list.p, n_slow.p, emask.p, cfast.p);
+            if (hash64) hipLaunchKernelGGL(sketch_fast_kernel<true>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                           n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p);
+            else hipLaunchKernelGGL(sketch_fast_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                                    n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p);
         }
         if (fill) {
             // the staged chunks are copied into place; the automaton runs a second time only for the listed chunks beyond the staging
