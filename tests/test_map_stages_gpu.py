@@ -67,6 +67,22 @@ def test_sketch_adversarial_matches_oracle(libmpn, oracle_built):
             assert np.array_equal(got[i], want), (k, w, i, len(sq), len(got[i]), len(want))
 
 
+def test_sketch_more_irregular_chunks_than_staging(libmpn, oracle_built):
+    """The automaton kernel stages its reports for the chunks the host lists + 2048 of those the fast kernel appends; a sequence
+    with an ambiguous base every few hundred positions has more: the rest take the automaton's own second pass."""
+    from megapath_nano_amd import mapper
+    from oracle import mm2_bindings as mb
+    rng = np.random.default_rng(78)
+    alpha = np.frombuffer(b'ACGT', dtype=np.uint8)
+    s = alpha[rng.integers(0, 4, size=1_300_000)]
+    s[rng.integers(0, len(s), size=len(s) // 300)] = ord('N')
+    t = alpha[rng.integers(0, 4, size=40_000)]
+    got = mapper.sketch_batch([t, s, t[:3000]])
+    for i, sq in enumerate([t, s, t[:3000]]):
+        want = mb.sketch(sq, 10, 15, i)
+        assert np.array_equal(got[i], want), (i, len(got[i]), len(want))
+
+
 def test_index_matches_oracle(world):
     import ctypes as ct
     from oracle import mm2_bindings as mb
