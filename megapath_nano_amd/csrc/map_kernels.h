@@ -1423,7 +1423,8 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                     }
                 }
                 const bool elig = !cont && lane < brk;
-                const int best = wave_reduce_max(elig ? sc : NEG_INF);
+                // the best eligible score is the running maximum at the last eligible lane: no second scan
+                const int best = brk > 0 ? __builtin_amdgcn_readlane(incl, brk - 1) : NEG_INF;
                 if (best > max_f) {
                     const unsigned long long who = __ballot(elig && sc == best);
                     const int wl = __builtin_ctzll(who);
