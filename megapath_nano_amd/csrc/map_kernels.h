@@ -1371,13 +1371,19 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
             for (int64_t j0 = i - 1; j0 >= 0 && !done; j0 -= 64) {
                 const int64_t j = j0 - lane;
                 const bool inw = j >= win_lo;
+                // A tile that lies in the LDS ring as a whole takes the short way with the marks below: every predecessor that
+                // passes the filters marks its own predecessor in the ring BEFORE the marks are read.  A mark goes to a LATER
+                // lane (an earlier anchor) only, so a lane still sees exactly the marks of the lanes before it; the marks of
+                // lanes at or past the break land on lanes past the break, which are not evaluated, and a stale mark `i` means
+                // nothing to the anchors after i.  Two LDS round trips per tile instead of four.
+                const bool tile_in_ring = j0 - 63 >= win_lo;   // (uniform)
                 bool in = j >= 0 && i - j <= cp.max_iter;
                 bool cont = true;
                 int32_t sc = NEG_INF, pj = -1, tj = 0;
                 if (in) {
                     uint64_t ax, ay;
                     int32_t fj;
-                    if (inw) { const int sl = (int)(j & M); ax = wx[sl]; ay = wy[sl]; pj = wp[sl]; tj = wt[sl]; fj = wf[sl]; }
+                    if (inw) { const int sl = (int)(j & M); ax = wx[sl]; ay = wy[sl]; pj = wp[sl]; if (!tile_in_ring) tj = wt[sl]; fj = wf[sl]; }
                     else { ax = a[j].x; ay = a[j].y; pj = p[j]; pj = pj >= 0 ? pj - rel : pj; tj = t[j]; fj = f[j]; }
                     if (ri > ax + (uint64_t)cp.max_dist_x) in = false;  // out of range: so is everything before it
                     else {
@@ -1400,11 +1406,21 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                 // the range ends inside (or right after) this tile if any lane fell out of it
                 if (__ballot(!in)) done = true;
                 // marks made by earlier lanes of this tile (p[j'] == my j)
-                mark[lane] = 0;
-                MPN_LDS_FENCE();
-                if (!cont && pj >= 0 && j0 - pj < 64 && j0 - pj >= 0) mark[(int)(j0 - pj)] = 1;
-                MPN_LDS_FENCE();
-                const bool tmark = (tj == (int32_t)i) || mark[lane];
+                bool tmark, gmark = false;
+                if (tile_in_ring) {
+                    if (!cont && pj >= 0) {
+                        if (pj >= win_lo) wt[(int)(pj & M)] = (int32_t)i;
+                        else { t[pj] = (int32_t)i; gmark = true; }
+                    }
+                    MPN_LDS_FENCE();
+                    tmark = j >= 0 && wt[(int)(j & M)] == (int32_t)i;
+                } else {
+                    mark[lane] = 0;
+                    MPN_LDS_FENCE();
+                    if (!cont && pj >= 0 && j0 - pj < 64 && j0 - pj >= 0) mark[(int)(j0 - pj)] = 1;
+                    MPN_LDS_FENCE();
+                    tmark = (tj == (int32_t)i) || mark[lane];
+                }
                 // running maximum before each lane (sequential order = lane order)
                 const int incl = wave_scan_max(cont ? NEG_INF : sc);
                 const int excl_raw = wave_shr1(incl, NEG_INF);
@@ -1431,8 +1447,7 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                     max_f = best;
                     max_j = j0 - wl;
                 }
-                bool gmark = false;
-                if (elig && pj >= 0) {
+                if (!tile_in_ring && elig && pj >= 0) {
                     if (pj >= win_lo) wt[(int)(pj & M)] = (int32_t)i;
                     else { t[pj] = (int32_t)i; gmark = true; }
                 }
