@@ -1427,17 +1427,16 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                 const int before = max(max_f, excl_raw);
                 const bool newmax = !cont && sc > before;
                 const bool skipev = !cont && !newmax && tmark;
-                unsigned long long m1 = __ballot(newmax), m2 = __ballot(skipev);
-                int brk = 64;
-                {
-                    unsigned long long m = m1 | m2;
-                    while (m) {
-                        const int b = __builtin_ctzll(m);
-                        if ((m1 >> b) & 1) { if (n_skip > 0) --n_skip; }
-                        else if (++n_skip > cp.max_skip) { brk = b; break; }
-                        m &= m - 1;
-                    }
-                }
+                // minimap2's skip counter over the lanes in order -- a new maximum takes one off (not below 0), a marked predecessor
+                // that does not improve adds one, and the walk breaks when it exceeds max_skip -- is the clamped running sum
+                // s_l = max(s_{l-1} + d_l, 0) = Q_l + max(s_before, -min_{t<=l} Q_t) with Q the prefix sum of d: two wave scans
+                // (a serial loop over the set lanes was half of this kernel's time)
+                const int Qs = wave_scan_add(newmax ? -1 : skipev ? 1 : 0);
+                const int minQ = -wave_scan_max(-Qs);
+                const int skips = Qs + max(n_skip, -minQ);
+                const unsigned long long over = __ballot(skipev && skips > cp.max_skip);
+                const int brk = over ? __builtin_ctzll(over) : 64;
+                if (!over) n_skip = __builtin_amdgcn_readlane(skips, 63);
                 const bool elig = !cont && lane < brk;
                 // the best eligible score is the running maximum at the last eligible lane: no second scan
                 const int best = brk > 0 ? __builtin_amdgcn_readlane(incl, brk - 1) : NEG_INF;

@@ -121,6 +121,16 @@ __device__ __forceinline__ int wave_scan_max(int v) {
     v = max(v, dpp_mov<0x143, 0xc>(NEG_INF, v));
     return v;
 }
+// inclusive prefix sum over the 64 lanes (the same DPP ladder; lanes a shift does not reach add 0)
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp_mov<0x111, 0xf>(0, v);
+    v += dpp_mov<0x112, 0xf>(0, v);
+    v += dpp_mov<0x114, 0xf>(0, v);
+    v += dpp_mov<0x118, 0xf>(0, v);
+    v += dpp_mov<0x142, 0xa>(0, v);
+    v += dpp_mov<0x143, 0xc>(0, v);
+    return v;
+}
 __device__ __forceinline__ int wave_reduce_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
 __device__ __forceinline__ int wave_reduce_min(int v) { return -wave_reduce_max(-v); }
 
