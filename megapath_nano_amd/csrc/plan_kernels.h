@@ -31,6 +31,8 @@ struct AnchorView {
     u128 *g;          // the read's anchors in global memory
     u128 *l;          // LDS copy of [lo, hi)
     int lo, hi;
+    const unsigned long long *kb;   // bit r: the gap between anchors lo + r - 1 and lo + r exceeds mm_filter_bad_seeds' min_gap (set by the wave)
+    int kb_n;                       // anchors the bits cover (r < kb_n)
     __device__ __forceinline__ u128 operator[](int i) const { return (i >= lo && i < hi) ? l[i - lo] : g[i]; }
     __device__ __forceinline__ void or_y(int i, uint64_t f) { g[i].y |= f; if (i >= lo && i < hi) l[i - lo].y |= f; }
 };
@@ -40,7 +42,20 @@ struct AnchorView {
 __device__ inline void pk_filter_bad_seeds(int as1, int cnt1, AnchorView &a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
     auto gap_at = [&](int i) { return (pk_y(a[as1 + i]) - pk_y(a[as1 + i - 1])) - (pk_x(a[as1 + i]) - pk_x(a[as1 + i - 1])); };
     auto is_k = [&](int i) { const int g = gap_at(i); return g < -min_gap || g > min_gap; };
-    auto next_k = [&](int i) { for (++i; i < cnt1; ++i) if (is_k(i)) return i; return cnt1; };   // anchor index of the next K entry (cnt1: none)
+    // anchor index of the next K entry (cnt1: none): a scan of the bits the wave prepared (a walk over the anchors beyond them)
+    const int off = as1 - a.lo;
+    auto next_k = [&](int i) {
+        ++i;
+        int r = i + off;
+        while (r < a.kb_n && i < cnt1) {
+            const unsigned long long w = a.kb[r >> 6] >> (r & 63);
+            if (w) { const int s_ = __builtin_ctzll(w); return i + s_ < cnt1 ? i + s_ : cnt1; }
+            const int step = 64 - (r & 63);
+            r += step; i += step;
+        }
+        for (; i < cnt1; ++i) if (is_k(i)) return i;
+        return cnt1;
+    };
     int first = next_k(0);
     if (first >= cnt1 || next_k(first) >= cnt1) return;   // fewer than two entries
     int max = 0, max_st_k = -1, max_en_k = -1, max_st_i = -1, max_en_i = -1;
@@ -72,7 +87,7 @@ __device__ inline void pk_filter_bad_seeds(int as1, int cnt1, AnchorView &a, int
 }
 
 // The planning half of mm_align1 for one hit.  FILL = false counts the windows; FILL = true writes them (jobs, job_anchor) and
-// the hit's stitching record.  Both passes set the same SEED_IGNORE flags (the filter is idempotent).
+// the hit's stitching record.  The counting pass sets the SEED_IGNORE flags (the filter is the most expensive walk), the other reads them.
 template <bool FILL>
 __device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, AnchorView &a, const int32_t *__restrict__ tlens, int32_t ri, int32_t first_job,
                                ExtJob *__restrict__ jobs, int32_t *__restrict__ job_anchor, StitchReg *__restrict__ sregs, PlanSum *__restrict__ psum) {
@@ -121,7 +136,7 @@ __device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, AnchorView &
             if (l >= o.bw << 1 || (m >= min_match && m >= o.bw) || m >= pr.mlen >> 1) break;
         }
     }
-    pk_filter_bad_seeds(as1, cnt1, a, 10, 40, o.max_gap >> 1, 10);
+    if constexpr (!FILL) pk_filter_bad_seeds(as1, cnt1, a, 10, 40, o.max_gap >> 1, 10);   // (the counting pass has set the flags)
     // ---- limits of the two extensions ----
     int32_t rs = pk_x(a[as1]) - kh, qs = pk_y(a[as1]) - kh;
     int32_t re = pk_x(a[as1 + cnt1 - 1]) - kh, qe = pk_y(a[as1 + cnt1 - 1]) - kh;
@@ -207,17 +222,33 @@ __device__ inline int plan_hit(const PlanOpt &o, const PlanReg &pr, AnchorView &
 // One wave per hit: the 64 lanes stage the hit's anchors in LDS, lane 0 counts the hit's windows, reserves their slots in the
 // job array (one atomic per hit; the windows of a hit are contiguous, hits come in no particular order) and writes them.
 constexpr int PLAN_LDS_ANCHORS = 1024;   // 16 KB: the rest of a longer hit (reads beyond ~50 kb) is walked in global memory
+constexpr int PLAN_KBITS = 8192;         // anchors of a hit whose "large gap" flags (mm_filter_bad_seeds' K list) the wave prepares as bits
 __global__ __launch_bounds__(64) void plan_kernel(PlanOpt o, const PlanReg *__restrict__ pregs, int n_regs, u128 *__restrict__ A,
                                                   const int32_t *__restrict__ tlens, unsigned long long *__restrict__ n_jobs_total,
                                                   ExtJob *__restrict__ jobs, int32_t *__restrict__ job_anchor, StitchReg *__restrict__ sregs,
                                                   PlanSum *__restrict__ psum) {
     __shared__ u128 lds_a[PLAN_LDS_ANCHORS];
+    __shared__ unsigned long long lds_kb[PLAN_KBITS / 64];
     const int lane = threadIdx.x;
     for (int ri = blockIdx.x; ri < n_regs; ri += gridDim.x) {
         const PlanReg pr = pregs[ri];
         AnchorView av;
         av.g = A + pr.a_off; av.l = lds_a; av.lo = pr.as; av.hi = pr.as + (pr.cnt < PLAN_LDS_ANCHORS ? pr.cnt : PLAN_LDS_ANCHORS);
+        av.kb = lds_kb; av.kb_n = pr.cnt < PLAN_KBITS ? pr.cnt : PLAN_KBITS;
         for (int i = lane; i < av.hi - av.lo; i += 64) lds_a[i] = av.g[av.lo + i];
+        __syncthreads();
+        // the K list of mm_filter_bad_seeds as bits: 64 anchors per step instead of one per dependent load of lane 0's walk
+        for (int r0 = 0; r0 < av.kb_n; r0 += 64) {
+            const int r = r0 + lane;
+            bool big = false;
+            if (r >= 1 && r < av.kb_n) {
+                const u128 cur = av[av.lo + r], prev = av[av.lo + r - 1];
+                const int gp = (pk_y(cur) - pk_y(prev)) - (pk_x(cur) - pk_x(prev));
+                big = gp < -10 || gp > 10;   // (min_gap of the call in plan_hit)
+            }
+            const unsigned long long m = __ballot(big);
+            if (lane == 0) lds_kb[r0 >> 6] = m;
+        }
         __syncthreads();
         if (lane == 0) {
             const int nj = plan_hit<false>(o, pr, av, tlens, ri, 0, jobs, job_anchor, sregs, psum);
