@@ -892,7 +892,8 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
                 hipLaunchKernelGGL((ext_dp_band_kernel<NW, TT>), dim3(n), dim3(NW * 64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, \
                                    d_read_len, rv, P.p, d_res.p);                                                                    \
             } while (0)
-            if (bvar == 0) MPN_BAND_LAUNCH(1, 2); else if (bvar == 1) MPN_BAND_LAUNCH(1, 4); else if (bvar == 2) MPN_BAND_LAUNCH(2, 4); else MPN_BAND_LAUNCH(4, 4);
+            // (two slots per thread: what bounds these kernels is the latency of an anti-diagonal, i.e. the cells a thread computes in a row)
+            if (bvar == 0) MPN_BAND_LAUNCH(1, 2); else if (bvar == 1) MPN_BAND_LAUNCH(2, 2); else if (bvar == 2) MPN_BAND_LAUNCH(4, 2); else MPN_BAND_LAUNCH(8, 2);
 #undef MPN_BAND_LAUNCH
         }
         MPN_HIP_CHECK(hipGetLastError());
