@@ -79,7 +79,9 @@ __device__ __forceinline__ bool sketch_chunk_in_range(int p0, int p1, int len, i
     return (k & 1) && w <= SKETCH_FAST_MAX_W && *A0 >= 0 && *A1 <= len;
 }
 
-template <bool HASH64>
+// (W_CT: the window length at compile time, 0 = the run-time argument; with it the 2 (w - 1) LDS reads of the window test are
+// unrolled and issued together instead of one round trip each)
+template <bool HASH64, int W_CT = 0>
 __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
                                                           const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
@@ -162,9 +164,20 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
                 const hash_t hp = hs[q];
                 int L = 0, R = 0;
                 bool go = true;
-                for (int d = 1; d < w; ++d) { go = go && hs[q - d] >= hp; L += go; }
-                go = true;
-                for (int d = 1; d < w; ++d) { go = go && hs[q + d] >= hp; R += go; }
+                if constexpr (W_CT > 0) {
+                    hash_t hl[W_CT - 1], hr[W_CT - 1];
+#pragma unroll
+                    for (int d = 1; d < W_CT; ++d) { hl[d - 1] = hs[q - d]; hr[d - 1] = hs[q + d]; }
+#pragma unroll
+                    for (int d = 1; d < W_CT; ++d) { go = go && hl[d - 1] >= hp; L += go; }
+                    go = true;
+#pragma unroll
+                    for (int d = 1; d < W_CT; ++d) { go = go && hr[d - 1] >= hp; R += go; }
+                } else {
+                    for (int d = 1; d < w; ++d) { go = go && hs[q - d] >= hp; L += go; }
+                    go = true;
+                    for (int d = 1; d < w; ++d) { go = go && hs[q + d] >= hp; R += go; }
+                }
                 emit = L + R >= w - 1;
             }
             const unsigned long long em = __ballot(emit);

@@ -144,10 +144,10 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
             else hipLaunchKernelGGL(sketch_fill_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, n_chunks, C,
                                     w, k, moff, crel, out, rid_base, (const unsigned long long *)emask.p, (const uint8_t *)cfast.p);
         } else {
-            if (hash64) hipLaunchKernelGGL(sketch_fast_kernel<true>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
-                                           n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p);
-            else hipLaunchKernelGGL(sketch_fast_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
-                                    n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p);
+#define MPN_SKETCH_FAST(H, WCT) hipLaunchKernelGGL((sketch_fast_kernel<H, WCT>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, \
+                                                  (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p)
+            if (hash64) MPN_SKETCH_FAST(true, 0); else if (w == 10) MPN_SKETCH_FAST(false, 10); else MPN_SKETCH_FAST(false, 0);   // (-x map-ont: w = 10)
+#undef MPN_SKETCH_FAST
         }
         if (fill) {
             // the staged chunks are copied into place; the automaton runs a second time only for the listed chunks beyond the staging
