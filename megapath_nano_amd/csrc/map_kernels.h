@@ -79,13 +79,20 @@ __device__ __forceinline__ bool sketch_chunk_in_range(int p0, int p1, int len, i
     return (k & 1) && w <= SKETCH_FAST_MAX_W && *A0 >= 0 && *A1 <= len;
 }
 
+// chunk -> sequence table: a wave per sequence writes its index over the sequence's chunks
+__global__ __launch_bounds__(256) void sketch_chunk_read_kernel(const int64_t *__restrict__ chunk_off, int n, int32_t *__restrict__ chunk_read) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4)
+        for (int64_t c = chunk_off[i] + lane; c < chunk_off[i + 1]; c += 64) chunk_read[c] = i;
+}
+
 // (W_CT: the window length at compile time, 0 = the run-time argument; with it the 2 (w - 1) LDS reads of the window test are
 // unrolled and issued together instead of one round trip each)
 template <bool HASH64, int W_CT = 0>
 __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
-                                                          const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
-                                                          int32_t *__restrict__ chunk_cnt,
+                                                          const int64_t *__restrict__ chunk_off, const int32_t *__restrict__ chunk_read, int64_t n_chunks,
+                                                          int C, int w, int k, int32_t *__restrict__ chunk_cnt,
                                                           int64_t *__restrict__ slow_list, unsigned long long *__restrict__ n_slow,
                                                           unsigned long long *__restrict__ emask, uint8_t *__restrict__ cfast) {
     // per wave: packed bases (2 bits each, first base in the top bits of a word), hashes of the k-mer end positions
@@ -98,9 +105,7 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
     hash_t *hs = s_hash[wv];
     const uint64_t mask = (1ULL << 2 * k) - 1;
     for (int64_t c = (int64_t)blockIdx.x * 4 + wv; c < n_chunks; c += (int64_t)gridDim.x * 4) {
-        int lo = 0, hi = n;  // last sequence with chunk_off[seq] <= c
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
-        const int i = lo;
+        const int i = chunk_read[c];   // (the sequence of the chunk: a table, not a search over chunk_off per chunk)
         const uint8_t *sq = seqs + seq_off[i];
         const int len = seq_len[i];
         const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(256) void sketch_fast_kernel(const uint8_t *__restr
 template <bool HASH64>
 __global__ __launch_bounds__(256) void sketch_fill_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
-                                                          const int64_t *__restrict__ chunk_off, int64_t n_chunks, int C, int w, int k,
+                                                          const int64_t *__restrict__ chunk_off, const int32_t *__restrict__ chunk_read, int64_t n_chunks,
+                                                          int C, int w, int k,
                                                           const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
                                                           u128 *__restrict__ mz, uint32_t rid_base,
                                                           const unsigned long long *__restrict__ emask, const uint8_t *__restrict__ cfast) {
@@ -210,9 +216,7 @@ __global__ __launch_bounds__(256) void sketch_fill_kernel(const uint8_t *__restr
     const unsigned long long lane_lt = (1ULL << lane) - 1;
     for (int64_t c = (int64_t)blockIdx.x * 4 + wv; c < n_chunks; c += (int64_t)gridDim.x * 4) {
         if (!cfast[c]) continue;   // the automaton kernel's chunk
-        int lo = 0, hi = n;  // last sequence with chunk_off[seq] <= c
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
-        const int i = lo;
+        const int i = chunk_read[c];   // (the sequence of the chunk: a table, not a search over chunk_off per chunk)
         const uint8_t *sq = seqs + seq_off[i];
         const int len = seq_len[i];
         const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
@@ -266,7 +270,8 @@ constexpr int SKETCH_STAGE_CAP = 256;   // reports per staged chunk (= C: one pe
 template <bool FILL>
 __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
                                                           const int32_t *__restrict__ seq_len, int n,
-                                                          const int64_t *__restrict__ chunk_off, const int64_t *__restrict__ slow_list,
+                                                          const int64_t *__restrict__ chunk_off, const int32_t *__restrict__ chunk_read,
+                                                          const int64_t *__restrict__ slow_list,
                                                           const unsigned long long *__restrict__ n_slow, int C, int w, int k,
                                                           const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
                                                           int32_t *__restrict__ chunk_cnt, u128 *__restrict__ mz, uint32_t rid_base,
@@ -279,9 +284,7 @@ __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restr
     const int64_t n_list = (int64_t)*n_slow;
     for (int64_t li = li_begin + (int64_t)blockIdx.x * blockDim.x + tid; li < n_list; li += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = slow_list[li];
-    int lo = 0, hi = n;  // last read with chunk_off[read] <= c
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
-    const int i = lo;
+    const int i = chunk_read[c];
     const uint8_t *s = seqs + seq_off[i];
     const int len = seq_len[i];
     const int p0 = (int)(c - chunk_off[i]) * C, p1 = min(len, p0 + C);
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(64) void sketch_chunk_kernel(const uint8_t *__restr
 }
 
 // the staged reports of the automaton kernel's count pass go to their places: a wave per listed chunk
-__global__ __launch_bounds__(256) void sketch_stage_copy_kernel(const int64_t *__restrict__ chunk_off, int n, const int64_t *__restrict__ slow_list,
+__global__ __launch_bounds__(256) void sketch_stage_copy_kernel(const int32_t *__restrict__ chunk_read, const int64_t *__restrict__ slow_list,
                                                                 const unsigned long long *__restrict__ n_slow, int64_t stage_chunks,
                                                                 const int64_t *__restrict__ mz_off, const int32_t *__restrict__ chunk_rel,
                                                                 const int32_t *__restrict__ chunk_cnt, const u128 *__restrict__ stage,
@@ -375,10 +378,8 @@ __global__ __launch_bounds__(256) void sketch_stage_copy_kernel(const int64_t *_
     const int64_t n_list = min((int64_t)*n_slow, stage_chunks);
     for (int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); li < n_list; li += (int64_t)gridDim.x * 4) {
         const int64_t c = slow_list[li];
-        int lo = 0, hi = n;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= c) lo = mid; else hi = mid; }
         const int cnt = chunk_cnt[c];
-        u128 *out = mz + mz_off[lo] + chunk_rel[c];
+        u128 *out = mz + mz_off[chunk_read[c]] + chunk_rel[c];
         const u128 *in = stage + li * SKETCH_STAGE_CAP;
         for (int q = lane; q < cnt; q += 64) out[q] = in[q];
     }

@@ -99,12 +99,14 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
     DevBuf<int32_t> chunk_cnt, chunk_rel;
     DevBuf<unsigned long long> n_slow, emask;
     DevBuf<uint8_t> cfast;
+    DevBuf<int32_t> chunk_read;
     DevBuf<u128> stage;
     int64_t stage_chunks = 0;
     if (cnt.alloc((size_t)n + 1) || mz_off.alloc((size_t)n + 1) || d_chunk_off.upload(chunk_off.data(), (size_t)n + 1, st) ||
         chunk_cnt.alloc((size_t)n_chunks) || chunk_rel.alloc((size_t)n_chunks) || slow_list.alloc((size_t)n_chunks) || n_slow.alloc(1) ||
-        emask.alloc((size_t)n_chunks * 4 + 4) || cfast.alloc((size_t)n_chunks + 1))
+        emask.alloc((size_t)n_chunks * 4 + 4) || cfast.alloc((size_t)n_chunks + 1) || chunk_read.alloc((size_t)n_chunks + 1))
         return -1;
+    hipLaunchKernelGGL(sketch_chunk_read_kernel, dim3(std::max(1, std::min((n + 3) / 4, 4096))), dim3(256), 0, st, (const int64_t *)d_chunk_off.p, n, chunk_read.p);
     {
         // the chunks that are irregular by their place in the sequence (its first chunk(s), its last one(s); all of them for
         // even k or a very wide window: the same rule as sketch_chunk_in_range) start the automaton kernel's list
@@ -139,25 +141,25 @@ int sketch_device(const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_
         int32_t *ccnt = fill ? nullptr : chunk_cnt.p;
         // (the count pass leaves the emit masks; the second pass of the regular chunks hashes the emitted positions only)
         if (fill) {
-            if (hash64) hipLaunchKernelGGL(sketch_fill_kernel<true>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, n_chunks, C,
+            if (hash64) hipLaunchKernelGGL(sketch_fill_kernel<true>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, (const int32_t *)chunk_read.p, n_chunks, C,
                                            w, k, moff, crel, out, rid_base, (const unsigned long long *)emask.p, (const uint8_t *)cfast.p);
-            else hipLaunchKernelGGL(sketch_fill_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, n_chunks, C,
+            else hipLaunchKernelGGL(sketch_fill_kernel<false>, dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, (const int32_t *)chunk_read.p, n_chunks, C,
                                     w, k, moff, crel, out, rid_base, (const unsigned long long *)emask.p, (const uint8_t *)cfast.p);
         } else {
 #define MPN_SKETCH_FAST(H, WCT) hipLaunchKernelGGL((sketch_fast_kernel<H, WCT>), dim3(fast_grid), dim3(256), 0, st, d_seqs, d_off, d_len, n, \
-                                                  (const int64_t *)d_chunk_off.p, n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p)
+                                                  (const int64_t *)d_chunk_off.p, (const int32_t *)chunk_read.p, n_chunks, C, w, k, ccnt, slow_list.p, n_slow.p, emask.p, cfast.p)
             if (hash64) MPN_SKETCH_FAST(true, 0); else if (w == 10) MPN_SKETCH_FAST(false, 10); else MPN_SKETCH_FAST(false, 0);   // (-x map-ont: w = 10)
 #undef MPN_SKETCH_FAST
         }
         if (fill) {
             // the staged chunks are copied into place; the automaton runs a second time only for the listed chunks beyond the staging
-            hipLaunchKernelGGL(sketch_stage_copy_kernel, dim3(slow_grid), dim3(256), 0, st, (const int64_t *)d_chunk_off.p, n, (const int64_t *)slow_list.p,
+            hipLaunchKernelGGL(sketch_stage_copy_kernel, dim3(slow_grid), dim3(256), 0, st, (const int32_t *)chunk_read.p, (const int64_t *)slow_list.p,
                                (const unsigned long long *)n_slow.p, stage_chunks, moff, crel, (const int32_t *)chunk_cnt.p, (const u128 *)stage.p, out);
             if (stage_chunks < n_chunks)
-                hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+                hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, (const int32_t *)chunk_read.p,
                                    (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base,
                                    (u128 *)nullptr, (int64_t)0, stage_chunks);
-        } else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p,
+        } else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3(slow_grid), dim3(64), lds, st, d_seqs, d_off, d_len, n, (const int64_t *)d_chunk_off.p, (const int32_t *)chunk_read.p,
                                   (const int64_t *)slow_list.p, (const unsigned long long *)n_slow.p, C, w, k, moff, crel, ccnt, out, rid_base,
                                   stage.p, stage_chunks, (int64_t)0);
     };
