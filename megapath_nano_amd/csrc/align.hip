@@ -916,15 +916,20 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     const int side_lo[2] = {base[L_WG], base[L_BAND + 8]}, side_hi[2] = {base[L_STRIP], base[N_LISTS]};
     const int main_lo[2] = {0, base[L_STRIP]}, main_hi[2] = {base[L_WG], base[L_BAND + 8]};
     auto bt_ztest = [&](const int *lo, const int *hi, hipStream_t s, bool timed) -> int {
-        // traceback, then the z-drop test of the gap-fill CIGARs (the test skips the other windows; flagged ones are recomputed with the
-        // exact maximum): one launch, a lane tests the CIGAR it has just written
         for (int k = 0; k < 2; ++k) {
             const int n = hi[k] - lo[k];
-            if (n > 0) hipLaunchKernelGGL(ext_bt_ztest_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, P.p, OFF.p, CIG.p, d_compact, d_used,
-                                          d_res.p, prm, d_reads, d_read_off, d_read_len, rv, d_redo_ids, d_used + 1, d_probes, d_used + 5);
+            if (n > 0) hipLaunchKernelGGL(ext_bt_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, P.p, OFF.p, CIG.p, d_compact, d_used, d_res.p);
         }
         MPN_HIP_CHECK(hipGetLastError());
         if (timed) ev.mark(25);
+        // z-drop test of the gap-fill CIGARs (the kernel skips the other windows); flagged ones are recomputed with the exact maximum
+        for (int k = 0; k < 2; ++k) {
+            const int n = hi[k] - lo[k];
+            if (n > 0) hipLaunchKernelGGL(ext_ztest_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs.p, d_order.p + lo[k], n, prm, d_reads, d_read_off, d_read_len, rv, CIG.p, d_res.p,
+                                          d_redo_ids, d_used + 1, d_probes, d_used + 5);
+        }
+        MPN_HIP_CHECK(hipGetLastError());
+        if (timed) ev.mark(26);
         return 0;
     };
     if (bt_ztest(side_lo, side_hi, SL.st2, false)) return -1;

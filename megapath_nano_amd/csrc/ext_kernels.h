@@ -7,8 +7,7 @@
 //                             clipped fills, the exact second pass): band in registers, one barrier per anti-diagonal
 //   ext_dp_kernel, ext_dp_wg_kernel<NT>   fallbacks (wider bands, windows beyond LDS): Suzuki-Kasahara states u,v,x,y,x2,y2
 //                             and the H row in LDS or global scratch, one wave or one workgroup per window
-//   ext_bt_ztest_kernel (ext_bt_kernel for the second pass)   one LANE per window: traceback is a serial pointer chase, the z-drop
-//                             test a walk of the CIGAR the lane has just written
+//   ext_bt_kernel, ext_ztest_kernel        one LANE per window: traceback is a serial pointer chase, the z-drop test a CIGAR walk
 #pragma once
 #include "mpn_common.h"
 #include "map_types.h"
@@ -1013,10 +1012,10 @@ __global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restri
 }
 
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
-__device__ __forceinline__ void ext_bt_body(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                            const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
-                                            uint32_t *__restrict__ CIG, uint32_t *__restrict__ COMPACT,
-                                            unsigned long long *__restrict__ compact_used, ExtRes *__restrict__ res) {
+__global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                    const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
+                                                    uint32_t *__restrict__ CIG, uint32_t *__restrict__ COMPACT,
+                                                    unsigned long long *__restrict__ compact_used, ExtRes *__restrict__ res) {
     // (no early exit: the whole wave meets again at the end to reserve its slice of the compact pool with ONE atomic --
     // one atomic per job on a single counter serialises tens of thousands of lanes at the memory side)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,13 +1098,13 @@ __device__ __forceinline__ void ext_bt_body(const ExtJob *__restrict__ jobs, con
 }
 
 // z-drop test of a finished gap-fill CIGAR (minimap2 mm_test_zdrop without the inversion probe): one lane per job
-__device__ __forceinline__ void ext_ztest_body(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                               const ExtParams &prm, const uint8_t *__restrict__ reads,
-                                               const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                               const RefView &rv,
-                                               const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res,
-                                               int32_t *__restrict__ redo_ids, unsigned long long *__restrict__ n_redo,
-                                               InvProbe *__restrict__ probes, unsigned long long *__restrict__ n_probe) {
+__global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                       ExtParams prm, const uint8_t *__restrict__ reads,
+                                                       const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                       RefView rv,
+                                                       const uint32_t *__restrict__ CIG, ExtRes *__restrict__ res,
+                                                       int32_t *__restrict__ redo_ids, unsigned long long *__restrict__ n_redo,
+                                                       InvProbe *__restrict__ probes, unsigned long long *__restrict__ n_probe) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_jobs) return;
     const int jid = order[k];
@@ -1168,27 +1167,6 @@ __device__ __forceinline__ void ext_ztest_body(const ExtJob *__restrict__ jobs, 
         return;
     }
     report(over);
-}
-
-__global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                                    const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
-                                                    uint32_t *__restrict__ CIG, uint32_t *__restrict__ COMPACT,
-                                                    unsigned long long *__restrict__ compact_used, ExtRes *__restrict__ res) {
-    ext_bt_body(jobs, order, n_jobs, P, OFF, CIG, COMPACT, compact_used, res);
-}
-
-// traceback and z-drop test of the same windows in one launch: a lane tests the CIGAR it has just written (one kernel boundary and
-// one "longest window of the launch" less on the stream)
-__global__ __launch_bounds__(64) void ext_bt_ztest_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                                          const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
-                                                          uint32_t *__restrict__ CIG, uint32_t *__restrict__ COMPACT,
-                                                          unsigned long long *__restrict__ compact_used, ExtRes *__restrict__ res,
-                                                          ExtParams prm, const uint8_t *__restrict__ reads,
-                                                          const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len, RefView rv,
-                                                          int32_t *__restrict__ redo_ids, unsigned long long *__restrict__ n_redo,
-                                                          InvProbe *__restrict__ probes, unsigned long long *__restrict__ n_probe) {
-    ext_bt_body(jobs, order, n_jobs, P, OFF, CIG, COMPACT, compact_used, res);
-    ext_ztest_body(jobs, order, n_jobs, prm, reads, read_off, read_len, rv, CIG, res, redo_ids, n_redo, probes, n_probe);
 }
 
 }  // namespace mpn
