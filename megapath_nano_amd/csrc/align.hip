@@ -37,7 +37,7 @@ int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32
                 DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st);
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
                       const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st);
-int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st);
+int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, bool with_anchors);
 
 const char *get_error();
 
@@ -55,6 +55,11 @@ struct Reg {
     int32_t aligned = 0;  // base-level extension already done (or not needed)
     int32_t fin_qs = 0, fin_rs = 0, fin_ql = 0, fin_tl = 0;   // an inversion hit before its extension: the window to extend
     int32_t fin_idx = -1;  // >= 0: stitched this round (its index among the round's hits): CIGAR fix-up and statistics are due
+    // The hit's first and last chained anchor (the anchors themselves stay in HBM: chain_backtrack_kernel's ChainRec) and, until
+    // the squeeze, where its chain lies in the chain stage's pool (relative to the read's b_pos) and its segment of the squeeze
+    uint64_t fx = 0, fy = 0, lx = 0, ly = 0;
+    int64_t src = 0;
+    int32_t seg = -1;
 };
 
 static inline uint64_t hash64(uint64_t key) {
@@ -78,51 +83,48 @@ static inline uint32_t x31_hash(const char *s) {
     return h;
 }
 
-static void cal_fuzzy_len(Reg &r, const u128 *a) {
-    r.mlen = r.blen = 0;
-    if (r.cnt <= 0) return;
-    r.mlen = r.blen = a[r.as].y >> 32 & 0xff;
-    for (int i = r.as + 1; i < r.as + r.cnt; ++i) {
-        const int span = a[i].y >> 32 & 0xff;
-        const int tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-        r.blen += tl > ql ? tl : ql;
-        r.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
-    }
+// mm_reg_set_coor from the hit's first and last anchor (the approximate lengths of mm_cal_fuzzy_len come with the chain
+// record, or are combined from two hits' when they are joined)
+static void reg_set_coor(Reg &r, int32_t qlen) {
+    const int32_t q_span = (int32_t)(r.fy >> 32 & 0xff);
+    r.rev = r.fx >> 63;
+    r.rid = r.fx << 1 >> 33;
+    r.rs = (int32_t)r.fx + 1 > q_span ? (int32_t)r.fx + 1 - q_span : 0;
+    r.re = (int32_t)r.lx + 1;
+    if (!r.rev) { r.qs = (int32_t)r.fy + 1 - q_span; r.qe = (int32_t)r.ly + 1; }
+    else { r.qs = qlen - ((int32_t)r.ly + 1); r.qe = qlen - ((int32_t)r.fy + 1 - q_span); }
 }
 
-static void reg_set_coor(Reg &r, int32_t qlen, const u128 *a) {
-    const int32_t k = r.as, q_span = (int32_t)(a[k].y >> 32 & 0xff);
-    r.rev = a[k].x >> 63;
-    r.rid = a[k].x << 1 >> 33;
-    r.rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
-    r.re = (int32_t)a[k + r.cnt - 1].x + 1;
-    if (!r.rev) { r.qs = (int32_t)a[k].y + 1 - q_span; r.qe = (int32_t)a[k + r.cnt - 1].y + 1; }
-    else { r.qs = qlen - ((int32_t)a[k + r.cnt - 1].y + 1); r.qe = qlen - ((int32_t)a[k].y + 1 - q_span); }
-    cal_fuzzy_len(r, a);
-}
+// Chain c of a read in the order of the first anchors (the order minimap2's chaining leaves them in, HostChains::chain_order):
+// its (score, count) word, its record and the start of its anchors relative to the read's slice of the chain pool
+struct ChainIn { uint64_t u; const ChainRec *rec; int64_t src; };
 
-static void gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const u128 *a, std::vector<Reg> &regs) {
-    struct Z { uint64_t x, y; };
+static void gen_regs(uint32_t hash, int qlen, int n_u, const ChainIn *c, std::vector<Reg> &regs) {
+    struct Z { uint64_t x, y; int i; };
     std::vector<Z> z(n_u);
     int k = 0;
     for (int i = 0; i < n_u; ++i) {
-        const uint32_t h = (uint32_t)hash64((hash64(a[k].x) + hash64(a[k].y)) ^ hash);
-        z[i].x = u[i] ^ h;
-        z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
-        k += (int32_t)u[i];
+        const uint32_t h = (uint32_t)hash64((hash64(c[i].rec->fx) + hash64(c[i].rec->fy)) ^ hash);
+        z[i].x = c[i].u ^ h;
+        z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)c[i].u;
+        z[i].i = i;
+        k += (int32_t)c[i].u;
     }
     std::sort(z.begin(), z.end(), [](const Z &p, const Z &q) { return p.x != q.x ? p.x < q.x : p.y < q.y; });
     regs.assign(n_u, Reg());
     for (int i = 0; i < n_u; ++i) {
         Reg &ri = regs[i];
         const Z &zi = z[n_u - 1 - i];
+        const ChainRec &rc = *c[zi.i].rec;
         ri.id = i;
         ri.parent = PARENT_UNSET;
         ri.score = ri.score0 = (int32_t)(zi.x >> 32);
         ri.hash = (uint32_t)zi.x;
         ri.cnt = (int32_t)zi.y;
         ri.as = (int32_t)(zi.y >> 32);
-        reg_set_coor(ri, qlen, a);
+        ri.fx = rc.fx; ri.fy = rc.fy; ri.lx = rc.lx; ri.ly = rc.ly; ri.src = c[zi.i].src;
+        ri.mlen = rc.mlen; ri.blen = rc.blen;
+        reg_set_coor(ri, qlen);
     }
 }
 
@@ -237,24 +239,30 @@ static void filter_regs(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs
     regs.resize(k);
 }
 
-static int squeeze_a(std::vector<Reg> &regs, u128 *a) {
+// mm_squeeze_a: the hits that survived selection get consecutive places in the read's anchor list, in the order of their first
+// anchors.  The anchors themselves are moved on the device (anchor_squeeze_kernel) along the segments written here: every hit
+// is still ONE chain at this point.  Returns the anchors the list holds.
+static int squeeze_a(std::vector<Reg> &regs, int read, int64_t pool_base, std::vector<SqueezeSeg> &segs) {
     const int n_regs = (int)regs.size();
     std::vector<std::pair<uint64_t, int>> aux(n_regs);
     for (int i = 0; i < n_regs; ++i) aux[i] = {(uint64_t)regs[i].as, i};
     std::sort(aux.begin(), aux.end());
+    segs.clear();
     int as = 0;
     for (int i = 0; i < n_regs; ++i) {
         Reg &r = regs[aux[i].second];
-        if (r.as != as) { memmove(&a[as], &a[r.as], (size_t)r.cnt * 16); r.as = as; }
+        r.as = as;
+        r.seg = (int32_t)segs.size();
+        segs.push_back(SqueezeSeg{pool_base + r.src, as, r.cnt, read, 0});
         as += r.cnt;
     }
     return as;
 }
 
-static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, u128 *a) {
+// (called on a squeezed list: squeeze_a above has run)
+static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, std::vector<SqueezeSeg> &segs) {
     const int n_regs = (int)regs.size();
     if (n_regs < 2) return;
-    squeeze_a(regs, a);
     std::vector<std::pair<uint64_t, int>> aux;
     for (int i = 0; i < n_regs; ++i)
         if (regs[i].parent == i || regs[i].parent < 0) aux.push_back({(uint64_t)regs[i].as, i});
@@ -264,7 +272,8 @@ static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, 
         Reg &r0 = regs[aux[i - 1].second], &r1 = regs[aux[i].second];
         if (r0.as + r0.cnt != r1.as) continue;
         if (r0.rid != r1.rid || r0.rev != r1.rev) continue;
-        const u128 *a0e = &a[r0.as + r0.cnt - 1], *a1s = &a[r1.as];
+        const u128 a0e_{r0.lx, r0.ly}, a1s_{r1.fx, r1.fy};
+        const u128 *a0e = &a0e_, *a1s = &a1s_;
         if (a1s->x <= a0e->x || (int32_t)a1s->y <= (int32_t)a0e->y) continue;
         int max_gap, min_gap;
         max_gap = min_gap = (int32_t)a1s->y - (int32_t)a0e->y;
@@ -276,9 +285,16 @@ static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, 
         const int min_flank_len = (int)(max_gap * opt->min_join_flank_ratio);
         if (r0.re - r0.rs < min_flank_len || r0.qe - r0.qs < min_flank_len) continue;
         if (r1.re - r1.rs < min_flank_len || r1.qe - r1.qs < min_flank_len) continue;
-        a[r1.as].y |= SEED_LONG_JOIN;
+        segs[(size_t)r1.seg].flag = 1;   // (a[r1.as].y |= SEED_LONG_JOIN, applied by the squeeze kernel)
         r0.cnt += r1.cnt; r0.score += r1.score;
-        reg_set_coor(r0, qlen, a);
+        {   // mm_cal_fuzzy_len over the joined anchors: both parts' sums and the step across the joint
+            const int span = (int)(a1s->y >> 32 & 0xff);
+            const int tl = (int32_t)a1s->x - (int32_t)a0e->x, ql = (int32_t)a1s->y - (int32_t)a0e->y;
+            r0.blen += r1.blen - span + (tl > ql ? tl : ql);
+            r0.mlen += r1.mlen - span + (tl > span && ql > span ? span : tl < ql ? tl : ql);
+        }
+        r0.lx = r1.lx; r0.ly = r1.ly;
+        reg_set_coor(r0, qlen);
         r1.cnt = 0;
         r1.parent = r0.id;
         ++n_drop;
@@ -340,8 +356,8 @@ static void set_mapq(std::vector<Reg> &regs, int min_chain_sc, int match_sc, int
     }
 }
 
-static void split_reg(Reg &r, Reg &r2, int n, int qlen, const u128 *a) {
-    if (n <= 0 || n >= r.cnt) return;
+static void split_reg(Reg &r, Reg &r2, int n, int qlen, const SplitRec *sp) {
+    if (n <= 0 || n >= r.cnt || !sp) return;
     r2 = r;
     r2.id = -1;
     r2.sam_pri = 0;
@@ -352,10 +368,14 @@ static void split_reg(Reg &r, Reg &r2, int n, int qlen, const u128 *a) {
     r2.score = (int32_t)(r.score * ((float)r2.cnt / r.cnt) + .499);
     r2.as = r.as + n;
     if (r.parent == r.id) r2.parent = PARENT_TMP_PRI;
-    reg_set_coor(r2, qlen, a);
+    r2.fx = sp->fx; r2.fy = sp->fy;   // (its last anchor is the hit's)
+    r2.mlen = sp->mlen_r; r2.blen = sp->blen_r;
+    reg_set_coor(r2, qlen);
     r.cnt -= r2.cnt;
     r.score -= r2.score;
-    reg_set_coor(r, qlen, a);
+    r.lx = sp->lx_left; r.ly = sp->ly_left;
+    r.mlen = sp->mlen_l; r.blen = sp->blen_l;
+    reg_set_coor(r, qlen);
     r.split |= 1; r2.split |= 2;
 }
 
@@ -370,14 +390,14 @@ struct CpuSect {
 // What the stitching kernel found for one hit (stitch_kernels.h) applied to the hit: coordinates, DP score, and -- when a
 // gap fill z-dropped -- the split of the hit at the last anchor before the drop (mm_align1's `dropped` branch; the kernel
 // has located the anchor).  returns true if a split remainder was produced in r2
-static bool apply_stitch(int qlen, Reg &r, Reg &r2, const u128 *a, const StitchOut &so, int fin_idx) {
+static bool apply_stitch(int qlen, Reg &r, Reg &r2, const SplitRec *splits, const StitchOut &so, int fin_idx) {
     bool has_r2 = false;
     r2.cnt = 0;
     if (so.has_p) r.has_p = 1;
     r.dp_score += so.dp_score;
     if (so.split_n > 0) {
         const int old_cnt = r.cnt;
-        split_reg(r, r2, so.split_n, qlen, a);
+        split_reg(r, r2, so.split_n, qlen, so.split_rec >= 0 ? splits + so.split_rec : nullptr);
         has_r2 = r2.cnt > 0 && r.cnt != old_cnt;
         if (so.split_inv) r2.split_inv = 1;
     }
@@ -481,8 +501,7 @@ static void parallel_for(int n, int n_threads, const std::function<void(int, int
 
 struct ReadState {
     std::vector<Reg> regs;
-    u128 *a = nullptr;     // chained anchors (squeezed): a slice of the worker's pinned slab, valid while its sub-batch is mapped
-    int n_a = 0;
+    int n_a = 0;           // anchors of the read's squeezed list (which lives in HBM)
     std::vector<int> pending; // reg indices aligned this round
 };
 
@@ -639,8 +658,8 @@ struct Slot {
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
-    PoolBuf pool_probes, pool_sizes, pool_buckets, pool_pregs, pool_psum, pool_job_anchor;
-    PoolBuf pin_anchors{nullptr, 0, true}, pin_pregs{nullptr, 0, true};
+    PoolBuf pool_probes, pool_sizes, pool_buckets, pool_pregs, pool_psum, pool_job_anchor, pool_splits;
+    PoolBuf pin_segs{nullptr, 0, true}, pin_pregs{nullptr, 0, true};
     PoolBuf pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
     PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
@@ -1095,8 +1114,8 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     const int n_sr = sr_base[(size_t)n];
     if (n_sr == 0) return 0;
     Slot &SL = *tl_slot;
-    if (SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut)) + 64) ||
-        SL.pool_souts.ensure((size_t)n_sr * sizeof(StitchOut) + 16) ||
+    if (SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut) + sizeof(SplitRec)) + 64) ||
+        SL.pool_souts.ensure((size_t)n_sr * sizeof(StitchOut) + 16) || SL.pool_splits.ensure((size_t)n_sr * sizeof(SplitRec) + 16) ||
         SL.pool_fin_jobs.ensure((size_t)n_sr * sizeof(FinJob) + 16) || SL.pool_fin_out.ensure((size_t)n_sr * sizeof(FinOut) + 16) ||
         SL.pool_fin_cig.ensure((size_t)dv.cig_cap * 4 + 16))
         return -1;
@@ -1107,19 +1126,28 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     unsigned long long *d_out_used = dv.used + 2;
     StitchOut *h_so = SL.pin_fin_out.as<StitchOut>();
     FinOut *h_fo = reinterpret_cast<FinOut *>(h_so + n_sr);
-    unsigned long long *h_out_used = reinterpret_cast<unsigned long long *>(h_fo + n_sr);
+    unsigned long long *h_out_used = reinterpret_cast<unsigned long long *>(h_fo + n_sr);   // [stitched ops, cut hits]
+    SplitRec *h_splits = reinterpret_cast<SplitRec *>(h_out_used + 2);
+    SplitRec *d_splits = SL.pool_splits.as<SplitRec>();
+    unsigned long long *d_n_splits = dv.used + 6;
     EvTimer ev(st);
     MPN_HIP_CHECK(hipMemsetAsync(d_out_used, 0, 8, st));
+    MPN_HIP_CHECK(hipMemsetAsync(d_n_splits, 0, 8, st));
     ev.skip();
     hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)std::min(n_sr, 256 * 32)), dim3(64), 0, st, rd.sregs, n_sr, (const ExtJob *)dv.jobs,
                        (const ExtRes *)dv.res, (const uint32_t *)dv.compact, d_cig, d_out_used, d_so, d_fj, rd.pregs, rd.psum, rd.job_anchor, rd.anchors,
-                       opt->min_cnt);
+                       opt->min_cnt, d_splits, d_n_splits);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(54);
     MPN_HIP_CHECK(hipMemcpyAsync(h_so, d_so, (size_t)n_sr * sizeof(StitchOut), hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(hipMemcpyAsync(h_out_used, d_out_used, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_out_used + 1, d_n_splits, 8, hipMemcpyDeviceToHost, st));
     MPN_HIP_CHECK(stream_sync(st));
     const int64_t n_ops = (int64_t)*h_out_used;
+    if (h_out_used[1]) {   // (the cut hits' records: rare)
+        MPN_HIP_CHECK(hipMemcpyAsync(h_splits, d_splits, (size_t)h_out_used[1] * sizeof(SplitRec), hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(stream_sync(st));
+    }
     // hits: coordinates, score, splits at z-drops
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
@@ -1128,7 +1156,7 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
         for (size_t pi = 0; pi < S.pending.size(); ++pi) {
             const int k = S.pending[pi] + shift, fi = sr_base[(size_t)i] + (int)pi;
             Reg r2;
-            const bool has = apply_stitch(seq_len[i], S.regs[(size_t)k], r2, S.a, h_so[fi], fi);
+            const bool has = apply_stitch(seq_len[i], S.regs[(size_t)k], r2, h_splits, h_so[fi], fi);
             if (has) { S.regs.insert(S.regs.begin() + k + 1, r2); ++shift; }
         }
     }, 4);
@@ -1222,6 +1250,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     ReadState *rs = rs_all.data() + lo;
     WallTimer wt;
     HostChains h;
+    SeedChainOut o;   // (the chained anchors stay in its device pool until the squeeze below)
     {
         // The seed + sort + chain stage is bound by HBM traffic and latency, the extension stage by VALU issue: workers in
         // different stages share the GPU well, workers in the same memory-bound stage only queue on HBM.  At most
@@ -1234,47 +1263,64 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         };
         static StageGate gate;
         struct Hold { StageGate &g; Hold(StageGate &x) : g(x) { g.enter(); } ~Hold() { g.leave(); } } hold(gate);
-        SeedChainOut o;
         if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
         wt.stop_into(g_stats[17]);
-        if (download_chains(n, o, h, tl_slot->pin_chain_u, tl_slot->pin_chain_b, st)) return -1;
+        if (download_chains(n, o, h, tl_slot->pin_chain_u, tl_slot->pin_chain_b, st, false)) return -1;
         wt.stop_into(g_stats[18]);
     }
     g_stats[3] += h.chain_off[n];
     for (int i = 0; i < n; ++i) rep_len_all[lo + i] = h.rep_len[i];
-    // hits from chains; the chained anchors of the sub-batch live in ONE pinned slab (read i at b_off[i]): the planning kernel
-    // needs them on the device, and they go up from where the host squeezed them, without another copy
+    // Hits from chains.  The host works on the chain records (first / last anchor, approximate lengths: 40 bytes per chain);
+    // the chained anchors never leave HBM.  What the host decides about them -- which chains survive hit selection, their
+    // places in the read's squeezed anchor list, the long-join marks -- goes back as 24-byte segments for the squeeze kernel.
     Slot &SL = *tl_slot;
-    if (SL.pin_anchors.ensure((size_t)h.b_off[(size_t)n] * sizeof(u128) + 64)) return -1;
-    u128 *slab = SL.pin_anchors.as<u128>();
+    if (SL.pin_segs.ensure((size_t)h.chain_off[(size_t)n] * sizeof(SqueezeSeg) + (size_t)(n + 1) * 8 + 64)) return -1;
+    int64_t *sq_off = SL.pin_segs.as<int64_t>();                                     // [n + 1] start of every read's squeezed list
+    SqueezeSeg *h_segs = reinterpret_cast<SqueezeSeg *>(sq_off + n + 1);
+    struct alignas(64) Cursor { std::atomic<int64_t> v{0}; } seg_cursor;
     parallel_for(n, n_threads, [&](int i, int) {
         ReadState &S = rs[i];
         const int nc = h.n_chain[i];
         if (nc == 0) return;
         const int qlen = seq_len[i];
         CpuSect sect(g_cpu_on);
-        std::vector<uint64_t> u_loc(nc);
-        S.a = slab + h.b_off[(size_t)i];
-        h.read_chains(i, u_loc.data(), S.a);
+        std::vector<int32_t> order(nc);
+        std::vector<int64_t> src(nc);
+        std::vector<ChainIn> cin(nc);
+        h.chain_order(i, order.data(), src.data());
+        for (int c = 0; c < nc; ++c) cin[c] = ChainIn{h.u_all[h.u_pos[i] + order[c]], h.rec_all + h.u_pos[i] + order[c], src[c]};
         sect.lap(3);
         uint32_t hash = names && names[lo + i] ? x31_hash(names[lo + i]) : 0;
         hash ^= wang32((uint32_t)qlen) + wang32(opt->seed);
         hash = wang32(hash);
-        gen_regs(hash, qlen, nc, u_loc.data(), S.a, S.regs);
+        gen_regs(hash, qlen, nc, cin.data(), S.regs);
         set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
         select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
-        join_long(opt, qlen, S.regs, S.a);
+        std::vector<SqueezeSeg> segs;
+        S.n_a = squeeze_a(S.regs, i, h.b_pos[i], segs);
+        join_long(opt, qlen, S.regs, segs);
         sect.lap(4);
-        if (opt->with_cigar) {
-            S.n_a = squeeze_a(S.regs, S.a);
+        if (opt->with_cigar && !segs.empty()) {
+            const int64_t at = seg_cursor.v.fetch_add((int64_t)segs.size(), std::memory_order_relaxed);
+            memcpy(h_segs + at, segs.data(), segs.size() * sizeof(SqueezeSeg));
             sect.lap(5);
         }
     }, 1);
     wt.stop_into(g_stats[19]);
-    if (opt->with_cigar && h.b_off[(size_t)n] > 0) {
+    sq_off[0] = 0;
+    for (int i = 0; i < n; ++i) sq_off[i + 1] = sq_off[i] + rs[i].n_a;
+    const int64_t n_sq = sq_off[n], n_segs = seg_cursor.v.load();
+    if (opt->with_cigar && n_sq > 0) {
         DevBuf<u128> d_a;
-        if (d_a.alloc((size_t)h.b_off[(size_t)n])) return -1;
-        MPN_HIP_CHECK(hipMemcpyAsync(d_a.p, slab, (size_t)h.b_off[(size_t)n] * sizeof(u128), hipMemcpyHostToDevice, st));
+        DevBuf<unsigned char> d_segs;
+        const size_t seg_bytes = (size_t)(n + 1) * 8 + (size_t)n_segs * sizeof(SqueezeSeg);
+        if (d_a.alloc((size_t)n_sq) || d_segs.alloc(seg_bytes)) return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(d_segs.p, sq_off, seg_bytes, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(anchor_squeeze_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_segs + 3) / 4, 256 * 16))), dim3(256), 0, st,
+                           reinterpret_cast<const SqueezeSeg *>(d_segs.p + (size_t)(n + 1) * 8), (int)n_segs, (const u128 *)o.chained.p,
+                           reinterpret_cast<const int64_t *>(d_segs.p), d_a.p);
+        MPN_HIP_CHECK(hipGetLastError());
+        g_stats[59] += n_sq;
         PlanOpt po;
         po.bw = opt->bw; po.bw15 = (int)(opt->bw * 1.5 + 1.); po.min_chain_score = opt->min_chain_score; po.max_gap = opt->max_gap;
         po.min_cnt = opt->min_cnt; po.a = opt->a; po.q = opt->q; po.e = opt->e; po.zdrop = opt->zdrop; po.zdrop_inv = opt->zdrop_inv;
@@ -1308,7 +1354,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
                 const ReadState &S = rs[i];
                 for (size_t pi = 0; pi < S.pending.size(); ++pi) {
                     const Reg &r = S.regs[(size_t)S.pending[pi]];
-                    h_pr[(size_t)sr_base[(size_t)i] + pi] = PlanReg{h.b_off[(size_t)i], S.n_a, r.as, r.cnt, r.mlen, i, seq_len[i], (int32_t)r.split_inv, 0};
+                    h_pr[(size_t)sr_base[(size_t)i] + pi] = PlanReg{sq_off[i], S.n_a, r.as, r.cnt, r.mlen, i, seq_len[i], (int32_t)r.split_inv, 0};
                     cap_t[(size_t)slot % cap_t.size()] += r.cnt + 2;   // a hit of cnt anchors has at most cnt + 1 windows
                 }
             }, 3);
@@ -1447,7 +1493,6 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             set_mapq(S.regs, opt->min_chain_score, opt->a, h.rep_len[i]);
         }
         n_aln += (int64_t)S.regs.size();
-        S.a = nullptr;   // (the slab belongs to the worker's next sub-batch from here on)
     }, 5);
     g_stats[6] += n_aln;
     wt.stop_into(g_stats[23]);
@@ -1623,7 +1668,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
                     S.arena.chunks.clear(); S.arena.cur = S.arena.off = S.arena.used = 0;
                     for (PoolBuf *pb : {&S.pool_jobs, &S.pool_P, &S.pool_P2, &S.pool_OFF, &S.pool_order, &S.pool_state, &S.pool_CIG, &S.pool_res, &S.pool_redo,
                                         &S.pool_compact, &S.pool_redo_ids, &S.pool_sregs, &S.pool_souts, &S.pool_fin_jobs, &S.pool_fin_out, &S.pool_fin_cig,
-                                        &S.pool_sizes, &S.pool_pregs, &S.pool_psum, &S.pool_job_anchor, &S.pin_anchors})
+                                        &S.pool_sizes, &S.pool_pregs, &S.pool_psum, &S.pool_job_anchor, &S.pool_splits, &S.pin_segs})
                         pb->release();
                     retry.push_back(sb);
                     if (dbg_workers) fprintf(stderr, "[worker %d] out of device memory at sub-batch %d: leaving, %d workers go on\n", wid, sb, live_workers);
@@ -1651,7 +1696,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
             for (const auto &c : S.arena.chunks) arena += c.cap;
             const size_t pools = S.pool_jobs.cap + S.pool_P.cap + S.pool_P2.cap + S.pool_OFF.cap + S.pool_order.cap + S.pool_state.cap + S.pool_CIG.cap +
                                  S.pool_res.cap + S.pool_redo.cap + S.pool_compact.cap + S.pool_used.cap;
-            const size_t pinned = S.pin_order.cap + S.pin_res.cap + S.pin_chain_u.cap + S.pin_chain_b.cap + S.pin_anchors.cap + S.pin_pregs.cap + S.pin_fin_cig.cap + S.pin_fin_out.cap;
+            const size_t pinned = S.pin_order.cap + S.pin_res.cap + S.pin_chain_u.cap + S.pin_chain_b.cap + S.pin_segs.cap + S.pin_pregs.cap + S.pin_fin_cig.cap + S.pin_fin_out.cap;
             fprintf(stderr, "[slot %d] arena %.2f GB, pools %.2f GB (P %.2f, CIG %.2f, compact %.2f), pinned host %.2f GB\n", wdx, arena / 1e9,
                     pools / 1e9, S.pool_P.cap / 1e9, S.pool_CIG.cap / 1e9, S.pool_compact.cap / 1e9, pinned / 1e9);
         }

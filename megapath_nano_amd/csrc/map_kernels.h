@@ -1612,7 +1612,8 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                                                              const int32_t *__restrict__ n_ends, u128 *__restrict__ B,
                                                              uint64_t *__restrict__ Uc, unsigned long long *__restrict__ used,
                                                              int64_t *__restrict__ u_pos, int64_t *__restrict__ b_pos,
-                                                             int32_t *__restrict__ n_chain, int64_t *__restrict__ n_chained) {
+                                                             int32_t *__restrict__ n_chain, int64_t *__restrict__ n_chained,
+                                                             ChainRec *__restrict__ Rc) {
     __shared__ int s_k;
     __shared__ unsigned long long s_up, s_bp;
     const int lane = threadIdx.x;
@@ -1655,10 +1656,30 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
         const int k = s_k;
         u128 *b = B + s_bp;
         uint64_t *uc = Uc + s_up;
+        ChainRec *rc = Rc + s_up;
         int off = 0;
         for (int c = 0; c < k; ++c) {
             const int ni = (int32_t)u[c];
-            for (int j = lane; j < ni; j += 64) b[off + j] = a[v[off + (ni - j - 1)]];
+            // the copy also measures the chain (mm_cal_fuzzy_len): the host makes its hits from these records and never sees an anchor
+            int ml = 0, bl = 0;
+            for (int j = lane; j < ni; j += 64) {
+                const u128 cur = a[v[off + (ni - j - 1)]];
+                b[off + j] = cur;
+                const int span = (int)(cur.y >> 32 & 0xff);
+                if (j == 0) { ml += span; bl += span; }
+                else {
+                    const u128 prev = a[v[off + (ni - j)]];
+                    const int tl = (int32_t)cur.x - (int32_t)prev.x, ql = (int32_t)cur.y - (int32_t)prev.y;
+                    bl += tl > ql ? tl : ql;
+                    ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
+                }
+            }
+            ml = __builtin_amdgcn_readlane(wave_scan_add(ml), 63);
+            bl = __builtin_amdgcn_readlane(wave_scan_add(bl), 63);
+            if (lane == 0) {
+                const u128 first = a[v[off + ni - 1]], last = a[v[off]];
+                rc[c] = ChainRec{first.x, first.y, last.x, last.y, ml, bl};
+            }
             off += ni;
         }
         for (int c = lane; c < k; c += 64) uc[c] = u[c];

@@ -6,6 +6,19 @@ namespace mpn {
 
 struct u128 { uint64_t x, y; };
 
+// What the host needs of a chain to make a hit of it (minimap2's mm_reg1_t before the base-level extension): its first and
+// last anchor and the approximate match / block lengths (mm_reg_set_coor + mm_cal_fuzzy_len).  The chained anchors themselves
+// stay in HBM; chain_backtrack_kernel writes one record per surviving chain beside the (score, count) word.
+struct ChainRec { uint64_t fx, fy, lx, ly; int32_t mlen, blen; };
+
+// One surviving chain of a read on its way into the read's squeezed anchor list (minimap2's mm_squeeze_a after hit selection):
+// cnt anchors from src (index into the chain stage's pool) to sq_off[read] + dst; flag: the first anchor gets SEED_LONG_JOIN.
+struct SqueezeSeg { int64_t src; int32_t dst, cnt, read, flag; };
+
+// The split of a z-dropped hit (mm_split_reg) as the host needs it: fuzzy lengths of both halves and the first anchor of the
+// remainder.  Written by stitch_kernel for the hits it cuts.
+struct SplitRec { uint64_t fx, fy, lx_left, ly_left; int32_t mlen_l, blen_l, mlen_r, blen_r; };
+
 __device__ __forceinline__ int nt4_code(uint8_t c) {
     c |= 0x20;
     return c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : (c == 't' || c == 'u') ? 3 : 4;

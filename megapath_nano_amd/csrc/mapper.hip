@@ -375,7 +375,10 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     g_stats[45] += n_c;
     DevBuf<int32_t> F, P, T, V;
     DevBuf<uint64_t> Utmp;
-    if (F.alloc(n_c) || P.alloc(n_c) || T.alloc(n_c) || V.alloc(n_c) || o.u.alloc(n_c) || Utmp.alloc(n_c) || o.chained.alloc(n_c)) return -1;
+    // (a surviving chain holds at least min_cnt anchors)
+    if (F.alloc(n_c) || P.alloc(n_c) || T.alloc(n_c) || V.alloc(n_c) || o.u.alloc(n_c) || Utmp.alloc(n_c) || o.chained.alloc(n_c) ||
+        o.recs.alloc((size_t)(n_c / std::max(1, opt->min_cnt)) + 1))
+        return -1;
     u128 *ca = tmp.p;  // the sort's bounce buffer is free now: it receives the compact anchors
     if (n_a > 0) {
         hipLaunchKernelGGL(anchor_compact_kernel<true>, dim3(gp), dim3(64), 0, st, (const u128 *)o.anchors.p, (const int64_t *)o.anchor_off.p, n, n_a,
@@ -405,7 +408,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     // chained anchors and surviving chains go to compact pools
     o.u_compact.p = Utmp.p; o.u_compact.n = Utmp.n; o.u_compact.owned = Utmp.owned; Utmp.p = nullptr; Utmp.n = 0;
     hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, n, cp, F.p, P.p, T.p, V.p,
-                       o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p);
+                       o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p, o.recs.p);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(14);
     MPN_HIP_CHECK(stream_sync(st));
@@ -413,8 +416,9 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     return 0;
 }
 
-// download the compact chain pools of a batch (pinned staging owned by the caller) and the per-read tables
-int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st) {
+// download the per-read tables and the compact chain pools of a batch (pinned staging owned by the caller): the (score, count)
+// words and the chain records; the chained anchors only for the stage test (with_anchors) -- the mapper leaves them in HBM
+int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, bool with_anchors) {
     h.n_anchor.resize((size_t)n);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
     unsigned long long used[2 + WORK_SLOTS] = {0};
@@ -432,9 +436,19 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolB
     }
     for (int k = 0; k < WORK_SLOTS; ++k) g_stats[44] += (int64_t)used[2 + k];
     ++g_stats[32];
-    if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;
-    if (o.u_compact.download(pin_u.as<uint64_t>(), (size_t)used[0], st) || o.chained.download(pin_b.as<u128>(), (size_t)used[1], st)) return -1;
-    h.u_all = pin_u.as<uint64_t>(); h.b_all = pin_b.as<u128>();
+    if (with_anchors) {
+        if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;
+        if (o.u_compact.download(pin_u.as<uint64_t>(), (size_t)used[0], st) || o.chained.download(pin_b.as<u128>(), (size_t)used[1], st)) return -1;
+        h.u_all = pin_u.as<uint64_t>(); h.b_all = pin_b.as<u128>();
+    } else {
+        // [records | (score, count) words] in one staging block
+        const size_t rec_bytes = ((size_t)used[0] * sizeof(ChainRec) + 15) & ~(size_t)15;
+        if (pin_u.ensure(rec_bytes + (size_t)used[0] * 8 + 16)) return -1;
+        h.rec_all = pin_u.as<ChainRec>();
+        h.u_all = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(pin_u.p) + rec_bytes);
+        h.b_all = nullptr;
+        if (o.recs.download(const_cast<ChainRec *>(h.rec_all), (size_t)used[0], st) || o.u_compact.download(const_cast<uint64_t *>(h.u_all), (size_t)used[0], st)) return -1;
+    }
     h.chain_off.assign((size_t)n + 1, 0);
     h.b_off.assign((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) { h.chain_off[i + 1] = h.chain_off[i] + h.n_chain[i]; h.b_off[i + 1] = h.b_off[i] + h.n_chained[i]; }
@@ -460,6 +474,19 @@ void HostChains::read_chains(int i, uint64_t *uo, u128 *bo) const {
         memcpy(bo + kk, b + start, (size_t)cnt * sizeof(u128));
         kk += cnt;
     }
+}
+
+void HostChains::chain_order(int i, int32_t *order, int64_t *src) const {
+    const int nc = n_chain[i];
+    if (nc == 0) return;
+    const uint64_t *u = u_all + u_pos[i];
+    const ChainRec *r = rec_all + u_pos[i];
+    // (the same key as read_chains: first anchor, then the chain's position in the pool)
+    std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w(nc);
+    int64_t k = 0;
+    for (int c = 0; c < nc; ++c) { w[c] = {{r[c].fx, (uint64_t)k << 32 | (uint32_t)c}, c}; k += (int32_t)u[c]; }
+    std::sort(w.begin(), w.end());
+    for (int c = 0; c < nc; ++c) { order[c] = w[c].second; src[c] = (int64_t)(w[c].first.second >> 32); }
 }
 
 }  // namespace mpn
@@ -911,7 +938,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     HostChains h;
     PoolBuf pin_u{nullptr, 0, true}, pin_b{nullptr, 0, true};
     struct Free { PoolBuf &a, &b; ~Free() { a.release(); b.release(); } } free_pins{pin_u, pin_b};
-    if (download_chains(n, o, h, pin_u, pin_b, st)) return -1;
+    if (download_chains(n, o, h, pin_u, pin_b, st, true)) return -1;
     for (int i = 0; i < n; ++i) { n_anchor[i] = h.n_anchor[i]; rep_len[i] = h.rep_len[i]; }
     memcpy(chain_off, h.chain_off.data(), ((size_t)n + 1) * 8);
     memcpy(anchor_off, h.b_off.data(), ((size_t)n + 1) * 8);

@@ -1,6 +1,7 @@
 // Internal types shared by mapper.hip (seed + chain stages) and align.hip (base-level extension, hit bookkeeping).
 #pragma once
 #include "mpn_common.h"
+#include "map_types.h"
 
 #include <atomic>
 #include <chrono>
@@ -13,9 +14,6 @@
 
 struct mpn_map_opt_s;
 
-namespace mpn {
-struct u128;
-}
 
 struct mpn_index {
     int k = 15, w = 10;
@@ -42,8 +40,6 @@ struct mpn_index {
 
 namespace mpn {
 
-struct u128;
-
 struct SeedChainOut {
     int64_t n_anchors = 0;
     // the per-read tables the host reads back (n_anchor, n_chained, u_pos, b_pos, n_chain, rep_len, used) are slices of ONE
@@ -55,6 +51,7 @@ struct SeedChainOut {
     DevBuf<int32_t> rep_len, n_ends, n_chain;
     DevBuf<u128> anchors, chained;
     DevBuf<uint64_t> u, u_compact;
+    DevBuf<ChainRec> recs;                                       // one record per surviving chain, parallel to u_compact
     DevBuf<unsigned long long> used;
 };
 
@@ -63,10 +60,14 @@ struct HostChains {
     std::vector<int64_t> n_chained, u_pos, b_pos;       // per read: chained anchors; start in the compact pools
     std::vector<int32_t> n_chain, rep_len;
     const uint64_t *u_all = nullptr;                    // compact pools as downloaded (caller-owned pinned memory)
-    const u128 *b_all = nullptr;
+    const u128 *b_all = nullptr;                        // (only when the anchors were asked for: the stage test)
+    const ChainRec *rec_all = nullptr;
     // chains of read i in ascending order of their first anchor (minimap2 re-sorts them like this so that neighbouring
     // chains can be joined): u_out[n_chain[i]], b_out[n_chained[i]]
     void read_chains(int i, uint64_t *u_out, u128 *b_out) const;
+    // the same order without the anchors: chain c of the sorted order is chain order[c] of the pool (u_all / rec_all at
+    // u_pos[i] + order[c]) and its anchors start at src[c] relative to b_pos[i] in the chain stage's device pool
+    void chain_order(int i, int32_t *order, int64_t *src) const;
 };
 
 constexpr int MPN_NSTATS = 64;

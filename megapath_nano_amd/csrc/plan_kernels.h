@@ -86,6 +86,24 @@ __device__ inline void pk_filter_bad_seeds(int as1, int cnt1, AnchorView &a, int
     (void)max_st_k;
 }
 
+// minimap2's mm_squeeze_a on the device: the chains that survived hit selection are gathered, in the order of their first
+// anchors, into the read's squeezed anchor list (the planning walks look at a hit's neighbours in THAT list).  A wave per
+// segment and pass; the first anchor of a chain that join_long attached to its predecessor carries SEED_LONG_JOIN.
+__global__ __launch_bounds__(256) void anchor_squeeze_kernel(const SqueezeSeg *__restrict__ segs, int n_segs, const u128 *__restrict__ src,
+                                                             const int64_t *__restrict__ sq_off, u128 *__restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int s = wave; s < n_segs; s += n_waves) {
+        const SqueezeSeg sg = segs[s];
+        const u128 *from = src + sg.src;
+        u128 *to = dst + sq_off[sg.read] + sg.dst;
+        for (int j = lane; j < sg.cnt; j += 64) {
+            u128 v = from[j];
+            if (j == 0 && sg.flag) v.y |= PK_SEED_LONG_JOIN;
+            to[j] = v;
+        }
+    }
+}
+
 // The planning half of mm_align1 for one hit.  FILL = false counts the windows; FILL = true writes them (jobs, job_anchor) and
 // the hit's stitching record.  The counting pass sets the SEED_IGNORE flags (the filter is the most expensive walk), the other reads them.
 template <bool FILL>

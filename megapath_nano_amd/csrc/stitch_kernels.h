@@ -23,7 +23,7 @@ struct StitchOut {
     int32_t n_ops, dp_score, rs1, re1, qs1, qe1;
     int32_t has_p, dropped, drop_fill, drop_max_t, drop_max_q;   // drop_fill: index of the z-dropped gap fill among the hit's fills
     int32_t split_n;                  // > 0: a z-drop cuts the hit after its first split_n anchors (mm_align1's mm_split_reg call)
-    int32_t split_inv, pad;           // the cut is at an inversion: the remainder is marked (mm_align1: r2->split_inv = 1)
+    int32_t split_inv, split_rec;     // the cut is at an inversion: the remainder is marked (mm_align1: r2->split_inv = 1); index of the hit's SplitRec
 };
 
 
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                                                     uint32_t *__restrict__ OUT, unsigned long long *__restrict__ out_used,
                                                     StitchOut *__restrict__ outs, FinJob *__restrict__ fin_jobs,
                                                     const PlanReg *__restrict__ pregs, const PlanSum *__restrict__ psum,
-                                                    const int32_t *__restrict__ job_anchor, const u128 *__restrict__ A, int min_cnt) {
+                                                    const int32_t *__restrict__ job_anchor, const u128 *__restrict__ A, int min_cnt,
+                                                    SplitRec *__restrict__ splits, unsigned long long *__restrict__ n_splits) {
     const int lane = threadIdx.x;
     for (int ri = blockIdx.x; ri < n_regs; ri += gridDim.x) {
         const StitchReg sr = regs[ri];
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
             }
         }
         // ---- coordinates ----
+        int split_n = 0, split_slot = -1;
         if (lane == 0) {
             int rs1 = sr.rs, qs1 = sr.qs, re1 = sr.re, qe1 = sr.qe;
             if (has_left) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                 qs1 = sr.qs - (reach ? sr.qs - sr.qs0 : max_q + 1);
             }
             StitchOut o;
-            o.drop_fill = -1; o.drop_max_t = o.drop_max_q = -1; o.split_n = 0; o.split_inv = 0; o.pad = 0;
+            o.drop_fill = -1; o.drop_max_t = o.drop_max_q = -1; o.split_n = 0; o.split_inv = 0; o.split_rec = -1;
             if (dropped) {
                 const ExtJob &jb = jb0[k_stop];
                 int max_t = -1, max_q = -1;
@@ -154,6 +156,8 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
                 for (j = job_anchor[sr.first_job + k_stop] - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= jb.ts + max_t) break;
                 if (j < 0) j = 0;
                 if (cnt1 - (j + 1) >= min_cnt) { o.split_n = as1 + j + 1 - pregs[ri].as; o.split_inv = (jb.flag & EZ_INV) ? 1 : 0; }
+                // (mm_split_reg does nothing for a cut outside the hit)
+                if (o.split_n > 0 && o.split_n < pregs[ri].cnt) { split_n = o.split_n; split_slot = (int)atomicAdd(n_splits, 1ULL); o.split_rec = split_slot; }
             } else if (n > 0 && (jb0[n - 1].flag & EZ_EXTZ_ONLY) && !jb0[n - 1].reversed) {
                 int reach = 0, max_t = -1, max_q = -1, mqe_t = -1;
                 if (!(jb0[n - 1].flag & EZ_REFUSED)) { const ExtRes &e = rs0[n - 1]; reach = e.reach_end; max_t = e.max_t; max_q = e.max_q; mqe_t = e.mqe_t; }
@@ -167,6 +171,31 @@ __global__ __launch_bounds__(64) void stitch_kernel(const StitchReg *__restrict_
             f.cig_off = (int64_t)base; f.code_off = 0; f.n_cigar = total; f.read = sr.read; f.rid = sr.rid; f.rev = sr.rev;
             f.qs1 = qs1; f.rs1 = rs1; f.qspan = qe1 > qs1 ? qe1 - qs1 : 0; f.tspan = re1 > rs1 ? re1 - rs1 : 0;
             fin_jobs[ri] = f;
+        }
+        // ---- the two halves of a cut hit, measured for the host (mm_split_reg's mm_reg_set_coor calls): the anchors stay here ----
+        split_n = __shfl(split_n, 0); split_slot = __shfl(split_slot, 0);
+        if (split_n > 0) {
+            const PlanReg pr = pregs[ri];
+            const u128 *a = A + pr.a_off + pr.as;
+            int ml[2] = {0, 0}, bl[2] = {0, 0};
+            for (int j = lane; j < pr.cnt; j += 64) {
+                const int h = j >= split_n;
+                const u128 cur = a[j];
+                const int span = (int)(cur.y >> 32 & 0xff);
+                if (j == 0 || j == split_n) { ml[h] += span; bl[h] += span; }
+                else {
+                    const u128 prev = a[j - 1];
+                    const int tl = (int32_t)cur.x - (int32_t)prev.x, ql = (int32_t)cur.y - (int32_t)prev.y;
+                    bl[h] += tl > ql ? tl : ql;
+                    ml[h] += tl > span && ql > span ? span : tl < ql ? tl : ql;
+                }
+            }
+            for (int h = 0; h < 2; ++h)
+                for (int d = 32; d; d >>= 1) { ml[h] += __shfl_xor(ml[h], d); bl[h] += __shfl_xor(bl[h], d); }
+            if (lane == 0) {
+                const u128 f = a[split_n], ll = a[split_n - 1];
+                splits[split_slot] = SplitRec{f.x, f.y, ll.x, ll.y, ml[0], bl[0], ml[1], bl[1]};
+            }
         }
     }
 }
