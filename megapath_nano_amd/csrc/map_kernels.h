@@ -1602,8 +1602,10 @@ __global__ __launch_bounds__(256) void chain_sort_ends_kernel(uint64_t *__restri
     }
 }
 
-// backtrack from the best chain end down: an anchor belongs to one chain only.  One wave per read; the walk
-// is sequential (lane 0), the copy of the chained anchors is parallel.
+constexpr int BT_PAR_MIN = 16;   // chain ends of a read from which the backtrack runs a lane per end
+
+// backtrack from the best chain end down: an anchor belongs to one chain only.  One wave per read; with few chain ends the
+// walk is sequential (lane 0) and the copy of the chained anchors parallel, with many a lane owns an end.
 //   out: u[k] = score<<32|cnt (in U, compacted), chained anchors in B (chain by chain, forward order), n_chain, n_chained
 __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
                                                              int n_reads, ChainParams cp, const int32_t *__restrict__ F,
@@ -1613,7 +1615,7 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                                                              uint64_t *__restrict__ Uc, unsigned long long *__restrict__ used,
                                                              int64_t *__restrict__ u_pos, int64_t *__restrict__ b_pos,
                                                              int32_t *__restrict__ n_chain, int64_t *__restrict__ n_chained,
-                                                             ChainRec *__restrict__ Rc) {
+                                                             ChainRec *__restrict__ Rc, int par_min) {
     __shared__ int s_k;
     __shared__ unsigned long long s_up, s_bp;
     const int lane = threadIdx.x;
@@ -1625,6 +1627,94 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
         int32_t *t = T + base, *v = V + base;
         uint64_t *u = U + base;
         const int n_u = n_ends[read];
+        if (n_u >= par_min) {
+            // Many chain ends (a strain-rich target set: a hundred loci per read): a lane per end instead of lane 0 for all.
+            // An anchor belongs to the best-ranked end whose way back passes through it, i.e. to the smallest rank in the subtree
+            // above it: every end walks back and leaves its rank with atomicMin, stopping where a better end has already been
+            // (that end goes on, or stopped at a still better one: nothing further back can be this end's).  The chain of an
+            // end is then the stretch of its way back that carries its own rank -- exactly what the ordered walk with "taken"
+            // marks yields, including the anchors that ends discarded later keep taken.
+            for (int64_t i = lane; i < n; i += 64) t[i] = 0x7fffffff;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            for (int e0 = 0; e0 < n_u; e0 += 64) {   // (ranks in order, 64 at a time: a better end is rarely overwritten)
+                const int e = e0 + lane;
+                if (e < n_u) {
+                    int32_t j = (int32_t)u[e];
+                    while (j >= 0) { if (atomicMin(&t[j], e) < e) break; j = p[j]; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __syncthreads();
+            // count and decide (v[e] = anchors of end e's chain, 0 if it does not survive) ...
+            int k_run = 0, nv_run = 0;
+            for (int e0 = 0; e0 < n_u; e0 += 64) {
+                const int e = e0 + lane;
+                int cnt = 0;
+                if (e < n_u) {
+                    const uint64_t ui = u[e];
+                    int32_t j = p[(int32_t)ui];
+                    cnt = 1;   // (the ordered walk visits its start even when a better end has taken it)
+                    while (j >= 0 && t[j] == e) { ++cnt; j = p[j]; }
+                    const bool keep = cnt >= cp.min_cnt && (j < 0 || (int32_t)(ui >> 32) - f[j] >= cp.min_sc);
+                    if (!keep) cnt = 0;
+                    v[e] = cnt;
+                }
+                k_run += __builtin_amdgcn_readlane(wave_scan_add(cnt > 0 ? 1 : 0), 63);
+                nv_run += __builtin_amdgcn_readlane(wave_scan_add(cnt), 63);
+            }
+            if (lane == 0) {
+                s_k = k_run;
+                n_chain[read] = k_run;
+                n_chained[read] = nv_run;
+                s_up = k_run ? atomicAdd(&used[0], (unsigned long long)k_run) : 0ULL;
+                s_bp = nv_run ? atomicAdd(&used[1], (unsigned long long)nv_run) : 0ULL;
+                u_pos[read] = (int64_t)s_up;
+                b_pos[read] = (int64_t)s_bp;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __syncthreads();
+            // ... then place: (score, count) words, records and anchors of the surviving chains in rank order, as the ordered
+            // walk leaves them; the second walk copies the chain back to front and measures it on the way (mm_cal_fuzzy_len)
+            u128 *b = B + s_bp;
+            uint64_t *uc = Uc + s_up;
+            ChainRec *rc = Rc + s_up;
+            k_run = 0; nv_run = 0;
+            for (int e0 = 0; e0 < n_u; e0 += 64) {
+                const int e = e0 + lane;
+                const int cnt = e < n_u ? v[e] : 0;
+                const int incl = wave_scan_add(cnt), kin = wave_scan_add(cnt > 0 ? 1 : 0);
+                if (cnt > 0) {
+                    const int kidx = k_run + kin - 1, off = nv_run + incl - cnt;
+                    const uint64_t ui = u[e];
+                    int32_t j = (int32_t)ui;
+                    u128 nxt = a[j];
+                    const u128 last = nxt;
+                    int ml = 0, bl = 0;
+                    b[off + cnt - 1] = nxt;
+                    for (int q = cnt - 2; q >= 0; --q) {
+                        j = p[j];
+                        const u128 cur = a[j];
+                        b[off + q] = cur;
+                        const int span = (int)(nxt.y >> 32 & 0xff);
+                        const int tl = (int32_t)nxt.x - (int32_t)cur.x, ql = (int32_t)nxt.y - (int32_t)cur.y;
+                        bl += tl > ql ? tl : ql;
+                        ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
+                        nxt = cur;
+                    }
+                    const int span0 = (int)(nxt.y >> 32 & 0xff);
+                    ml += span0; bl += span0;
+                    j = p[j];   // where the chain stops: nothing, or an anchor a better end owns (its score is taken off)
+                    const uint64_t sc = j < 0 ? ui >> 32 : (ui >> 32) - (uint64_t)f[j];
+                    uc[kidx] = sc << 32 | (uint32_t)cnt;
+                    rc[kidx] = ChainRec{nxt.x, nxt.y, last.x, last.y, ml, bl};
+                }
+                k_run += __builtin_amdgcn_readlane(kin, 63);
+                nv_run += __builtin_amdgcn_readlane(incl, 63);
+            }
+            __syncthreads();
+            continue;
+        }
         for (int64_t i = lane; i < n; i += 64) t[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();

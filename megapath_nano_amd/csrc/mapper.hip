@@ -407,8 +407,9 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     MPN_HIP_CHECK(hipGetLastError());
     // chained anchors and surviving chains go to compact pools
     o.u_compact.p = Utmp.p; o.u_compact.n = Utmp.n; o.u_compact.owned = Utmp.owned; Utmp.p = nullptr; Utmp.n = 0;
+    static const int bt_par_min = []() { const char *e = getenv("MPN_BT_PAR_MIN"); return e ? std::max(1, atoi(e)) : BT_PAR_MIN; }();   // (tests force either path)
     hipLaunchKernelGGL(chain_backtrack_kernel, dim3(g), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, n, cp, F.p, P.p, T.p, V.p,
-                       o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p, o.recs.p);
+                       o.u.p, o.n_ends.p, o.chained.p, o.u_compact.p, o.used.p, o.u_pos.p, o.b_pos.p, o.n_chain.p, o.n_chained.p, o.recs.p, bt_par_min);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(14);
     MPN_HIP_CHECK(stream_sync(st));
