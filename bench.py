@@ -540,8 +540,11 @@ def main():
     dt = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0
     if thr0 is not None and rank == 0:
-        for name, (cnt, sec) in thread_cpu.diff(thr0, thread_cpu.snapshot())[:12]:
+        thr1 = thread_cpu.snapshot()
+        for name, (cnt, sec) in thread_cpu.diff(thr0, thr1)[:12]:
             log(f'threads {name!r} x{cnt}: {sec / max(1, args.steps):.3f} CPU-s per step')
+        for tid, name, sec, is_main in thread_cpu.top_threads(thr0, thr1):
+            log(f'  thread {tid} {name!r}{" (main)" if is_main else ""}: {sec / max(1, args.steps):.3f} CPU-s per step')
     if args.config != 'c2':
         for s in range(args.steps):
             sampled += np.bincount(batches[(args.warmup + s) % n_distinct].truth['genome'], minlength=n)

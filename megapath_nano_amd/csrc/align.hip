@@ -95,13 +95,25 @@ static void reg_set_coor(Reg &r, int32_t qlen) {
     else { r.qs = qlen - ((int32_t)r.ly + 1); r.qe = qlen - ((int32_t)r.fy + 1 - q_span); }
 }
 
+// Per-thread scratch of the per-read hit bookkeeping: a few hundred thousand reads per step each need a handful of small
+// arrays; allocating them per read costs more than the work on them.
+struct HitScratch {
+    std::vector<uint64_t> cov;
+    std::vector<int> w, idx;
+    std::vector<std::pair<uint64_t, int>> aux;
+    std::vector<int32_t> order;
+    std::vector<int64_t> src;
+};
+static thread_local HitScratch tl_hs;
+
 // Chain c of a read in the order of the first anchors (the order minimap2's chaining leaves them in, HostChains::chain_order):
 // its (score, count) word, its record and the start of its anchors relative to the read's slice of the chain pool
 struct ChainIn { uint64_t u; const ChainRec *rec; int64_t src; };
 
 static void gen_regs(uint32_t hash, int qlen, int n_u, const ChainIn *c, std::vector<Reg> &regs) {
     struct Z { uint64_t x, y; int i; };
-    std::vector<Z> z(n_u);
+    static thread_local std::vector<Z> z;
+    z.resize((size_t)n_u);
     int k = 0;
     for (int i = 0; i < n_u; ++i) {
         const uint32_t h = (uint32_t)hash64((hash64(c[i].rec->fx) + hash64(c[i].rec->fy)) ^ hash);
@@ -132,8 +144,9 @@ static void set_parent(float mask_level, std::vector<Reg> &r, int sub_diff) {
     const int n = (int)r.size();
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) r[i].id = i;
-    std::vector<uint64_t> cov(n);
-    std::vector<int> w(n);
+    std::vector<uint64_t> &cov = tl_hs.cov;
+    std::vector<int> &w = tl_hs.w;
+    if ((int)cov.size() < n) { cov.resize((size_t)n); w.resize((size_t)n); }
     w[0] = 0; r[0].parent = 0;
     int k = 1;
     for (int i = 1; i < n; ++i) {
@@ -242,12 +255,13 @@ static void filter_regs(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs
 // mm_squeeze_a: the hits that survived selection get consecutive places in the read's anchor list, in the order of their first
 // anchors.  The anchors themselves are moved on the device (anchor_squeeze_kernel) along the segments written here: every hit
 // is still ONE chain at this point.  Returns the anchors the list holds.
+// (the read's segments are appended to `segs`, the staging list of the calling pool thread; Reg::seg indexes it)
 static int squeeze_a(std::vector<Reg> &regs, int read, int64_t pool_base, std::vector<SqueezeSeg> &segs) {
     const int n_regs = (int)regs.size();
-    std::vector<std::pair<uint64_t, int>> aux(n_regs);
+    std::vector<std::pair<uint64_t, int>> &aux = tl_hs.aux;
+    aux.resize((size_t)n_regs);
     for (int i = 0; i < n_regs; ++i) aux[i] = {(uint64_t)regs[i].as, i};
-    std::sort(aux.begin(), aux.end());
-    segs.clear();
+    if (n_regs > 1) std::sort(aux.begin(), aux.end());
     int as = 0;
     for (int i = 0; i < n_regs; ++i) {
         Reg &r = regs[aux[i].second];
@@ -263,7 +277,8 @@ static int squeeze_a(std::vector<Reg> &regs, int read, int64_t pool_base, std::v
 static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, std::vector<SqueezeSeg> &segs) {
     const int n_regs = (int)regs.size();
     if (n_regs < 2) return;
-    std::vector<std::pair<uint64_t, int>> aux;
+    std::vector<std::pair<uint64_t, int>> &aux = tl_hs.aux;
+    aux.clear();
     for (int i = 0; i < n_regs; ++i)
         if (regs[i].parent == i || regs[i].parent < 0) aux.push_back({(uint64_t)regs[i].as, i});
     std::sort(aux.begin(), aux.end());
@@ -311,13 +326,13 @@ static void join_long(const mpn_map_opt *opt, int qlen, std::vector<Reg> &regs, 
 static void hit_sort(std::vector<Reg> &r) {
     const int n = (int)r.size();
     if (n <= 1) return;
-    struct A { uint64_t x; int y; };
-    std::vector<A> aux;
+    std::vector<std::pair<uint64_t, int>> &aux = tl_hs.aux;
+    aux.clear();
     for (int i = 0; i < n; ++i)
         if (r[i].inv || r[i].cnt > 0) aux.push_back({(uint64_t)(uint32_t)(r[i].has_p ? r[i].dp_max : r[i].score) << 32 | r[i].hash, i});
-    std::sort(aux.begin(), aux.end(), [](const A &p, const A &q) { return p.x != q.x ? p.x < q.x : p.y < q.y; });
+    std::sort(aux.begin(), aux.end());
     std::vector<Reg> t(aux.size());
-    for (int i = (int)aux.size() - 1; i >= 0; --i) t[aux.size() - 1 - i] = r[aux[i].y];
+    for (int i = (int)aux.size() - 1; i >= 0; --i) t[aux.size() - 1 - i] = std::move(r[(size_t)aux[i].second]);
     r.swap(t);
 }
 
@@ -477,13 +492,17 @@ public:
         std::lock_guard<std::mutex> g(mu);
         while ((int)threads.size() < n_threads - 1) threads.emplace_back([this]() { worker(); });
     }
-    void parallel_for(int n, int max_par, const std::function<void(int, int)> &fn, int tag = 0) {
+    // grain: items that are worth one helping thread.  The bursts of a sub-batch are a few thousand light items: waking all
+    // pool threads for each of them (a futex round trip and a fight for the queue lock per thread and burst) cost more CPU
+    // than the items themselves.
+    void parallel_for(int n, int max_par, const std::function<void(int, int)> &fn, int tag = 0, int grain = 512) {
+        max_par = std::min(max_par, 1 + n / std::max(1, grain));
         if (max_par <= 1 || n < 2) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
         Job j;
         j.fn = &fn; j.n = n; j.max_par = max_par; j.tag = tag;
         j.chunk = std::max(1, std::min(32, n / (max_par * 8)));
         { std::lock_guard<std::mutex> g(mu); jobs.push_back(&j); }
-        cv_work.notify_all();
+        for (int k = 1; k < max_par; ++k) cv_work.notify_one();
         run(j, 0);
         std::unique_lock<std::mutex> lk(mu);
         for (auto it = jobs.begin(); it != jobs.end(); ++it) if (*it == &j) { jobs.erase(it); break; }
@@ -497,7 +516,7 @@ public:
 };
 static HostPool g_pool;
 
-static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn, int tag = 0) { g_pool.parallel_for(n, n_threads, fn, tag); }
+static void parallel_for(int n, int n_threads, const std::function<void(int, int)> &fn, int tag = 0, int grain = 512) { g_pool.parallel_for(n, n_threads, fn, tag, grain); }
 
 struct ReadState {
     std::vector<Reg> regs;
@@ -663,6 +682,7 @@ struct Slot {
     PoolBuf pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
     PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
+    std::vector<std::vector<SqueezeSeg>> seg_stage;   // per pool thread: the squeeze segments of the reads it handled
 };
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
@@ -672,7 +692,7 @@ static int g_force_kernel = 0;  // test hook: 0 auto, 1 single-wave LDS kernel, 
 static void parallel_chunks(int64_t n, int n_threads, const std::function<void(int64_t, int64_t, int)> &fn, int tag = 0) {
     if (n_threads <= 1 || n < 8192) { fn(0, n, 0); return; }
     // chunk t of n_threads equal ranges; the chunk index is what the callers use for their per-thread accumulators
-    g_pool.parallel_for(n_threads, n_threads, [&](int t, int) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); }, tag);
+    g_pool.parallel_for(n_threads, n_threads, [&](int t, int) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); }, tag, 1);
 }
 
 // the second pass of a gap fill whose CIGAR failed the z-drop test: exact maximum, band (or anti-diagonal) layout
@@ -1277,16 +1297,20 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     if (SL.pin_segs.ensure((size_t)h.chain_off[(size_t)n] * sizeof(SqueezeSeg) + (size_t)(n + 1) * 8 + 64)) return -1;
     int64_t *sq_off = SL.pin_segs.as<int64_t>();                                     // [n + 1] start of every read's squeezed list
     SqueezeSeg *h_segs = reinterpret_cast<SqueezeSeg *>(sq_off + n + 1);
-    struct alignas(64) Cursor { std::atomic<int64_t> v{0}; } seg_cursor;
-    parallel_for(n, n_threads, [&](int i, int) {
+    // (every pool thread stages the segments of its reads in a list of its own: a shared cursor is a hot cache line)
+    std::vector<std::vector<SqueezeSeg>> &stage = SL.seg_stage;
+    if ((int)stage.size() < std::max(1, n_threads)) stage.resize((size_t)std::max(1, n_threads));
+    for (auto &v : stage) v.clear();
+    parallel_for(n, n_threads, [&](int i, int slot) {
         ReadState &S = rs[i];
         const int nc = h.n_chain[i];
         if (nc == 0) return;
         const int qlen = seq_len[i];
         CpuSect sect(g_cpu_on);
-        std::vector<int32_t> order(nc);
-        std::vector<int64_t> src(nc);
-        std::vector<ChainIn> cin(nc);
+        static thread_local std::vector<ChainIn> cin;
+        std::vector<int32_t> &order = tl_hs.order;
+        std::vector<int64_t> &src = tl_hs.src;
+        order.resize((size_t)nc); src.resize((size_t)nc); cin.resize((size_t)nc);
         h.chain_order(i, order.data(), src.data());
         for (int c = 0; c < nc; ++c) cin[c] = ChainIn{h.u_all[h.u_pos[i] + order[c]], h.rec_all + h.u_pos[i] + order[c], src[c]};
         sect.lap(3);
@@ -1296,20 +1320,20 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         gen_regs(hash, qlen, nc, cin.data(), S.regs);
         set_parent(opt->mask_level, S.regs, opt->a * 2 + opt->b);
         select_sub(opt->pri_ratio, idx->k * 2, opt->best_n, S.regs);
-        std::vector<SqueezeSeg> segs;
+        sect.lap(4);
+        std::vector<SqueezeSeg> &segs = stage[(size_t)slot % stage.size()];
+        const size_t seg0 = segs.size();
         S.n_a = squeeze_a(S.regs, i, h.b_pos[i], segs);
         join_long(opt, qlen, S.regs, segs);
-        sect.lap(4);
-        if (opt->with_cigar && !segs.empty()) {
-            const int64_t at = seg_cursor.v.fetch_add((int64_t)segs.size(), std::memory_order_relaxed);
-            memcpy(h_segs + at, segs.data(), segs.size() * sizeof(SqueezeSeg));
-            sect.lap(5);
-        }
-    }, 1);
+        if (!opt->with_cigar) segs.resize(seg0);
+        sect.lap(5);
+    }, 1, 128);
+    int64_t n_segs = 0;
+    for (auto &v : stage) { if (!v.empty()) memcpy(h_segs + n_segs, v.data(), v.size() * sizeof(SqueezeSeg)); n_segs += (int64_t)v.size(); }
     wt.stop_into(g_stats[19]);
     sq_off[0] = 0;
     for (int i = 0; i < n; ++i) sq_off[i + 1] = sq_off[i] + rs[i].n_a;
-    const int64_t n_sq = sq_off[n], n_segs = seg_cursor.v.load();
+    const int64_t n_sq = sq_off[n];
     if (opt->with_cigar && n_sq > 0) {
         DevBuf<u128> d_a;
         DevBuf<unsigned char> d_segs;
@@ -1742,7 +1766,7 @@ static int64_t emit_batch(const Targets tg, const mpn_map_opt *opt, int32_t n, c
             const char *nm = names && names[i] ? names[i] : "*";
             if (want_paf && !regs[i]->empty()) write_paf(tg, opt, nm, seq_len[i], *regs[i], rep_len[i], paf_lines[i]);
             if (want_sam) write_sam(tg, nm, seq_len[i], seqs + seq_off[i], quals ? quals + seq_off[i] : nullptr, *regs[i], rep_len[i], sam_lines[i]);
-        });
+        }, 0, 16);   // (text is heavy per read)
     bool short_cols = false, short_text = false;
     g_kept.cols.clear(); g_kept.text.clear(); g_kept.sam.clear(); g_kept.n_rows = -1; g_kept.has_text = g_kept.has_sam = false;
     if (cols) {
@@ -1897,7 +1921,7 @@ extern "C" int64_t mpn_hits_finish(mpn_hits *acc, const mpn_map_opt *opt, int32_
     const int n_threads = default_host_threads(opt);
     g_pool.ensure(n_threads);
     if (!acc->n_parts) { set_error("mpn_hits_finish: no part was mapped"); return -1; }
-    parallel_for(n, n_threads, [&](int i, int) { merge_regs(opt, acc->k, acc->regs[(size_t)i], acc->rep_len[(size_t)i]); });
+    parallel_for(n, n_threads, [&](int i, int) { merge_regs(opt, acc->k, acc->regs[(size_t)i], acc->rep_len[(size_t)i]); }, 0, 128);
     std::vector<std::vector<Reg>*> regs((size_t)n);
     for (int i = 0; i < n; ++i) regs[(size_t)i] = &acc->regs[(size_t)i];
     return emit_batch(Targets{&acc->names, &acc->lens}, opt, n, names, seqs, quals, seq_off, seq_len, regs, acc->rep_len, n_threads, paf, paf_cap, cols);

@@ -483,7 +483,8 @@ void HostChains::chain_order(int i, int32_t *order, int64_t *src) const {
     const uint64_t *u = u_all + u_pos[i];
     const ChainRec *r = rec_all + u_pos[i];
     // (the same key as read_chains: first anchor, then the chain's position in the pool)
-    std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w(nc);
+    static thread_local std::vector<std::pair<std::pair<uint64_t, uint64_t>, int>> w;
+    w.resize((size_t)nc);
     int64_t k = 0;
     for (int c = 0; c < nc; ++c) { w[c] = {{r[c].fx, (uint64_t)k << 32 | (uint32_t)c}, c}; k += (int32_t)u[c]; }
     std::sort(w.begin(), w.end());

@@ -8,6 +8,7 @@
 #include <time.h>
 #include <mutex>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -87,8 +88,10 @@ struct EvTimer {
     hipStream_t st;
     std::vector<hipEvent_t> ev;
     std::vector<int> slot, slot2;  // slot[i] (and slot2[i]): g_stats indices charged with ev[i] -> ev[i+1]; -1 = not charged
+    static bool enabled() { static const bool on = []() { const char *e = getenv("MPN_KERNEL_EVENTS"); return !e || atoi(e) != 0; }(); return on; }
     explicit EvTimer(hipStream_t s) : st(s) { push(); }
     void push() {
+        if (!enabled()) return;   // MPN_KERNEL_EVENTS=0: no per-kernel timing (an event per kernel group is a completion signal the runtime's thread handles)
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
         (void)hipEventRecord(e, st);
@@ -96,9 +99,10 @@ struct EvTimer {
         slot.push_back(-1); slot2.push_back(-1);
     }
     // the span that ends here goes to stat_index (a kernel family) and, if given, to `single` (one kernel's own slot)
-    void mark(int stat_index, int single = -1) { slot.back() = stat_index; slot2.back() = single; push(); }
+    void mark(int stat_index, int single = -1) { if (!enabled()) return; slot.back() = stat_index; slot2.back() = single; push(); }
     void skip() { push(); }                                            // the span that ends here is not charged
     void resolve() {  // call after the stream has been synchronised
+        if (!enabled()) return;
         for (size_t i = 0; i + 1 < ev.size(); ++i) {
             if (slot[i] < 0 && slot2[i] < 0) continue;
             float ms = 0;

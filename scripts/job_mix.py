@@ -6,7 +6,8 @@ r = np.fromfile(sys.argv[1], dtype=np.int32).reshape(-1, 6)
 cls, q, t, w, flag, ncol = (r[:, k].astype(np.int64) for k in range(6))
 lst = cls & 0xff
 EXTZ, RIGHT, APPROX = 0x40, 0x02, 0x08   # printed for orientation only: see ext_kernels.h for the flag values
-fam = np.where(lst < 5, 0, np.where(lst < 20, 1, np.where(lst < 68, 2, 3)))
+L_BAND = 164   # plan_kernels.h: L_STRIP + 16 * N_STRIP_CLASS
+fam = np.where(lst < 5, 0, np.where(lst < 20, 1, np.where(lst < L_BAND, 2, 3)))
 names = ['lds', 'wg', 'strip', 'band']
 print('windows', len(r))
 for f in range(4):
@@ -16,10 +17,10 @@ for f in range(4):
     nominal = ((q + t - 1) * ncol)[m].sum()
     print(f'{names[f]:6s} n={m.sum():9d} q*t={(q * t)[m].sum() / 1e9:8.2f} G  n_r*n_col={nominal / 1e9:8.2f} G  mean q {q[m].mean():7.1f} t {t[m].mean():7.1f}')
     if f == 3:
-        for l in range(68, 84):
+        for l in range(L_BAND, L_BAND + 16):
             ml = m & (lst == l)
             if ml.any():
                 qq, tt = q[ml], t[ml]
-                print(f'   list {l} (variant {(l - 68) // 4}, lds class {(l - 68) % 4}): n={ml.sum():8d}  q*t {(qq * tt).sum() / 1e9:7.2f} G  '
+                print(f'   list {l} (variant {(l - L_BAND) // 4}, lds class {(l - L_BAND) % 4}): n={ml.sum():8d}  q*t {(qq * tt).sum() / 1e9:7.2f} G  '
                       f'n_r*n_col {((qq + tt - 1) * ncol[ml]).sum() / 1e9:7.2f} G  mean q {qq.mean():7.1f} t {tt.mean():7.1f}  max q {qq.max()} t {tt.max()}  '
                       f'flags {np.unique(flag[ml] & 0xff)[:8]}')

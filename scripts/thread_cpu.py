@@ -23,3 +23,9 @@ def diff(a, b):
         n, tot = agg.get(name, (0, 0.0))
         agg[name] = (n + 1, tot + d)
     return sorted(agg.items(), key=lambda kv: -kv[1][1])
+
+
+def top_threads(a, b, k=8):
+    """the k busiest single threads: (tid, name, CPU seconds, is_main)"""
+    rows = [(tid, name, t - a.get(tid, (name, 0.0))[1], tid == os.getpid()) for tid, (name, t) in b.items()]
+    return sorted(rows, key=lambda r: -r[2])[:k]
