@@ -8,17 +8,22 @@
 A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM:
 seed-chain-extend against the resident index (HIP kernels), host hit bookkeeping, read reassignment (HIP kernels),
 best hit per read and the per-species / per-name counters, followed for N > 1 by the RCCL all-reduce of those counters.
-Workload (--config, default c3) = BASELINE.json configs[2]: a 10-species community (incl. a 99 %-identity strain pair)
-sampled against an index of N_g synthetic genomes; every rank holds the whole index and maps its own reads (weak
-scaling, no data-path collective).  Other --config values are the variants VERDICT r2 asked to be timed beside the
-headline (strain-rich index, the largest one-piece index, a two-part index through mpn_hits, configs[1]); each names
-itself in config.workload.  Genomes and reads are generated ON THE GPU (torch); a few distinct read batches are generated
+Workload (--config, default refseq) = BASELINE.json configs[2] at the scale and composition north_star names: a 10-species
+community sampled against a STRAIN-RICH target set (100 assemblies of every community species at 97-99.9 % identity) of
+18000 genomes = 72 Gbp, held as RESIDENT index parts built one after another (minimap2 -I; 288 GB of HBM keep all of them,
+where a CPU host streams them), every read mapped against every part and the hits merged per read like --split-prefix
+(mpn_hits); every rank holds all parts and maps its own reads (weak scaling, no data-path collective).  --config c3 is the
+round-1..3 headline (20 Gbp of random genomes + 10 strain copies in one index); strain / big / parts / c2 are the other
+variants; each names itself in config.workload.  Genomes and reads are generated ON THE GPU (torch); a few distinct read batches are generated
 once and rotated over the steps (the mapper keeps no state between calls, so a repeated batch costs what a fresh one does).
 
-Rank 0 prints ONE JSON line.  `value` = read bases / wall time of the K timed steps with the reads resident in HBM;
-`pcie_inclusive_gbp_per_min` = the same steps fed from host buffers (H2D inside the call).  `roofline` is for the kernel with
-the largest device time of THIS run (HIP events around each launch on the stream it is launched on) plus a `valu` object for
-the DP (the path is VALU-issue bound); `cpu_baseline` times the CPU oracle (oracle/mm2_oracle.c, a port)
+Rank 0 prints ONE JSON line.  `value` = read bases / wall time of the K timed steps fed from HOST buffers (the read H2D is
+inside the timed call: SURVEY 8d's wall time includes it); `resident_input_gbp_per_min` = a few more steps with the reads
+already in HBM, as a side figure.  `roofline` is for the kernel with the largest EXCLUSIVE device time: after the timed region
+a slice of a batch runs through ONE pipeline worker (nothing else on the GPU), which gives every candidate's launch duration
+alone (`alone_ms`) beside its HIP-event span inside the 12-worker pipeline (`in_pipeline_ms`); fractions are given on the HBM
+axis (8 TB/s) and on the VALU axis (1.229e12 wave-instructions/s = 1024 SIMDs x 2.4 GHz / 2 cycles, the guide's figure; the
+instruction-mix ceiling is a side note).  `cpu_baseline` times the CPU oracle (oracle/mm2_oracle.c, a port)
 on a bounded sample of the same reads on this host's cores against an index of >= 1 Gbp; `correctness` checks the output of
 THIS run at the full index size (outside the timed region): truth hit rate from the generator's read origins, the
 independent PAF checker (tests/paf_check.py) over target slices fetched from the index in HBM, per-name counts against the
@@ -51,20 +56,28 @@ VALU_CEIL_WAVE_INSTR = 1024 * 2.4e9 / STRIP_CYCLES_PER_INSTR   # 1024 SIMDs at 2
 T00 = time.time()
 
 
-def pmc_traffic(kernel, launches_per_step):
+def pmc_traffic(kernel, launches_per_step, config='refseq'):
     """HBM bytes per launch of `kernel` from the PMC summary committed under profiles/ (collected by scripts/collect_r03.sh on this
     workload in separate --pmc passes, as MI355X_MICROARCH.md prescribes); None when the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r03', 'r03_pmc_summary.json')
-    try:
-        with open(path) as f:
-            ks = json.load(f)['kernels']
-    except (OSError, ValueError, KeyError):
+    ks, rel = None, None
+    for rel in ('profiles/r04/r04_pmc_summary.json', 'profiles/r03/r03_pmc_summary.json'):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                doc = json.load(f)
+            if doc.get('config', 'c3') != config:   # (a PMC summary belongs to the workload it was collected on; r03's was c3)
+                continue
+            ks = doc['kernels']
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    if ks is None:
         return None, None
-    stem = kernel.split('<')[0]
+    stem = kernel.split('<')[0].split(' ')[0]
+    want_exact = '<true>' in kernel
     rows = [v for k, v in ks.items() if k.split('<')[0] == stem and not k.startswith('setup:')
-            and not (stem == 'ext_dp_strip_kernel' and 'true' in k)]   # (the exact strip variants are not the gap-fill candidate)
+            and not (stem == 'ext_dp_strip_kernel' and ('true' in k) != want_exact)]
     b = sum(v.get('hbm_bytes_per_step', 0) for v in rows)
-    return (int(b / max(launches_per_step, 1)) if b else None), 'profiles/r03/r03_pmc_summary.json (bytes per step / launches per step)'
+    return (int(b / max(launches_per_step, 1)) if b else None), rel + ' (bytes per step / launches per step)'
 
 
 def log(msg):
@@ -166,6 +179,51 @@ def build_workload(args, device, rank, world):
                           f'25% from 5 microbial genomes outside the index; {args.reads_per_step} reads/step, -x map-ont -c (-N 5 -p 0.8), human/decoy '
                           f'classification (megapath_nano.py:1135-1200) inside the step')
         del flat, mic, all_flat
+    elif cfg == 'refseq':
+        # configs[2] as north_star names it: a strain-rich target set of args.genomes x genome_len (default 18000 x 4 Mbp = 72 Gbp)
+        # as args.parts RESIDENT index parts, generated and indexed one after another (the ASCII of a part leaves HBM before the
+        # next one is made); reads come from the 10 base genomes of the community; every step maps every part, hits merged per read
+        n_parts, n_fam, copies = args.parts, 10, 100
+        per = args.genomes // n_parts
+        base_names, base_flat, _ = synth.make_genomes_device(20240901, n_fam, args.genome_len, 0, device)
+        base = base_flat.view(n_fam, args.genome_len)
+        weights = np.random.default_rng(7).lognormal(0.0, 1.0, size=n_fam)
+        batches = [make_batch(base_flat, weights, args, 1000 * (rank + 1) + s_, device) for s_ in range(n_distinct)]
+        idx, fam_all, part_s, n_tot = [], [], [], 0
+        t_all = time.time()
+        for p_ in range(n_parts):
+            names, flat, lens, fam = synth.make_refseq_part_device(20240901, p_, n_parts, per, args.genome_len, base, copies, 0.97, 0.999, device)
+            torch.cuda.synchronize()
+            if p_ == 0 and rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # host copies of the genomes the CPU baseline indexes: the community + fillers (the first genomes of part 0)
+                view = flat.view(per, args.genome_len)
+                W['cpu_genomes'] = [(names[g], view[g].cpu().numpy()) for g in range(min(per, max(n_fam, args.cpu_index_genomes)))]
+            t0 = time.time()
+            idx.append(mapper.Index.from_device(names, flat.data_ptr(), lens))
+            part_s.append(round(time.time() - t0, 2))
+            fam_all.append(fam)
+            n_tot += len(names)
+            del flat
+            torch.cuda.empty_cache()
+            if rank == 0:
+                log(f'part {p_ + 1}/{n_parts}: {per} genomes indexed in {part_s[-1]:.1f} s ({idx[-1].n_minimizers} minimizers)')
+        W['index_s'] = sum(part_s)
+        fam_all = np.concatenate(fam_all)
+        n = n_tot
+        gid = np.arange(n, dtype=np.int64)
+        # the species name of an assembly is its base genome's (sequence_name -> species, reassignment.py:69-71); truth genome f = target f
+        name_code = np.where(fam_all >= 0, fam_all, gid).astype(np.int32)
+        twin_of = np.where((fam_all >= 0) & (gid >= n_fam), fam_all, -1).astype(np.int64)
+        opt_kw = dict(best_n=50, pri_ratio=1.0)  # megapath_nano.py:1270  -N 50 -p 1 -x map-ont
+        W.update(idx=idx, tax=Taxonomy(name_code, n, name_code, n), n=n, members=list(range(n_fam)), twin_of=twin_of,
+                 index_bp=n * args.genome_len, n_index_genomes=n, part_build_s=part_s, parts=n_parts,
+                 workload=f'configs[2] (1M-read 10-species community vs full RefSeq bacterial, reassignment on) at N_g = {n} synthetic genomes x '
+                          f'{args.genome_len} bp = {n * args.genome_len / 1e9:.1f} Gbp of targets, STRAIN-RICH ({copies} assemblies of each of the {n_fam} community '
+                          f'species at 97-99.9% identity, spread over the parts), held as {n_parts} RESIDENT index parts of {per * args.genome_len / 1e9:.1f} Gbp '
+                          f'(minimap2 -I) on every GPU, every read mapped against every part and the hits merged per read (mpn_hits = --split-prefix); '
+                          f'{args.reads_per_step} synthetic ONT-like reads/step/GPU (Gamma lengths, mean {args.mean_len} bp, 12% errors, homopolymer-biased '
+                          f'indels; in-repo stand-in for badread, generated on the GPU; {n_distinct} distinct batches rotated over the steps), -N 50 -p 1 -x map-ont -c')
+        del base_flat
     else:
         n = args.genomes
         families = (10, 100, 0.97, 0.999) if cfg == 'strain' else None
@@ -268,7 +326,7 @@ def cpu_baseline(genomes, packed, opt_kw, seconds_target=15.0):
                 sample=f'{n} reads ({bases} bp) of the step batch, oracle/mm2_oracle.c seed-chain-extend on {cores} threads, {dt:.1f} s wall; '
                        f'its index holds {len(genomes)} of the genomes (the community + fillers, {idx_bp} bp, built in {idx_s:.1f} s, '
                        f'mid_occ {mid}): {idx_bp / 1e9:.2f} Gbp against the GPU\'s full index, so the CPU still sees fewer stray seed hits',
-                index_bp=idx_bp, index_build_s=round(idx_s, 1), mid_occ=mid,
+                index_bp=idx_bp, index_build_s=round(idx_s, 1), mid_occ=mid, same_inputs=False,   # (same reads, a smaller index: host RAM and the time budget do not hold the GPU's)
                 minimap2_on_box=shutil.which('minimap2'))   # a real binary would be timed beside the port; none ships in the image
 
 
@@ -439,18 +497,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--config', default='c3', choices=['c3', 'strain', 'big', 'parts', 'c2'],
-                    help='c3 = BASELINE configs[2] (the headline); strain = the same with 100 assemblies of every community species in the '
-                         'index; big = the largest one-piece index (36 Gbp); parts = the 20 Gbp target set as two index parts merged like '
-                         'minimap2 --split-prefix; c2 = BASELINE configs[1] (100k reads vs a repeat-rich human-like genome + decoys, -N 5 -p 0.8, '
-                         'human/decoy classification)')
+    ap.add_argument('--config', default='refseq', choices=['refseq', 'c3', 'strain', 'big', 'parts', 'c2'],
+                    help='refseq = BASELINE configs[2] at north_star\'s scale (the headline): a strain-rich 72 Gbp target set as resident index '
+                         'parts, hits merged per read; c3 = the round-1..3 headline (20 Gbp of random genomes + 10 strain copies, one index); '
+                         'strain = c3\'s size with 100 assemblies of every community species; big = the largest one-piece index (36 Gbp); '
+                         'parts = the 20 Gbp target set as two index parts merged like minimap2 --split-prefix; c2 = BASELINE configs[1] '
+                         '(100k reads vs a repeat-rich human-like genome + decoys, -N 5 -p 0.8, human/decoy classification)')
+    ap.add_argument('--parts', type=int, default=4, help='refseq: resident index parts the target set is cut into (9 = the reference\'s -I 8G on a 512 GiB host)')
     ap.add_argument('--genomes', type=int, default=None)
     ap.add_argument('--genome-len', type=int, default=4000000)
     ap.add_argument('--strain-pairs', type=int, default=10)
     ap.add_argument('--reads-per-step', type=int, default=None)
     ap.add_argument('--mean-len', type=int, default=8000)
     ap.add_argument('--distinct-batches', type=int, default=3)
-    ap.add_argument('--pcie-steps', type=int, default=10, help='extra steps fed from host buffers (PCIe-inclusive rate, never `value`)')
+    ap.add_argument('--resident-steps', '--pcie-steps', dest='resident_steps', type=int, default=6,
+                    help='extra steps with the reads already resident in HBM (the side figure resident_input_gbp_per_min; `value` is fed from host buffers)')
+    ap.add_argument('--alone-reads', type=int, default=0, help='reads of the single-worker pass that times every kernel alone (0 = an eighth of a batch; -1 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-correctness', action='store_true')
     ap.add_argument('--mapping-only', action='store_true', help='diagnostic: no base-level extension (the reference\'s mapping_only mode); implies --no-correctness, not the metric')
@@ -459,7 +521,7 @@ def main():
     if args.mapping_only:
         args.no_correctness = True
         args.no_cpu_baseline = True
-    cfg_defaults = {'c3': (5000, 262144), 'strain': (5000, 16384), 'big': (9000, 262144), 'parts': (5000, 262144), 'c2': (0, 100000)}
+    cfg_defaults = {'refseq': (18000, 65536), 'c3': (5000, 262144), 'strain': (5000, 65536), 'big': (9000, 262144), 'parts': (5000, 262144), 'c2': (0, 100000)}
     if args.genomes is None:
         args.genomes = cfg_defaults[args.config][0]
     if args.reads_per_step is None:
@@ -510,7 +572,7 @@ def main():
         return align_and_assign(idx, opt, b, tax, allreduce=allreduce, rng=rnd, shard=(rank, world), use_device=use_device)
 
     for s in range(args.warmup):
-        run(batches[s % n_distinct])
+        run(batches[s % n_distinct], use_device=False)
         if rank == 0:
             log(f'warmup step {s + 1}/{args.warmup} done')
     mdist.barrier()
@@ -528,7 +590,7 @@ def main():
     bases = 0
     for s in range(args.steps):
         b = batches[(args.warmup + s) % n_distinct]
-        out = run(b)
+        out = run(b, use_device=False)   # fed from host buffers: the read H2D is inside the timed call (SURVEY 8d's wall time)
         bases += b.bases
         counts = out['read_count'] if counts is None else counts + out['read_count']
         for k, v in mapper.last_stats().items():
@@ -560,31 +622,49 @@ def main():
         bases = int(bt.item())
         if args.config != 'c2':
             allreduce(sampled)   # counts are already global (align_and_assign all-reduces them)
-    # PCIe-inclusive rate (never `value`): the same steps fed from the host buffers, read H2D inside the timed call
-    pcie = None
-    if args.pcie_steps > 0:
+    # side figure: the same steps with the reads already resident in HBM (no H2D in the call)
+    resident = None
+    if args.resident_steps > 0:
         mdist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         pb = 0
-        for s in range(args.pcie_steps):
+        for s in range(args.resident_steps):
             b = batches[s % n_distinct]
-            run(b, use_device=False)
+            run(b, use_device=True)
             pb += b.bases
         torch.cuda.synchronize()
         mdist.barrier()
-        pcie = pb * world / (time.perf_counter() - t1) * 60 / 1e9
+        resident = pb * world / (time.perf_counter() - t1) * 60 / 1e9
         if rank == 0:
-            log(f'{args.pcie_steps} PCIe-inclusive steps done')
+            log(f'{args.resident_steps} resident-input steps done')
     if rank != 0:
         return
 
     K = max(1, args.steps)
-    st = {k: v / K for k, v in stats_acc.items()}  # per step (rank 0)
+    st = {k: v / K for k, v in stats_acc.items()}  # per step (rank 0), summed over the index parts a step maps
     nsub = max(st['sub_batches'], 1)
     rounds = max(st['dp_rounds'], 1)
-    # Candidate kernels for the roofline line: device ns from HIP events around each launch (rank 0, per step), launches per
-    # step, and ALGORITHMIC bytes per step (DESIGN.md section 5 states the per-unit figures):
+
+    # ---- every kernel ALONE: a slice of a batch through ONE pipeline worker (nothing else on the GPU), after the timed region ----
+    alone = None
+    if args.alone_reads >= 0:
+        na = args.alone_reads or max(256, batches[0].n // 8)
+        sub = sub_batch(batches[0], min(na, batches[0].n))
+        os.environ['MPN_PIPE_WORKERS'] = '1'
+        try:
+            acc = {}
+            for part in (idx if isinstance(idx, (list, tuple)) else [idx]):
+                mapper.map_batch_ex(part, opt, sub, want_paf=False, want_cols=True, use_device=False)
+                for k, v in mapper.last_stats().items():
+                    acc[k] = acc.get(k, 0) + v
+            alone = acc
+        finally:
+            del os.environ['MPN_PIPE_WORKERS']
+        log(f'single-worker pass over {sub.n} reads done ({int(alone["sub_batches"])} sub-batches)')
+
+    # Candidate kernels: (stat key(s) of the HIP-event span, launches per sub-batch or round, ALGORITHMIC bytes per step, cells per
+    # step for the DP kernels).  Algorithmic bytes:
     #   sketch (count pass + fill)   : 2 x 1 B per read base in + 16 B per minimizer out
     #   seed lookup                  : 16 B per minimizer in + 12 B (count, first position) out
     #   stray-hit filter (2 passes)  : 2 x 8 B per index position gathered + 1 keep bit per position out
@@ -593,44 +673,80 @@ def main():
     #   anchor window sort           : 16 B in + 16 B out per emitted anchor
     #   anchor compaction (2 passes) : 2 x 16 B per emitted anchor in + 16 B per kept anchor out
     #   chain DP                     : 16 B per kept anchor in + 16 B (f, p, t, v) out
-    #   strip DP <GL>                : 1 direction byte out per DP cell (qlen x tlen per window)
+    #   strip DP (gap fill / exact)  : 1 direction byte out per DP cell (qlen x tlen per window)
     #   alignment finishing          : 4 B per CIGAR op in + 4 B out, ~1 B per aligned query base + 0.25 B per target base in
-    cand = {
-        'sketch_fast_kernel + sketch_fill_kernel': (st['k_sketch_count_ns'] + st['k_sketch_fill_ns'], 2 * nsub, 2 * st['bases'] + 16 * st['minimizers']),
-        'seed_lookup_kernel': (st['k_seed_lookup_ns'], nsub, 28 * st['minimizers']),
-        'seed_filter_kernel': (st['k_seed_filter_ns'], nsub, 16 * st['anchors'] + st['anchors'] / 8),
-        'seed_emit_kernel': (st['k_seed_fill_ns'], nsub, 24 * st['anchors_emitted']),
-        'anchor_msd_kernel': (st['k_sort_msd_ns'], nsub, 40 * st['anchors_emitted']),
-        'anchor_window_sort_kernel': (st['k_sort_chunk_ns'], nsub, 32 * st['anchors_emitted']),
-        'anchor_compact_kernel<count|write>': (st['k_compact_ns'], 2 * nsub, 32 * st['anchors_emitted'] + 16 * st['anchors_kept']),
-        'chain_dp_kernel': (st['k_chain_dp_ns'], nsub, 32 * st['anchors_kept']),
-        # (one launch per round: 16-, 32- and 64-lane groups are segments of its grid)
-        'ext_dp_strip_kernel<gap fill>': (st['k_strip16_ns'] + st['k_strip32_ns'] + st['k_strip64_ns'], rounds,
-                                          st['strip16_cells'] + st['strip32_cells'] + st['strip64_cells']),
-        'aln_finish_wave_kernel': (st['k_finish_ns'], 4 * rounds, 8 * st['cigar_ops'] + 2 * st['bases']),
-    }
-    strip_inst = {f'{g}-lane groups': {'cells_per_step': int(st[f'strip{g}_cells'])} for g in (16, 32, 64)}   # (one launch per round holds all three)
-    dom = max(cand, key=lambda k: cand[k][0])
-    ns, launches, abytes = cand[dom]
-    achieved = abytes / max(ns, 1)  # bytes per ns == GB/s
-    traffic, traffic_src = pmc_traffic(dom, launches)
-    hits_per_mz = st['anchors'] / max(st['minimizers'], 1)
-    # VALU view of the DP: the strip kernels' cells and device time (HIP events; the launches of the 12
-    # pipeline workers overlap, so the sum of their spans can exceed the wall time: both rates are given)
-    strip_ns = st['k_strip16_ns'] + st['k_strip32_ns'] + st['k_strip64_ns']
     strip_cells = st['strip16_cells'] + st['strip32_cells'] + st['strip64_cells']
-    wi_per_cell = STRIP_INSTR_PER_CELL / 64.0
-    valu = {
-        'kernel': 'ext_dp_strip_kernel<gap fill>', 'cells_per_step': int(strip_cells), 'all_dp_cells_per_step': int(st['dp_cells']),
-        'wave_instr_per_cell': round(wi_per_cell, 4),
-        'gcups_in_kernel': round(strip_cells / max(strip_ns, 1), 2),                      # cells per ns of the kernels' own spans
-        'gcups_whole_step': round(st['dp_cells'] / (dt / K * 1e9), 2),                     # every DP cell of the step over the step's wall time
-        'achieved_wave_instr_per_s': round(strip_cells * wi_per_cell / max(strip_ns, 1) * 1e9, 0),
-        'peak_wave_instr_per_s': VALU_CEIL_WAVE_INSTR,
-        'frac': round(strip_cells * wi_per_cell / max(strip_ns, 1) * 1e9 / VALU_CEIL_WAVE_INSTR, 4),
-        'note': 'peak = issue rate of the cell\'s own instruction mix (9.5 two-operand 32-bit instructions at 2.7 cycles and 12 packed / three-operand ones at 4.4 per cell: profiles/r03/valu_microbench2.txt), not the 39 T lane-ops/s of SURVEY 8d; '
-                'wave-instructions = cells x 21.5 (ISA count per cell and lane) / 64; the lane slots the systolic ramps and padding rows leave empty are not counted (profiles/r03: 0.87 of the slots hold a cell)',
+    cand = {
+        'sketch_fast_kernel + sketch_fill_kernel': (('k_sketch_count_ns', 'k_sketch_fill_ns'), ('sub', 2), 2 * st['bases'] + 16 * st['minimizers'], 0),
+        'seed_lookup_kernel': (('k_seed_lookup_ns',), ('sub', 1), 28 * st['minimizers'], 0),
+        'seed_filter_kernel': (('k_seed_filter_ns',), ('sub', 1), 16 * st['anchors'] + st['anchors'] / 8, 0),
+        'seed_emit_kernel': (('k_seed_fill_ns',), ('sub', 1), 24 * st['anchors_emitted'], 0),
+        'anchor_msd_kernel': (('k_sort_msd_ns',), ('sub', 1), 40 * st['anchors_emitted'], 0),
+        'anchor_window_sort_kernel': (('k_sort_chunk_ns',), ('sub', 1), 32 * st['anchors_emitted'], 0),
+        'anchor_compact_kernel<count|write>': (('k_compact_ns',), ('sub', 2), 32 * st['anchors_emitted'] + 16 * st['anchors_kept'], 0),
+        'chain_dp_kernel': (('k_chain_dp_ns',), ('sub', 1), 32 * st['anchors_kept'], 0),
+        # (one launch per round: 16-, 32- and 64-lane groups are segments of its grid)
+        'ext_dp_strip_kernel<false> (gap fills)': (('k_strip16_ns', 'k_strip32_ns', 'k_strip64_ns'), ('round', 1), strip_cells, strip_cells),
+        'ext_dp_strip_kernel<true> (end extensions, exact fills)': (('k_xstrip_ns',), ('round', 1), st['xstrip_cells'], st['xstrip_cells']),
+        'aln_finish_wave_kernel': (('k_finish_ns',), ('round', 4), 8 * st['cigar_ops'] + 2 * st['bases'], 0),
     }
+    VALU_PEAK = 1024 * 2.4e9 / 2.0    # MI355X_MICROARCH.md: 1024 SIMDs, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
+    wi_per_cell = STRIP_INSTR_PER_CELL / 64.0
+    rows = {}
+    n_launch = lambda unit, stats: unit[1] * max(stats['sub_batches'] if unit[0] == 'sub' else stats['dp_rounds'], 1)
+    for name, (keys, unit, abytes, cells) in cand.items():
+        launches = n_launch(unit, st)
+        ns_pipe = sum(st[k] for k in keys)
+        row = {'launches_per_step': round(launches, 1), 'alg_GB_per_step': round(abytes / 1e9, 3),
+               'in_pipeline_ms': round(ns_pipe / 1e6 / max(launches, 1), 3), 'in_pipeline_ms_per_step': round(ns_pipe / 1e6, 2)}
+        if alone is not None:
+            # the single-worker pass ran a fraction of a step: scale by the work unit the kernel's time follows (read bases)
+            ns_alone = sum(alone[k] for k in keys)
+            launches_a = n_launch(unit, alone)
+            row['alone_ms'] = round(ns_alone / 1e6 / max(launches_a, 1), 3)
+            row['alone_ms_per_step'] = round(ns_alone / 1e6 * st['bases'] / max(alone['bases'], 1), 2)
+        rows[name] = row
+    # the dominant kernel: largest EXCLUSIVE device time per step (alone), else largest in-pipeline span
+    keyf = (lambda k: rows[k].get('alone_ms_per_step', 0.0)) if alone is not None else (lambda k: rows[k]['in_pipeline_ms_per_step'])
+    dom = max(rows, key=keyf)
+    keys, unit, abytes, cells = cand[dom]
+    launches = n_launch(unit, st)
+    ns = sum(st[k] for k in keys)
+    achieved = abytes / max(ns, 1)  # bytes per ns == GB/s, from the HIP-event spans of the timed region (the contract's figure)
+    traffic, traffic_src = pmc_traffic(dom, launches, args.config)
+    hits_per_mz = st['anchors'] / max(st['minimizers'], 1)
+    roof = {
+        'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
+        'launches_per_step': round(launches, 1), 'launch_ms_avg': round(ns / 1e6 / max(launches, 1), 3),
+        'algorithmic_bytes_per_launch': int(abytes / max(launches, 1)),
+        'chosen_by': 'largest exclusive device time per step (single-worker pass)' if alone is not None else 'largest in-pipeline HIP-event span (no single-worker pass)',
+    }
+    if alone is not None:
+        roof['alone_ms'] = rows[dom]['alone_ms']
+        roof['frac_alone'] = round(abytes / max(launches, 1) / max(rows[dom]['alone_ms'] * 1e6, 1) / HBM_PEAK_GBS, 5)
+    if cells:
+        wi_launch = cells * wi_per_cell / max(launches, 1)
+        roof['valu'] = {
+            'cells_per_step': int(cells), 'wave_instr_per_cell': round(wi_per_cell, 4), 'wave_instr_per_launch': int(wi_launch),
+            'peak_wave_instr_per_s': VALU_PEAK,
+            'achieved_wave_instr_per_s': round(wi_launch / max(ns / max(launches, 1), 1) * 1e9, 0),
+            'frac': round(wi_launch / max(ns / max(launches, 1), 1) * 1e9 / VALU_PEAK, 4),
+            'frac_alone': round(wi_launch / max(rows[dom]['alone_ms'] * 1e6, 1) * 1e9 / VALU_PEAK, 4) if alone is not None else None,
+            'mix_ceiling_wave_instr_per_s': VALU_CEIL_WAVE_INSTR,
+            'gcups_whole_step': round(st['dp_cells'] / (dt / K * 1e9), 2),
+            'note': 'the DP kernels are bound by VALU issue, not by HBM. wave-instructions = cells x 21.5 (ISA count of the loop body per cell and lane) / 64: '
+                    'the ALGORITHMIC count -- ramps of the systolic array, padding rows and per-step overhead are not in it (PMC: 25.7 per cell). peak = 1024 SIMDs x '
+                    '2.4 GHz / 2 cycles (the guide); mix_ceiling = what the cell\'s own instruction mix can issue (profiles/r03/valu_microbench2.txt: 9.5 instructions '
+                    'at 2.7 cycles + 12 packed / three-operand ones at 4.4 per cell).',
+        }
+    roof['note'] = ('in_pipeline_ms / frac: HIP-event span per launch on its own stream over the timed region, while the other pipeline workers share the GPU '
+                    '(the rocprofv3 average of the same command, profiles/, is the figure to compare). alone_ms / frac_alone: the same launch with nothing else on '
+                    'the GPU (single-worker pass after the timed region). traffic: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from committed PMC passes of the '
+                    'same workload (separate rocprofv3 runs), null when none is committed for this --config.')
+    roof['candidates'] = rows
+    roof['whole_path_alg_bytes_per_bp'] = round(9.73 + 13.1 * hits_per_mz + 1.75 * st['alignments'] / max(args.reads_per_step, 1), 2)
+    n_parts = len(idx) if isinstance(idx, (list, tuple)) else 1
     line = {
         'metric': 'Gbp/min ONT reads aligned+species-assigned vs RefSeq, 1/2/4/8 MI355X',
         'value': bases / dt * 60 / 1e9,
@@ -647,32 +763,21 @@ def main():
         'config': {
             'workload': W['workload'] + f' (index built on the GPU in {index_s:.1f} s)', 'name': args.config,
             'reads_per_step_per_gpu': args.reads_per_step, 'index_genomes': W['n_index_genomes'], 'index_bp': W['index_bp'],
-            'index_build_s': round(index_s, 2), 'mid_occ': int(opt.mid_occ),
+            'index_parts': n_parts, 'part_build_s': W.get('part_build_s'),
+            'index_build_s': round(index_s, 2), 'mid_occ': [int(i.mid_occ()) for i in idx] if isinstance(idx, (list, tuple)) else int(opt.mid_occ),
             'index_minimizers': int(sum(i.n_minimizers for i in (idx if isinstance(idx, (list, tuple)) else [idx]))),
+            'hits_per_read_minimizer_per_part': round(hits_per_mz, 2),                                     # h of SURVEY 8d (per part mapped)
+            'alignments_per_read': round(st['alignments'] / max(args.reads_per_step, 1) / 1.0, 3),         # c (after the merge over parts)
             'parallelism': f'reads sharded over {world} GPU(s), index replicated', 'host_cpus': os.cpu_count(), 'cpu_quota': cpu_quota(),
             'ranks_on_node': int(os.environ.get('MPN_RANKS_ON_NODE', '1')),
         },
-        'value_inputs': 'reads resident in HBM when the timed region starts',
-        'pcie_inclusive_gbp_per_min': None if pcie is None else round(pcie, 2),
-        'pcie_steps': args.pcie_steps,
+        'value_inputs': 'reads in HOST buffers when the timed region starts: the read H2D is inside the timed calls (SURVEY 8d); index resident in HBM',
+        'resident_input_gbp_per_min': None if resident is None else round(resident, 2),
+        'resident_steps': args.resident_steps,
         'host_cpu_s_per_step': round(host_cpu_s / K, 3),           # rank 0's process CPU time per step
         'host_cpu_s_per_step_max_rank': round(host_cpu_max / K, 3),
         'host_cpu_s_per_gbp': round(host_cpu_s / max(bases / world, 1) * 1e9, 3),
-        'roofline': {
-            'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
-            'launches_per_step': round(launches, 1), 'launch_ms_avg': round(ns / 1e6 / launches, 3),
-            'algorithmic_bytes_per_launch': int(abytes / launches),
-            'note': 'dominant kernel = largest device time of this run among the candidates below; durations are HIP-event spans around each '
-                    'launch on its own stream while the other pipeline workers share the GPU. The strip DP is bound by VALU issue, not by '
-                    'HBM: see "valu" for it in that unit. traffic: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed PMC '
-                    'passes of the same workload (separate rocprofv3 runs), not measured inside this process.',
-            'candidates': {k: {'ms_per_step': round(v[0] / 1e6, 2), 'launches_per_step': round(v[1], 1), 'alg_GB_per_step': round(v[2] / 1e9, 3),
-                               'GBps': round(v[2] / max(v[0], 1), 1)} for k, v in cand.items()},
-            'strip_instantiations': strip_inst,
-            'whole_path_alg_bytes_per_bp': round(9.73 + 13.1 * hits_per_mz + 1.75 * st['alignments'] / max(args.reads_per_step, 1), 2),
-            'valu': valu,
-        },
+        'roofline': roof,
         'per_step': {k: (round(v / 1e6, 2) if k.endswith('_ns') else int(v)) for k, v in st.items()},
         'reads_per_name_top': sorted(((int(c), int(i)) for i, c in enumerate(counts) if c), reverse=True)[:5],
     }

@@ -683,6 +683,23 @@ struct Slot {
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
     PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
     std::vector<std::vector<SqueezeSeg>> seg_stage;   // per pool thread: the squeeze segments of the reads it handled
+    size_t device_bytes() const {
+        size_t h = 0;
+        for (const PoolBuf *pb : {&pool_jobs, &pool_P, &pool_P2, &pool_OFF, &pool_order, &pool_state, &pool_CIG, &pool_res, &pool_redo, &pool_compact, &pool_used,
+                                  &pool_redo_ids, &pool_sregs, &pool_souts, &pool_fin_jobs, &pool_fin_out, &pool_fin_cig, &pool_probes, &pool_sizes, &pool_buckets,
+                                  &pool_pregs, &pool_psum, &pool_job_anchor, &pool_splits})
+            h += pb->cap;
+        for (const auto &c : arena.chunks) h += c.cap;
+        return h;
+    }
+    // the slot's device memory goes back to the device (a worker that sheds, or a slot that idles in this call)
+    void release_device() {
+        arena.release_all();
+        for (PoolBuf *pb : {&pool_jobs, &pool_P, &pool_P2, &pool_OFF, &pool_order, &pool_state, &pool_CIG, &pool_res, &pool_redo, &pool_compact, &pool_used,
+                            &pool_redo_ids, &pool_sregs, &pool_souts, &pool_fin_jobs, &pool_fin_out, &pool_fin_cig, &pool_probes, &pool_sizes, &pool_buckets,
+                            &pool_pregs, &pool_psum, &pool_job_anchor, &pool_splits})
+            pb->release();
+    }
 };
 static Slot g_slots[16];
 static thread_local Slot *tl_slot = &g_slots[0];
@@ -1619,8 +1636,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         size_t free_b = 0, total_b = 0, held = 0, held_max = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             for (const Slot &S : g_slots) {
-                size_t h = S.pool_P.cap + S.pool_P2.cap + S.pool_CIG.cap + S.pool_compact.cap + S.pool_jobs.cap + S.pool_res.cap;
-                for (const auto &c : S.arena.chunks) h += c.cap;
+                const size_t h = S.device_bytes();
                 held += h;
                 held_max = std::max(held_max, h);
             }
@@ -1631,6 +1647,10 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
             n_workers = std::min(n_workers, fit);
         }
     }
+    // slots that idle in this call give their scratch back: the running workers may need it (a call with fewer workers than the
+    // last one -- less free memory since another index part became resident, or MPN_PIPE_WORKERS lowered)
+    for (int wdx = n_workers; wdx < 16; ++wdx)
+        if (g_slots[wdx].device_bytes()) { MPN_HIP_CHECK(hipDeviceSynchronize()); g_slots[wdx].release_device(); }
     int dev = 0;
     MPN_HIP_CHECK(hipGetDevice(&dev));
     rs.assign((size_t)n, ReadState());
@@ -1638,7 +1658,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     std::atomic<int> next(0), failed(0);
     std::mutex mu;
     std::deque<int> retry;          // sub-batches given back by a worker that ran out of device memory (guarded by mu)
-    int live_workers = n_workers, live_workers_busy = 0;   // (guarded by mu)
+    int live_workers = n_workers, live_workers_busy = 0, n_shed = 0;   // (guarded by mu)
     int64_t tot_stats[MPN_NSTATS] = {0};
     std::string err;
     const bool dbg_workers = getenv("MPN_DEBUG_WORKERS") != nullptr;
@@ -1674,6 +1694,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
             { std::lock_guard<std::mutex> g(mu); ++live_workers_busy; }
             struct Busy { std::mutex &m; int &c; ~Busy() { std::lock_guard<std::mutex> g(m); --c; } } busy_{mu, live_workers_busy};
             S.arena.reset();
+            tl_oom = false;
             int64_t stats_before[MPN_NSTATS];
             memcpy(stats_before, g_stats, sizeof(stats_before));
             const double t_in = since();
@@ -1683,17 +1704,13 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
                 // Out of device memory: the workers' scratch grows with what the target set throws at them (a strain-rich index
                 // yields tens of times the anchors of a random one), and the up-front estimate can be too low.  This worker gives
                 // its memory back and leaves; its sub-batch goes to the others.  The last worker standing reports the failure.
-                if (strstr(get_error(), "out of memory") && live_workers > 1) {
+                if (tl_oom && live_workers > 1) {   // (the flag of this thread's failed device allocation, not the error text)
                     --live_workers;
+                    ++n_shed;
                     memcpy(g_stats, stats_before, sizeof(stats_before));
                     (void)hipGetLastError();
                     (void)hipStreamSynchronize(S.st);
-                    for (auto &c : S.arena.chunks) (void)hipFree(c.p);
-                    S.arena.chunks.clear(); S.arena.cur = S.arena.off = S.arena.used = 0;
-                    for (PoolBuf *pb : {&S.pool_jobs, &S.pool_P, &S.pool_P2, &S.pool_OFF, &S.pool_order, &S.pool_state, &S.pool_CIG, &S.pool_res, &S.pool_redo,
-                                        &S.pool_compact, &S.pool_redo_ids, &S.pool_sregs, &S.pool_souts, &S.pool_fin_jobs, &S.pool_fin_out, &S.pool_fin_cig,
-                                        &S.pool_sizes, &S.pool_pregs, &S.pool_psum, &S.pool_job_anchor, &S.pool_splits, &S.pin_segs})
-                        pb->release();
+                    S.release_device();
                     retry.push_back(sb);
                     if (dbg_workers) fprintf(stderr, "[worker %d] out of device memory at sub-batch %d: leaving, %d workers go on\n", wid, sb, live_workers);
                     break;
@@ -1745,6 +1762,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         memcpy(g_stats, tot_stats, sizeof(tot_stats));
         g_stats[16] = h2d;
         g_stats[0] = bases;
+        g_stats[60] = n_shed; g_stats[61] = n_workers;
     }
     return 0;
 }

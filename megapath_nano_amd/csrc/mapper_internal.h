@@ -127,8 +127,14 @@ struct PoolBuf {
         if (bytes <= cap) return 0;
         if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 4096;
-        if (pinned_host) MPN_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
-        else MPN_HIP_CHECK(hipMalloc(&p, want));
+        const hipError_t e_ = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e_ != hipSuccess) {
+            if (e_ == hipErrorOutOfMemory && !pinned_host) tl_oom = true;
+            p = nullptr;
+            set_error("%s of %zu bytes failed: %s", pinned_host ? "hipHostMalloc" : "hipMalloc", want, hipGetErrorString(e_));
+            (void)hipGetLastError();
+            return -1;
+        }
         cap = want;
         return 0;
     }

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 namespace mpn {
@@ -24,6 +25,14 @@ void set_error(const char *fmt, ...);
 // hipMalloc/hipFree per batch cost more than the kernels they serve (and hipFree synchronises the device, which would
 // serialise the pipelined workers).  A worker thread points tl_arena at its slot's arena; every DevBuf it creates then
 // bump-allocates from chunks that persist across calls.  reset() rewinds; nothing is freed until process exit.
+// Set by the calling thread's failed device allocation (arena, pool or plain buffer) when the device is out of memory: the
+// pipelined mapper sheds a worker on it (align.hip) instead of failing the call.  A distinct flag, not a match on error text.
+extern thread_local bool tl_oom;
+// test hook: MPN_TEST_ARENA_BUDGET=<bytes> makes the arenas of all workers share that budget; an arena that would grow past it
+// fails like a device that is out of memory (tests/test_map_e2e_gpu.py sheds workers with it)
+extern std::atomic<long long> g_arena_bytes;
+long long arena_test_budget();
+
 struct Arena {
     struct Chunk { void *p; size_t cap; };
     std::vector<Chunk> chunks;
@@ -37,12 +46,20 @@ struct Arena {
             size_t total = 0;
             for (const Chunk &c : chunks) { total += c.cap; (void)hipFree(c.p); }
             chunks.clear();
+            g_arena_bytes -= (long long)total;
             const size_t want = std::max(used + used / 4, total / 2) + ((size_t)64 << 20);
             Chunk c{nullptr, want};
-            if (hipMalloc(&c.p, c.cap) == hipSuccess) chunks.push_back(c);
+            const long long budget = arena_test_budget();
+            if ((budget <= 0 || g_arena_bytes + (long long)want <= budget) && hipMalloc(&c.p, c.cap) == hipSuccess) { chunks.push_back(c); g_arena_bytes += (long long)want; }
             else (void)hipGetLastError();  // take() will report the failure if the memory is really gone
         }
         cur = 0; off = 0; used = 0;
+    }
+    // give everything back (a worker that leaves, or a slot that idles while the others need the memory)
+    void release_all() {
+        for (const Chunk &c : chunks) { (void)hipFree(c.p); g_arena_bytes -= (long long)c.cap; }
+        chunks.clear();
+        cur = off = used = 0;
     }
     void *take(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
@@ -51,7 +68,15 @@ struct Arena {
             if (off + bytes <= chunks[cur].cap) { void *r = (char *)chunks[cur].p + off; off += bytes; return r; }
         Chunk c;
         c.cap = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
-        if (hipMalloc(&c.p, c.cap) != hipSuccess) { mpn::set_error("arena: hipMalloc of %zu bytes failed", c.cap); return nullptr; }
+        const long long budget = arena_test_budget();
+        if (budget > 0) c.cap = bytes > ((size_t)16 << 20) ? bytes : ((size_t)16 << 20);   // (small chunks, so that a small budget binds)
+        if ((budget > 0 && g_arena_bytes + (long long)c.cap > budget) || hipMalloc(&c.p, c.cap) != hipSuccess) {
+            (void)hipGetLastError();
+            tl_oom = true;
+            mpn::set_error("arena: out of memory (hipMalloc of %zu bytes failed)", c.cap);
+            return nullptr;
+        }
+        g_arena_bytes += (long long)c.cap;
         chunks.push_back(c);
         cur = chunks.size() - 1;
         off = bytes;
@@ -80,7 +105,14 @@ struct DevBuf {
             owned = false;
             return p ? 0 : -1;
         }
-        MPN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        const hipError_t e_ = hipMalloc((void **)&p, count * sizeof(T));
+        if (e_ != hipSuccess) {
+            if (e_ == hipErrorOutOfMemory) tl_oom = true;
+            p = nullptr;
+            mpn::set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e_));
+            (void)hipGetLastError();
+            return -1;
+        }
         return 0;
     }
     int zero(hipStream_t st) {

@@ -15,6 +15,12 @@ void set_error(const char *fmt, ...) {
 }
 const char *get_error() { return g_err.c_str(); }
 thread_local Arena *tl_arena = nullptr;
+thread_local bool tl_oom = false;
+std::atomic<long long> g_arena_bytes{0};
+long long arena_test_budget() {
+    static const long long b = []() { const char *e = getenv("MPN_TEST_ARENA_BUDGET"); return e ? atoll(e) : 0LL; }();
+    return b;
+}
 }  // namespace mpn
 
 // The pipelined mapper keeps 12 workers x 2 HIP streams in flight.  ROCm multiplexes streams onto GPU_MAX_HW_QUEUES

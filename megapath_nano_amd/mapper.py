@@ -507,7 +507,7 @@ STAT_NAMES = {0: 'bases', 1: 'minimizers', 2: 'anchors', 3: 'chains', 4: 'dp_job
               33: 'k_sketch_count_ns', 34: 'k_sketch_fill_ns', 35: 'k_seed_lookup_ns', 36: 'k_seed_fill_ns',
               37: 'k_chain_dp_ns', 38: 'k_strip16_ns', 39: 'k_strip32_ns', 40: 'k_strip64_ns', 41: 'strip16_cells',
               42: 'strip32_cells', 43: 'strip64_cells', 44: 'sort_records_moved', 45: 'anchors_kept', 46: 'k_compact_ns', 47: 'k_sort_msd_ns', 48: 'k_sort_chunk_ns', 49: 'k_sort_radix_ns',
-              50: 'k_seed_filter_ns', 51: 'anchors_emitted', 52: 'k_finish_ns', 53: 'cigar_ops', 54: 'k_stitch_ns', 55: 'k_plan_ns', 56: 'k_layout_ns', 57: 'k_xstrip_ns', 58: 'xstrip_cells', 59: 'anchors_squeezed'}
+              50: 'k_seed_filter_ns', 51: 'anchors_emitted', 52: 'k_finish_ns', 53: 'cigar_ops', 54: 'k_stitch_ns', 55: 'k_plan_ns', 56: 'k_layout_ns', 57: 'k_xstrip_ns', 58: 'xstrip_cells', 59: 'anchors_squeezed', 60: 'workers_shed', 61: 'workers'}
 
 
 def last_stats():

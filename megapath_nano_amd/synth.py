@@ -51,15 +51,27 @@ def make_genomes(seed, n_genomes, length, strain_pairs=1, repeats=True):
     return out
 
 
-def ont_errors(rng, seq, sub=0.04, ins=0.03, dele=0.05):
-    """Per-base independent errors (vectorised): deletion drops the base, insertion adds random bases after it."""
+HP_IN, HP_OUT = 1.75, 0.75   # indel rate inside / outside a homopolymer context (a base equal to its predecessor: a quarter of
+                             # the positions of random sequence, so the mean rates stay sub / ins / dele)
+
+
+def ont_errors(rng, seq, sub=0.04, ins=0.03, dele=0.05, hp_bias=True):
+    """ONT-like errors (vectorised), SURVEY 8d: substitutions are independent per base; deletions and insertions are
+    homopolymer-biased -- a base that repeats its predecessor is deleted or followed by an insertion HP_IN / HP_OUT times as often
+    as another one, and what is inserted after it is a further copy of it (a homopolymer read too long); elsewhere inserted
+    bases are random.  Deletion drops the base, insertion adds a geometric number of bases after it."""
     n = len(seq)
+    hp = np.zeros(n, dtype=bool)
+    if hp_bias and n > 1:
+        hp[1:] = seq[1:] == seq[:-1]
+    scale = np.where(hp, HP_IN, HP_OUT) if hp_bias else 1.0
+    d_eff, i_eff = dele * scale, ins * scale
     r = rng.random(n)
-    keep = r >= dele
-    subm = (r >= dele) & (r < dele + sub)
+    keep = r >= d_eff
+    subm = keep & (r < d_eff + sub)
     s = seq.copy()
     s[subm] = ALPHA[(np.searchsorted(ALPHA, s[subm]) + rng.integers(1, 4, size=int(subm.sum()))) % 4]
-    n_ins = np.where(rng.random(n) < ins, rng.geometric(0.6, size=n), 0)
+    n_ins = np.where(rng.random(n) < i_eff, rng.geometric(0.6, size=n), 0)
     n_ins[~keep] = 0
     counts = keep.astype(np.int64) + n_ins
     out = np.repeat(s, counts)
@@ -67,7 +79,7 @@ def ont_errors(rng, seq, sub=0.04, ins=0.03, dele=0.05):
     starts = np.cumsum(counts) - counts
     first = np.zeros(len(out), dtype=bool)
     first[starts[counts > 0]] = True
-    ins_mask = ~first
+    ins_mask = ~first & ~np.repeat(hp, counts)   # (insertions in a homopolymer context stay copies of the base)
     out[ins_mask] = ALPHA[rng.integers(0, 4, size=int(ins_mask.sum()))]
     return out
 
@@ -151,6 +163,54 @@ def make_genomes_device(seed, n_genomes, length, strain_pairs, device, repeats=T
                 view[n_base + f * copies + c] = torch.where(mut, alpha[(cur + shift) % 4], base)
                 names.append(f'NZ_FAM{f:02d}_{c:03d}.1')
     return names, out, np.full(n_genomes, length, dtype=np.int32)
+
+
+def make_refseq_part_device(seed, part, n_parts, n_genomes_part, length, base, copies, id_lo, id_hi, device, chunk=64):
+    """One part of a strain-RICH target set that is generated and indexed part by part (the whole set need not fit beside the
+    resident index parts): `n_genomes_part` genomes of `length` bp = [the community's base genomes `base` (part 0 only)] +
+    [random genomes] + [the assemblies c = part, part + n_parts, ... < copies of every base genome, each mutated on its own at
+    an identity drawn uniformly from [id_lo, id_hi]] -- the hundreds of near-identical assemblies RefSeq holds of a common
+    species are spread over the parts of a `-I`-split index like this.
+    -> (names, uint8 tensor of the concatenated ASCII, int32 lens, family) with family[i] = the base genome an assembly was
+    copied from (the base genomes themselves included), -1 for the random genomes."""
+    import torch
+    n_fam = base.shape[0]
+    mine = [c for c in range(copies) if c % n_parts == part]
+    n_base = n_fam if part == 0 else 0
+    n_rand = n_genomes_part - n_base - n_fam * len(mine)
+    assert n_rand >= 0
+    rn, rflat, _ = make_genomes_device(int(seed) * 1000 + part, n_rand, length, 0, device, chunk=chunk) if n_rand else ([], None, None)
+    out = torch.empty(n_genomes_part * length, dtype=torch.uint8, device=device)
+    view = out.view(n_genomes_part, length)
+    names, family = [], []
+    k = 0
+    if n_base:
+        view[:n_fam] = base
+        names += [f'NZ_COM{f:02d}.1' for f in range(n_fam)]
+        family += list(range(n_fam))
+        k = n_fam
+    if n_rand:
+        view[k:k + n_rand] = rflat.view(n_rand, length)
+        names += [f'NZ_P{part:02d}R{i:05d}.1' for i in range(n_rand)]
+        family += [-1] * n_rand
+        k += n_rand
+        del rflat
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed) * 7919 + 31 * part + 5)
+    alpha = torch.tensor(list(b'ACGT'), dtype=torch.uint8, device=device)
+    for f in range(n_fam):
+        b = base[f]
+        cur = (b == alpha[1]).long() + 2 * (b == alpha[2]).long() + 3 * (b == alpha[3]).long()
+        for c in mine:
+            ident = id_lo + (id_hi - id_lo) * float(torch.rand(1, generator=gen, device=device))
+            mut = torch.rand(length, generator=gen, device=device) < (1.0 - ident)
+            shift = torch.randint(1, 4, (length,), generator=gen, device=device)
+            view[k] = torch.where(mut, alpha[(cur + shift) % 4], b)
+            names.append(f'NZ_FAM{f:02d}_{c:03d}.1')
+            family.append(f)
+            k += 1
+    assert k == n_genomes_part
+    return names, out, np.full(n_genomes_part, length, dtype=np.int32), np.array(family, dtype=np.int64)
 
 
 def make_humanlike_device(seed, n_chrom, chrom_len, device, repeat_frac=0.45, n_decoys=8):
@@ -239,20 +299,28 @@ def _reads_from_spans(gen, genomes_flat, g0_all, L, n_reads, device, truth_t, su
         frag = genomes_flat[src]
         frag = torch.where(rv, comp[frag.long()], frag)
         del src, p
+        # homopolymer-biased indels (see ont_errors): a base that repeats its predecessor is deleted / followed by an insertion
+        # HP_IN / HP_OUT times as often as another one, and what is inserted after it is a further copy of it
+        hp = torch.zeros(T, dtype=torch.bool, device=device)
+        if T > 1:
+            hp[1:] = frag[1:] == frag[:-1]
+        scale = torch.where(hp, HP_IN, HP_OUT)
         r = torch.rand(T, generator=gen, device=device)
-        keep = r >= dele
-        subm = keep & (r < dele + sub)
+        keep = r >= dele * scale
+        subm = keep & (r < dele * scale + sub)
         n_sub = int(subm.sum())
         frag[subm] = alpha[(code_of[frag[subm].long()] + torch.randint(1, 4, (n_sub,), generator=gen, device=device)) % 4]
-        n_ins = torch.where(torch.rand(T, generator=gen, device=device) < ins,
+        n_ins = torch.where(torch.rand(T, generator=gen, device=device) < ins * scale,
                             torch.empty(T, device=device).geometric_(0.6, generator=gen).long(), torch.zeros((), dtype=torch.long, device=device))
         counts = keep.long() + torch.where(keep, n_ins, torch.zeros((), dtype=torch.long, device=device))
         out = torch.repeat_interleave(frag, counts)
         cstart = torch.cumsum(counts, 0) - counts
         first = torch.zeros(out.numel(), dtype=torch.bool, device=device)
         first[cstart[counts > 0]] = True
-        n_insd = int((~first).sum())
-        out[~first] = alpha[torch.randint(0, 4, (n_insd,), generator=gen, device=device)]
+        rnd_ins = ~first & ~torch.repeat_interleave(hp, counts)
+        n_insd = int(rnd_ins.sum())
+        out[rnd_ins] = alpha[torch.randint(0, 4, (n_insd,), generator=gen, device=device)]
+        del hp, scale, rnd_ins
         csum = torch.cumsum(counts, 0)
         tot_at_end = csum[off + Lc - 1]
         new_len = tot_at_end - torch.cat([torch.zeros(1, dtype=torch.long, device=device), tot_at_end[:-1]])
@@ -305,20 +373,28 @@ def make_reads_device(seed, genomes_flat, genome_len, n_reads, weights, device, 
         frag = genomes_flat[src]
         frag = torch.where(rv, comp[frag.long()], frag)
         del src, p
+        # homopolymer-biased indels (see ont_errors): a base that repeats its predecessor is deleted / followed by an insertion
+        # HP_IN / HP_OUT times as often as another one, and what is inserted after it is a further copy of it
+        hp = torch.zeros(T, dtype=torch.bool, device=device)
+        if T > 1:
+            hp[1:] = frag[1:] == frag[:-1]
+        scale = torch.where(hp, HP_IN, HP_OUT)
         r = torch.rand(T, generator=gen, device=device)
-        keep = r >= dele
-        subm = keep & (r < dele + sub)
+        keep = r >= dele * scale
+        subm = keep & (r < dele * scale + sub)
         n_sub = int(subm.sum())
         frag[subm] = alpha[(code_of[frag[subm].long()] + torch.randint(1, 4, (n_sub,), generator=gen, device=device)) % 4]
-        n_ins = torch.where(torch.rand(T, generator=gen, device=device) < ins,
+        n_ins = torch.where(torch.rand(T, generator=gen, device=device) < ins * scale,
                             torch.empty(T, device=device).geometric_(0.6, generator=gen).long(), torch.zeros((), dtype=torch.long, device=device))
         counts = keep.long() + torch.where(keep, n_ins, torch.zeros((), dtype=torch.long, device=device))
         out = torch.repeat_interleave(frag, counts)
         cstart = torch.cumsum(counts, 0) - counts
         first = torch.zeros(out.numel(), dtype=torch.bool, device=device)
         first[cstart[counts > 0]] = True
-        n_insd = int((~first).sum())
-        out[~first] = alpha[torch.randint(0, 4, (n_insd,), generator=gen, device=device)]
+        rnd_ins = ~first & ~torch.repeat_interleave(hp, counts)
+        n_insd = int(rnd_ins.sum())
+        out[rnd_ins] = alpha[torch.randint(0, 4, (n_insd,), generator=gen, device=device)]
+        del hp, scale, rnd_ins
         # new length of every read: sum of its counts
         csum = torch.cumsum(counts, 0)
         ends = off + Lc - 1

@@ -255,8 +255,8 @@ def test_split_index_parts_merge_matches_oracle(world, tmp_path):
             for a, b in zip(one, want):
                 if a and b:
                     fa, fb = a.splitlines()[0].split('\t'), b.splitlines()[0].split('\t')
-                    if fa[14] != fb[14]:
-                        continue  # (equal-score hits on the strain pair may swap)
+                    if fa[14] != fb[14] or fa[11] == '0' or fb[11] == '0':
+                        continue  # (equal-score hits on the strain pair, or on two copies of a planted repeat, may swap)
                     assert fa[:11] == fb[:11] and fa[-1] == fb[-1], (fa[0],)
                     same += 1
             assert same >= len(reads) // 2
@@ -470,3 +470,37 @@ print('OK')
     env = dict(os.environ, MPN_DP_BUDGET=str(2 << 20))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
+
+
+_SHED_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+from map_cases import small_world
+from megapath_nano_amd import mapper
+gen, reads = small_world(seed=3, n_genomes=6, glen=150000, n_reads=60, mean_len=4000)
+idx = mapper.Index(gen)
+opt = mapper.default_opt(best_n=50, pri_ratio=1.0)
+names = [r['name'] for r in reads]
+paf = mapper.map_batch(idx, opt, names, [r['seq'] for r in reads])
+st = mapper.last_stats()
+print(json.dumps(dict(paf=paf, shed=st['workers_shed'], workers=st['workers'], sub_batches=st['sub_batches'])))
+'''
+
+
+def test_worker_sheds_on_arena_oom(world):
+    """A worker whose device ARENA cannot grow (MPN_TEST_ARENA_BUDGET: all arenas share a budget that only some of the workers fit
+    in) gives its scratch back and leaves; its sub-batch goes to the others and the output is what the unconstrained run gives.
+    The decision rests on the allocation's out-of-memory flag, not on the error text (ADVICE r3)."""
+    import json
+    from megapath_nano_amd import mapper
+    gen, reads, gidx, oidx = world
+    gopt = mapper.default_opt(best_n=50, pri_ratio=1.0)
+    names = [r['name'] for r in reads]
+    want = mapper.map_batch(gidx, gopt, names, [r['seq'] for r in reads])
+    env = dict(os.environ, MPN_PIPE_WORKERS='4', MPN_SUB_BATCH_BP='15000', MPN_TEST_ARENA_BUDGET=str(40 << 20))
+    out = subprocess.run([sys.executable, '-c', _SHED_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got['sub_batches'] >= 8 and got['workers'] == 4
+    assert got['shed'] >= 1, got['shed']
+    assert got['paf'] == want
