@@ -74,6 +74,11 @@ int mpn_index_save(const mpn_index *idx, const char *path);
 /* "@SQ" lines of the targets + one "@PG" line (cmdline may be NULL); returns the text length, or -3 if cap is too small */
 int64_t mpn_sam_header(const mpn_index *idx, const char *cmdline, char *buf, int64_t cap);
 mpn_index *mpn_index_load(const char *path);
+/* A target set of several index parts (minimap2 -I) in ONE file, as minimap2 -d dumps it (bin/megapath_nano.py:1641-1645):
+ * save_append adds a part behind what the file holds; load_at reads the part that starts at byte `offset` and leaves in
+ * *next_offset where the next one starts, or -1 after the last (next_offset may be NULL). */
+int mpn_index_save_append(const mpn_index *idx, const char *path);
+mpn_index *mpn_index_load_at(const char *path, int64_t offset, int64_t *next_offset);
 /* names and lengths of the targets of an index (for a loaded one): name i is copied into buf (cap bytes incl. NUL) */
 int32_t mpn_index_n_seq(const mpn_index *idx);
 int32_t mpn_index_seq_len(const mpn_index *idx, int32_t i);

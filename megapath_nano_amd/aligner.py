@@ -258,22 +258,36 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
             results.append(MappedBatch(b, text, sam, cols, names, lens))
 
     if _is_saved_index(target_paths):
+        # a saved index may hold several parts (minimap2 -d dumps every part of a -I split into the one file): they are loaded
+        # one at a time, like the parts of a FASTA target
         idx = _INDEX_CACHE.get(cache_key) if cache_key else None
-        if idx is None:
-            idx = mapper.Index.load(target_paths[0])
-            if cache_key:
-                _INDEX_CACHE[cache_key] = idx
-        if options.split:
-            hits = [mapper.Hits(b) for b in batches]
-            for h in hits:
-                h.add_part(idx, opt)
-            header = hits[0].sam_header() if (want_sam and hits) else (idx.sam_header() if want_sam else None)
+        parts = [idx] if idx is not None else mapper.Index.iter_parts(target_paths[0])
+        hits = [mapper.Hits(b) for b in batches] if options.split else None
+        n_parts, first_header = 0, None
+        for idx in parts:
+            n_parts += 1
+            if hits is not None:
+                for h in hits:
+                    h.add_part(idx, opt)
+            else:
+                single(idx)
+                first_header = first_header if first_header is not None else header
+            if cache_key and n_parts == 1:
+                _INDEX_CACHE[cache_key] = idx      # (kept only when it turns out to be the only part)
+                kept = idx
+            else:
+                if n_parts == 2 and cache_key:
+                    _INDEX_CACHE.pop(cache_key, None)
+                    kept.close()
+                idx.close()
+        if hits is not None:
+            header = hits[0].sam_header() if (want_sam and hits) else None
             results.header(header)
             _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
             for h in hits:
                 h.close()
         else:
-            single(idx)
+            header = first_header
         return results, header
 
     hits = [mapper.Hits(b) for b in batches] if options.split else None
@@ -299,12 +313,8 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
             del part
             n_parts += 1
             if save_index:
-                # minimap2 -d FILE dumps every part into the one file; the .mpi format holds one index, so a target set that
-                # needs several parts is refused loudly instead of being saved truncated
-                if n_parts > 1:
-                    raise ValueError(f'-d {save_index}: the target set needs more than one index part at -I {options.batch_bases}; '
-                                     'raise -I (the index is built on the GPU: one part holds ~36 Gbp)')
-                idx.save(save_index)
+                # minimap2 -d FILE dumps every part into the one file (bin/megapath_nano.py:1641-1645): so does this
+                idx.save(save_index, append=n_parts > 1)
             use(idx)
             prev = idx
         if prev is not None:

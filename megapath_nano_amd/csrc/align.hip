@@ -1232,8 +1232,7 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
         prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e;
         const RefView rvw{idx->d_seq2.p, idx->d_seq_off.p, idx->d_nrun_s.p, idx->d_nrun_e.p, idx->n_nruns};
         ev.skip();
-        static std::once_flag fin_attr;
-        std::call_once(fin_attr, [&]() { (void)hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[NC - 1]); });
+        MPN_HIP_CHECK(hipFuncSetAttribute((const void *)aln_finish_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds[NC - 1]));
         for (int c = 0; c < NC; ++c)
             if (!lists[c].empty())
                 hipLaunchKernelGGL(aln_finish_wave_kernel<true>, dim3((unsigned)std::min<size_t>(lists[c].size(), 256 * 64)), dim3(64), kLds[c], st, (const FinJob *)d_fj,

@@ -270,10 +270,8 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             static const int64_t round2 = []() { const char *e = getenv("MPN_FLT_ROUND2"); return e ? atoll(e) : INT64_MAX; }();
             fp.second_round = round2;
         }
-        static std::once_flag flt_attr;
-        std::call_once(flt_attr, [&]() {
-            (void)hipFuncSetAttribute((const void *)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLT_LDS_BYTES);
-        });
+        // (set on every call and checked: the call is a table update, and a failure must not be hidden behind a later "invalid value")
+        MPN_HIP_CHECK(hipFuncSetAttribute((const void *)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLT_LDS_BYTES));
         hipLaunchKernelGGL(seed_order_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)o.n_anchor.p, n, order.p);
         static const int flt_wgs = []() { const char *e = getenv("MPN_FLT_WGS"); return e ? std::max(1, atoi(e)) : 256; }();
         hipLaunchKernelGGL(seed_filter_kernel, dim3(std::max(1, std::min(n, flt_wgs))), dim3(FLT_THREADS), FLT_LDS_BYTES, st, mz.p, mz_off.p, n, occ.p,
@@ -324,10 +322,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
             lists.count = n_list.p;
         }
         const size_t msd_lds = (size_t)(MSD_NB + 32) * sizeof(uint32_t);
-        static std::once_flag lds_attr;
-        std::call_once(lds_attr, [&]() {
-            (void)hipFuncSetAttribute((const void *)anchor_msd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_lds);
-        });
+        MPN_HIP_CHECK(hipFuncSetAttribute((const void *)anchor_msd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_lds));
         const int gr = std::max(1, std::min(n, 256 * 4));
         hipLaunchKernelGGL(anchor_msd_kernel, dim3(gr), dim3(MSD_THREADS), msd_lds, st, (const u128 *)tmp.p, o.anchors.p, (const int64_t *)o.anchor_off.p, n, bp,
                            lists, o.used.p + 2);
@@ -716,7 +711,12 @@ static int fetch_keys(const mpn_index *idx, uint64_t *keys, int64_t *key_off, hi
 // then lens[n_seq] int32, names (u32 length + bytes each), N runs (start[], end[] int64), 2-bit words, keys, key_off, pos.
 static const char MPN_IDX_MAGIC[8] = {'M', 'P', 'N', 'I', 'D', 'X', '0', '1'};
 
-int mpn_index_save(const mpn_index *idx, const char *path) {
+static int index_save(const mpn_index *idx, const char *path, bool append);
+int mpn_index_save(const mpn_index *idx, const char *path) { return index_save(idx, path, false); }
+// minimap2 -d with a target set of several parts: every part is dumped into the one file, one after another
+int mpn_index_save_append(const mpn_index *idx, const char *path) { return index_save(idx, path, true); }
+
+static int index_save(const mpn_index *idx, const char *path, bool append) {
     if (!idx || !path) { set_error("mpn_index_save: null argument"); return -1; }
     hipStream_t st = 0;
     const int64_t total = idx->seq_off.empty() ? 0 : idx->seq_off.back();
@@ -728,7 +728,7 @@ int mpn_index_save(const mpn_index *idx, const char *path) {
         idx->d_seq2.download(words.data(), words.size(), st))
         return -1;
     MPN_HIP_CHECK(stream_sync(st));
-    FILE *f = fopen(path, "wb");
+    FILE *f = fopen(path, append ? "ab" : "wb");
     if (!f) { set_error("mpn_index_save: cannot open %s", path); return -1; }
     bool ok = true;
     auto put = [&](const void *p, size_t bytes) { if (bytes && fwrite(p, 1, bytes, f) != bytes) ok = false; };
@@ -747,10 +747,16 @@ int mpn_index_save(const mpn_index *idx, const char *path) {
     return 0;
 }
 
-mpn_index *mpn_index_load(const char *path) {
-    if (!path) { set_error("mpn_index_load: null path"); return nullptr; }
+mpn_index *mpn_index_load(const char *path) { return mpn_index_load_at(path, 0, nullptr); }
+
+// One part of a saved index: the part that starts at byte `offset` of the file; *next_offset = where the next part starts, or
+// -1 after the last one (a file written by mpn_index_save holds one part, one extended by mpn_index_save_append several).
+mpn_index *mpn_index_load_at(const char *path, int64_t offset, int64_t *next_offset) {
+    if (next_offset) *next_offset = -1;
+    if (!path || offset < 0) { set_error("mpn_index_load: null path or negative offset"); return nullptr; }
     FILE *f = fopen(path, "rb");
     if (!f) { set_error("mpn_index_load: cannot open %s", path); return nullptr; }
+    if (offset && fseeko(f, (off_t)offset, SEEK_SET) != 0) { fclose(f); set_error("mpn_index_load: cannot seek in %s", path); return nullptr; }
     mpn_index *idx = new mpn_index();
     bool ok = true;
     auto get = [&](void *p, size_t bytes) { if (bytes && fread(p, 1, bytes, f) != bytes) ok = false; };
@@ -758,6 +764,7 @@ mpn_index *mpn_index_load(const char *path) {
     char magic[8];
     int32_t h32[4];
     int64_t h64[4];
+    int64_t file_size = 0;
     get(magic, 8); get(h32, sizeof(h32)); get(h64, sizeof(h64));
     if (!ok || memcmp(magic, MPN_IDX_MAGIC, 8) != 0) return fail("not an mpn index file");
     idx->k = h32[0]; idx->w = h32[1]; idx->n_seq = h32[2]; idx->n_nruns = h32[3];
@@ -771,7 +778,8 @@ mpn_index *mpn_index_load(const char *path) {
         if (fstat(fileno(f), &sb) != 0) return fail("cannot stat");
         const int64_t fixed = 8 + 16 + 32 + (int64_t)idx->n_seq * 8 /* lens + name length words */ + (int64_t)idx->n_nruns * 16 + n_words * 4 +
                               idx->n_keys * 8 + (idx->n_keys + 1) * 8 + idx->n_mz * 8;
-        if ((int64_t)sb.st_size < fixed) return fail("truncated file");
+        if ((int64_t)sb.st_size < offset + fixed) return fail("truncated file");
+        file_size = (int64_t)sb.st_size;
     }
     idx->lens.resize((size_t)idx->n_seq);
     get(idx->lens.data(), idx->lens.size() * 4);
@@ -808,6 +816,10 @@ mpn_index *mpn_index_load(const char *path) {
     for (int64_t i = 0; i < idx->n_mz; ++i) {
         const uint64_t rid = pos[(size_t)i] >> 32, p = (uint32_t)pos[(size_t)i] >> 1;
         if (rid >= (uint64_t)idx->n_seq || p >= (uint64_t)idx->lens[(size_t)rid]) return fail("position outside its target");
+    }
+    {
+        const int64_t end = (int64_t)ftello(f);
+        if (next_offset && end >= 0 && end < file_size) *next_offset = end;
     }
     fclose(f);
     f = nullptr;

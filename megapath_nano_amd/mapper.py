@@ -59,6 +59,10 @@ def _bind():
         lib.mpn_index_save.restype = ct.c_int
         lib.mpn_index_load.argtypes = [ct.c_char_p]
         lib.mpn_index_load.restype = P
+        lib.mpn_index_save_append.argtypes = [P, ct.c_char_p]
+        lib.mpn_index_save_append.restype = ct.c_int
+        lib.mpn_index_load_at.argtypes = [ct.c_char_p, ct.c_int64, ct.POINTER(ct.c_int64)]
+        lib.mpn_index_load_at.restype = P
         for fn in ('mpn_index_n_seq', 'mpn_index_k', 'mpn_index_w'):
             getattr(lib, fn).argtypes = [P]
             getattr(lib, fn).restype = ct.c_int32
@@ -178,16 +182,40 @@ class Index:
             raise _ffi.MpnError(f'mpn_sam_header rc={r}')
         return buf.raw[:r].decode()
 
-    def save(self, path):
-        """Persistent form (minimap2 `-d FILE`): load() gives back an index that maps identically."""
-        _ffi.check(_bind().mpn_index_save(self.h, os.fsencode(path)), 'mpn_index_save')
+    def save(self, path, append=False):
+        """Persistent form (minimap2 `-d FILE`): load() gives back an index that maps identically.  append=True adds this
+        index as a further PART of the target set the file holds (minimap2 dumps all parts of a -I split into the one file)."""
+        lib = _bind()
+        _ffi.check((lib.mpn_index_save_append if append else lib.mpn_index_save)(self.h, os.fsencode(path)), 'mpn_index_save')
 
     @classmethod
     def load(cls, path):
+        """The (first) index part of a saved file."""
+        idx, _ = cls.load_at(path, 0)
+        return idx
+
+    @classmethod
+    def iter_parts(cls, path):
+        """The index parts of a saved file, one at a time (the caller closes each before asking for the next)."""
+        off = 0
+        while off >= 0:
+            idx, off = cls.load_at(path, off)
+            yield idx
+
+    @classmethod
+    def load_at(cls, path, offset):
+        """-> (the part that starts at byte `offset`, offset of the next part or -1)"""
         lib = _bind()
-        h = lib.mpn_index_load(os.fsencode(path))
+        nxt = ct.c_int64(-1)
+        h = lib.mpn_index_load_at(os.fsencode(path), int(offset), ct.byref(nxt))
         if not h:
             raise _ffi.MpnError('mpn_index_load failed: ' + _ffi.last_error())
+        self = cls._from_handle(h)
+        return self, int(nxt.value)
+
+    @classmethod
+    def _from_handle(cls, h):
+        lib = _bind()
         self = cls.__new__(cls)
         self.h = h
         n = lib.mpn_index_n_seq(h)

@@ -279,6 +279,23 @@ def test_split_index_parts_merge_matches_oracle(world, tmp_path):
     oopt = mb.default_opt()
     assert body == ''.join(sp.map_read(oopt, n_, s_, sam=True, qual=q_) for n_, s_, q_ in zip(names, seqs, quals))
     assert out.stdout.count('@SQ\t') == len(gen)
+    # -d with a target set of several parts (bin/megapath_nano.py:1641-1645): every part goes into the one file, and the file
+    # as the target gives what the FASTA gave
+    mpi = tmp_path / 'three_parts.mpi'
+    cmd = [sys.executable, os.path.join(root, 'bin', 'mpn-aligner'), '-c', '-a', '-t', '4', '-I', '200K', '-x', 'map-ont']
+    out_d = subprocess.run(cmd + ['-d', str(mpi), str(fa), str(fq), '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300, env=env)
+    assert out_d.returncode == 0, out_d.stderr[-2000:]
+    n_loaded, off, seen = 0, 0, []
+    while off >= 0:
+        part, off = mapper.Index.load_at(str(mpi), off)
+        seen += part.names
+        n_loaded += 1
+        part.close()
+    assert n_loaded == 3 and seen == [g[0] for g in gen]
+    out_l = subprocess.run(cmd + [str(mpi), str(fq), '--split-prefix', 'tmp'], capture_output=True, text=True, timeout=300, env=env)
+    assert out_l.returncode == 0, out_l.stderr[-2000:]
+    assert ''.join(l for l in out_l.stdout.splitlines(keepends=True) if not l.startswith('@')) == body == \
+        ''.join(l for l in out_d.stdout.splitlines(keepends=True) if not l.startswith('@'))
     sp.close()
     for x in gparts + oparts:
         x.close()
