@@ -365,8 +365,7 @@ def map_text_and_cols(idx, opt, sub):
     if isinstance(idx, (list, tuple)):
         h = mapper.Hits(sub)
         try:
-            for part in idx:
-                h.add_part(part, opt, use_device=False)
+            h.add_parts(list(idx), opt, use_device=False)
             paf, _, c = h.finish(opt, want_paf=True, want_cols=True)
         finally:
             h.close()

@@ -169,6 +169,12 @@ void mpn_hits_destroy(mpn_hits *h);
 int mpn_map_batch_part(const mpn_index *part, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                        const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs, const int64_t *d_off,
                        const int32_t *d_len, mpn_hits *acc);
+/* The same for several parts that are RESIDENT together (an accelerator with room for the whole target set keeps every part in
+ * memory instead of streaming them): one call, the reads are uploaded once and the (sub-batch, part) pairs share one pipeline.
+ * The accumulator ends up as n_parts calls of mpn_map_batch_part in the given order would leave it. */
+int mpn_map_batch_parts(const mpn_index *const *parts, int32_t n_parts, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                        const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off,
+                        const int32_t *r_len, mpn_hits *acc);
 int64_t mpn_hits_finish(mpn_hits *acc, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                         const char *quals, const int64_t *seq_off, const int32_t *seq_len, char *paf, int64_t paf_cap,
                         mpn_aln_cols *cols);

@@ -95,7 +95,7 @@ def host_cover_by_group(ac, sc, start, end, n_groups):
 
 
 def covered_bp_by_assembly(rows, noise_bed=None, device=None):
-    """Union length of [sequence_from, sequence_to) per (assembly_id, sequence_id), summed per assembly.
+    r"""Union length of [sequence_from, sequence_to) per (assembly_id, sequence_id), summed per assembly.
     noise_bed: DataFrame(sequence_id, start, end[, assembly_id]) -- what it covers on a sequence is subtracted
     (`covered_bed.subtract(noise_bed)`, megapath_nano.py:516-518): |A \ N| = |A u N| - |N| per sequence.
     device: None / True = the HIP path (libmpn.so and a GPU are REQUIRED: like every product path of this package it raises

@@ -11,6 +11,7 @@
 #include "fin_kernels.h"
 #include "stitch_kernels.h"
 #include "plan_kernels.h"
+#include "hit_kernels.h"
 #include "mapper_internal.h"
 #include "../../include/mpn_map.h"
 #include "../../include/mpn_ssw.h"
@@ -37,7 +38,8 @@ int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32
                 DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st);
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
                       const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st);
-int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, bool with_anchors);
+int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, int mode);
+int download_chain_records(SeedChainOut &o, HostChains &h, PoolBuf &pin_u, hipStream_t st);
 
 const char *get_error();
 
@@ -678,7 +680,7 @@ struct Slot {
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
     PoolBuf pool_probes, pool_sizes, pool_buckets, pool_pregs, pool_psum, pool_job_anchor, pool_splits;
-    PoolBuf pin_segs{nullptr, 0, true}, pin_pregs{nullptr, 0, true};
+    PoolBuf pin_segs{nullptr, 0, true}, pin_pregs{nullptr, 0, true}, pin_hits{nullptr, 0, true};
     PoolBuf pin_order{nullptr, 0, true}, pin_res{nullptr, 0, true};
     PoolBuf pin_chain_u{nullptr, 0, true}, pin_chain_b{nullptr, 0, true};
     PoolBuf pin_fin_cig{nullptr, 0, true}, pin_fin_out{nullptr, 0, true};
@@ -1274,8 +1276,8 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
 // Fills rs[lo..hi) (the final hits of every read) and rep_len[lo..hi).
 static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *const *names, const char *seqs,
                      const int64_t *seq_off_all, const int32_t *seq_len_all, const uint8_t *d_seqs_p, const int64_t *d_off_all,
-                     const int32_t *d_len_all, int lo, int hi, int n_threads, hipStream_t st, std::vector<ReadState> &rs_all,
-                     std::vector<int32_t> &rep_len_all) {
+                     const int32_t *d_len_all, const uint32_t *d_name_hash_all, int lo, int hi, int n_threads, hipStream_t st,
+                     std::vector<ReadState> &rs_all, std::vector<int32_t> &rep_len_all) {
     const int n = hi - lo;
     if (n <= 0) return 0;
     const int64_t *seq_off = seq_off_all + lo;
@@ -1287,6 +1289,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
     WallTimer wt;
     HostChains h;
     SeedChainOut o;   // (the chained anchors stay in its device pool until the squeeze below)
+    bool gpu_hits = true;
     {
         // The seed + sort + chain stage is bound by HBM traffic and latency, the extension stage by VALU issue: workers in
         // different stages share the GPU well, workers in the same memory-bound stage only queue on HBM.  At most
@@ -1301,18 +1304,60 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         struct Hold { StageGate &g; Hold(StageGate &x) : g(x) { g.enter(); } ~Hold() { g.leave(); } } hold(gate);
         if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
         wt.stop_into(g_stats[17]);
-        if (download_chains(n, o, h, tl_slot->pin_chain_u, tl_slot->pin_chain_b, st, false)) return -1;
+        // MPN_HOST_HITS=1 (tests): hits from chains on the host for every read, from the downloaded chain records
+        static const bool host_hits = []() { const char *e = getenv("MPN_HOST_HITS"); return e && atoi(e) != 0; }();
+        gpu_hits = !host_hits;
+        if (download_chains(n, o, h, tl_slot->pin_chain_u, tl_slot->pin_chain_b, st, gpu_hits ? 0 : 1)) return -1;
         wt.stop_into(g_stats[18]);
     }
     g_stats[3] += h.chain_off[n];
     for (int i = 0; i < n; ++i) rep_len_all[lo + i] = h.rep_len[i];
-    // Hits from chains.  The host works on the chain records (first / last anchor, approximate lengths: 40 bytes per chain);
-    // the chained anchors never leave HBM.  What the host decides about them -- which chains survive hit selection, their
-    // places in the read's squeezed anchor list, the long-join marks -- goes back as 24-byte segments for the squeeze kernel.
+    // Hits from chains.  hit_select_kernel (hit_kernels.h) makes them on the GPU from the chain records and leaves the squeeze
+    // segments there too; the host receives the selected hits (72 bytes each) and 24 bytes per read.  The chained anchors never
+    // leave HBM.  Reads with more chains than the kernel stages (and every read under MPN_HOST_HITS=1) take the host path: the same
+    // functions of hit.c on the downloaded records, their segments uploaded behind the kernel's.
     Slot &SL = *tl_slot;
-    if (SL.pin_segs.ensure((size_t)h.chain_off[(size_t)n] * sizeof(SqueezeSeg) + (size_t)(n + 1) * 8 + 64)) return -1;
+    const int64_t n_chains_all = h.chain_off[(size_t)n];
+    if (SL.pin_segs.ensure((size_t)n_chains_all * sizeof(SqueezeSeg) + (size_t)(n + 1) * 8 + 64)) return -1;
     int64_t *sq_off = SL.pin_segs.as<int64_t>();                                     // [n + 1] start of every read's squeezed list
     SqueezeSeg *h_segs = reinterpret_cast<SqueezeSeg *>(sq_off + n + 1);
+    DevBuf<HitRec> d_hregs;
+    DevBuf<SqueezeSeg> d_hsegs;
+    DevBuf<unsigned char> d_hreads;   // [counters (4 x 8 bytes) | HitRead[n]]
+    const HitRead *h_reads = nullptr;
+    const HitRec *h_hregs = nullptr;
+    unsigned long long hit_counters[4] = {0, 0, 0, 0};
+    if (d_hsegs.alloc((size_t)n_chains_all + 1)) return -1;
+    if (gpu_hits && n_chains_all > 0) {
+        const size_t reads_bytes = 32 + (size_t)n * sizeof(HitRead);
+        if (d_hregs.alloc((size_t)n_chains_all + 1) || d_hreads.alloc(reads_bytes) || SL.pin_hits.ensure(reads_bytes + (size_t)n_chains_all * sizeof(HitRec) + 64)) return -1;
+        MPN_HIP_CHECK(hipMemsetAsync(d_hreads.p, 0, 32, st));
+        HitSelParams hp;
+        hp.mask_level = opt->mask_level; hp.pri_ratio = opt->pri_ratio; hp.min_join_flank_ratio = opt->min_join_flank_ratio;
+        hp.min_diff = idx->k * 2; hp.best_n = opt->best_n; hp.max_join_long = opt->max_join_long; hp.max_join_short = opt->max_join_short;
+        hp.min_join_flank_sc = opt->min_join_flank_sc; hp.min_cnt = opt->min_cnt; hp.with_cigar = opt->with_cigar; hp.seed_mix = wang32(opt->seed);
+        static const int hit_max = []() { const char *e = getenv("MPN_HIT_MAX_CHAINS"); return e ? std::max(0, std::min(HIT_MAX_CHAINS, atoi(e))) : HIT_MAX_CHAINS; }();
+        hp.max_chains = hit_max;
+        EvTimer evh(st);
+        hipLaunchKernelGGL(hit_select_kernel, dim3((unsigned)std::max(1, std::min(n, 256 * 8))), dim3(64), 0, st, hp, n, (const int32_t *)o.n_chain.p,
+                           (const int64_t *)o.u_pos.p, (const int64_t *)o.b_pos.p, (const uint64_t *)o.u_compact.p, (const ChainRec *)o.recs.p, d_len.p,
+                           d_name_hash_all + lo, d_hregs.p, d_hsegs.p, reinterpret_cast<unsigned long long *>(d_hreads.p),
+                           reinterpret_cast<HitRead *>(d_hreads.p + 32));
+        MPN_HIP_CHECK(hipGetLastError());
+        evh.mark(62);
+        unsigned char *pin = SL.pin_hits.as<unsigned char>();
+        MPN_HIP_CHECK(hipMemcpyAsync(pin, d_hreads.p, reads_bytes, hipMemcpyDeviceToHost, st));
+        MPN_HIP_CHECK(stream_sync(st));
+        evh.resolve();
+        memcpy(hit_counters, pin, 32);
+        h_reads = reinterpret_cast<const HitRead *>(pin + 32);
+        HitRec *dst = reinterpret_cast<HitRec *>(pin + ((reads_bytes + 15) & ~(size_t)15));
+        if (hit_counters[0]) MPN_HIP_CHECK(hipMemcpyAsync(dst, d_hregs.p, (size_t)hit_counters[0] * sizeof(HitRec), hipMemcpyDeviceToHost, st));
+        if (hit_counters[2] && download_chain_records(o, h, SL.pin_chain_u, st)) return -1;   // reads left to the host
+        MPN_HIP_CHECK(stream_sync(st));
+        h_hregs = dst;
+        g_stats[63] += (int64_t)hit_counters[2];
+    }
     // (every pool thread stages the segments of its reads in a list of its own: a shared cursor is a hot cache line)
     std::vector<std::vector<SqueezeSeg>> &stage = SL.seg_stage;
     if ((int)stage.size() < std::max(1, n_threads)) stage.resize((size_t)std::max(1, n_threads));
@@ -1322,6 +1367,23 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         const int nc = h.n_chain[i];
         if (nc == 0) return;
         const int qlen = seq_len[i];
+        if (h_reads && h_reads[i].n_regs >= 0) {
+            // the kernel's hits: the rest of the record follows from the first and last anchor (mm_reg_set_coor)
+            const HitRead &hr = h_reads[i];
+            const HitRec *src = h_hregs + hr.reg_pos;
+            S.regs.assign((size_t)hr.n_regs, Reg());
+            for (int k = 0; k < hr.n_regs; ++k) {
+                Reg &r = S.regs[(size_t)k];
+                const HitRec &x = src[k];
+                r.id = k; r.parent = x.parent; r.score = x.score; r.score0 = x.score0; r.hash = x.hash; r.cnt = x.cnt; r.as = x.as;
+                r.subsc = x.subsc; r.n_sub = x.n_sub; r.mlen = x.mlen; r.blen = x.blen;
+                r.fx = x.fx; r.fy = x.fy; r.lx = x.lx; r.ly = x.ly;
+                reg_set_coor(r, qlen);
+            }
+            if (hr.flags & 1) set_sam_pri(S.regs);
+            S.n_a = hr.n_a;
+            return;
+        }
         CpuSect sect(g_cpu_on);
         static thread_local std::vector<ChainIn> cin;
         std::vector<int32_t> &order = tl_hs.order;
@@ -1344,21 +1406,22 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         if (!opt->with_cigar) segs.resize(seg0);
         sect.lap(5);
     }, 1, 128);
-    int64_t n_segs = 0;
-    for (auto &v : stage) { if (!v.empty()) memcpy(h_segs + n_segs, v.data(), v.size() * sizeof(SqueezeSeg)); n_segs += (int64_t)v.size(); }
+    int64_t n_host_segs = 0;
+    for (auto &v : stage) { if (!v.empty()) memcpy(h_segs + n_host_segs, v.data(), v.size() * sizeof(SqueezeSeg)); n_host_segs += (int64_t)v.size(); }
+    const int64_t n_dev_segs = (int64_t)hit_counters[1], n_segs = n_dev_segs + n_host_segs;
     wt.stop_into(g_stats[19]);
     sq_off[0] = 0;
     for (int i = 0; i < n; ++i) sq_off[i + 1] = sq_off[i] + rs[i].n_a;
     const int64_t n_sq = sq_off[n];
     if (opt->with_cigar && n_sq > 0) {
         DevBuf<u128> d_a;
-        DevBuf<unsigned char> d_segs;
-        const size_t seg_bytes = (size_t)(n + 1) * 8 + (size_t)n_segs * sizeof(SqueezeSeg);
-        if (d_a.alloc((size_t)n_sq) || d_segs.alloc(seg_bytes)) return -1;
-        MPN_HIP_CHECK(hipMemcpyAsync(d_segs.p, sq_off, seg_bytes, hipMemcpyHostToDevice, st));
+        DevBuf<int64_t> d_sq_off;
+        if (d_a.alloc((size_t)n_sq) || d_sq_off.alloc((size_t)n + 1)) return -1;
+        MPN_HIP_CHECK(hipMemcpyAsync(d_sq_off.p, sq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+        // (the host's segments go behind the kernel's in the device list)
+        if (n_host_segs) MPN_HIP_CHECK(hipMemcpyAsync(d_hsegs.p + n_dev_segs, h_segs, (size_t)n_host_segs * sizeof(SqueezeSeg), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(anchor_squeeze_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_segs + 3) / 4, 256 * 16))), dim3(256), 0, st,
-                           reinterpret_cast<const SqueezeSeg *>(d_segs.p + (size_t)(n + 1) * 8), (int)n_segs, (const u128 *)o.chained.p,
-                           reinterpret_cast<const int64_t *>(d_segs.p), d_a.p);
+                           (const SqueezeSeg *)d_hsegs.p, (int)n_segs, (const u128 *)o.chained.p, (const int64_t *)d_sq_off.p, d_a.p);
         MPN_HIP_CHECK(hipGetLastError());
         g_stats[59] += n_sq;
         PlanOpt po;
@@ -1581,10 +1644,12 @@ static int default_host_threads(const mpn_map_opt *opt) {
     return detected;
 }
 
-// the mapping itself: every read's final hits against ONE index -> rs, rep_len (no text)
-static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
+// The mapping itself: every read's final hits against every one of n_parts RESIDENT indexes -> rs[part], rep_len[part] (no text).
+// One index is the plain case.  Several are the parts of a target set that exceeds one index (minimap2 -I): the work items of
+// the pipeline are (sub-batch, part) pairs, so the reads go up once, and the pipeline neither drains nor refills between parts.
+static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                           const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off, const int32_t *r_len,
-                          std::vector<ReadState> &rs, std::vector<int32_t> &rep_len, int *n_threads_out) {
+                          std::vector<std::vector<ReadState>> &rs, std::vector<std::vector<int32_t>> &rep_len, int *n_threads_out) {
     hipStream_t st0 = 0;
     struct Borrowed {  // device views of the reads: owned uploads or the caller's resident buffers
         DevBuf<uint8_t> seqs; DevBuf<int64_t> off; DevBuf<int32_t> len;
@@ -1598,6 +1663,14 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
     } else {
         if (upload_seqs(n, seqs, seq_off, seq_len, dv.seqs, dv.off, dv.len, &bases, st0)) return -1;
         dv.p = dv.seqs.p; dv.po = dv.off.p; dv.pl = dv.len.p;
+    }
+    // per read: the x31 hash of its name (what minimap2 mixes into the order of equal-scoring chains), for hit_select_kernel
+    DevBuf<uint32_t> d_name_hash;
+    {
+        std::vector<uint32_t> nh((size_t)n, 0u);
+        if (names) for (int i = 0; i < n; ++i) nh[(size_t)i] = names[i] ? x31_hash(names[i]) : 0u;
+        if (d_name_hash.upload(nh.data(), (size_t)n, st0)) return -1;
+        MPN_HIP_CHECK(hipStreamSynchronize(st0));
     }
     MPN_HIP_CHECK(hipStreamSynchronize(st0));
     wt.stop_into(g_stats[16]);
@@ -1628,7 +1701,8 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         cut.push_back(n);
     }
     const int n_sub = (int)cut.size() - 1;
-    n_workers = std::max(1, std::min(n_workers, n_sub));
+    const int n_items = n_sub * n_parts;   // item k: sub-batch k / n_parts against part k % n_parts
+    n_workers = std::max(1, std::min(n_workers, n_items));
     {
         // every worker holds its own scratch (direction matrices above all): about 400 bytes per base of a sub-batch
         // with map-ont settings.  Do not start more workers than the free HBM (plus what the slots already hold) covers.
@@ -1652,8 +1726,9 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
         if (g_slots[wdx].device_bytes()) { MPN_HIP_CHECK(hipDeviceSynchronize()); g_slots[wdx].release_device(); }
     int dev = 0;
     MPN_HIP_CHECK(hipGetDevice(&dev));
-    rs.assign((size_t)n, ReadState());
-    rep_len.assign((size_t)n, 0);
+    rs.assign((size_t)n_parts, std::vector<ReadState>());
+    rep_len.assign((size_t)n_parts, std::vector<int32_t>());
+    for (int p = 0; p < n_parts; ++p) { rs[(size_t)p].assign((size_t)n, ReadState()); rep_len[(size_t)p].assign((size_t)n, 0); }
     std::atomic<int> next(0), failed(0);
     std::mutex mu;
     std::deque<int> retry;          // sub-batches given back by a worker that ran out of device memory (guarded by mu)
@@ -1681,7 +1756,7 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
             int sb = -1;
             { std::lock_guard<std::mutex> g(mu); if (!retry.empty()) { sb = retry.front(); retry.pop_front(); } }
             if (sb < 0) sb = next.fetch_add(1);
-            if (sb >= n_sub || failed) {
+            if (sb >= n_items || failed) {
                 // (a sub-batch may still come back from a worker that is shedding: wait for those before leaving)
                 std::unique_lock<std::mutex> lk(mu);
                 if (failed || (retry.empty() && live_workers_busy == 0)) break;
@@ -1698,7 +1773,8 @@ static int map_batch_core(const mpn_index *idx, const mpn_map_opt *opt, int32_t 
             memcpy(stats_before, g_stats, sizeof(stats_before));
             const double t_in = since();
             struct Out { bool on; int wid, sb; double t_in; decltype(since) &f; ~Out() { if (on) fprintf(stderr, "[worker %d] sub-batch %d: %.1f -> %.1f ms\n", wid, sb, t_in, f()); } } out_{dbg_workers, wid, sb, t_in, since};
-            if (map_range(idx, opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, cut[sb], cut[sb + 1], n_threads, S.st, rs, rep_len)) {
+            const int sbi = sb / n_parts, prt = sb % n_parts;
+            if (map_range(parts[prt], opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, d_name_hash.p, cut[sbi], cut[sbi + 1], n_threads, S.st, rs[(size_t)prt], rep_len[(size_t)prt])) {
                 std::lock_guard<std::mutex> g(mu);
                 // Out of device memory: the workers' scratch grows with what the target set throws at them (a strain-rich index
                 // yields tens of times the anchors of a random one), and the up-front estimate can be too low.  This worker gives
@@ -1846,11 +1922,13 @@ extern "C" int64_t mpn_map_batch_q(const mpn_index *idx, const mpn_map_opt *opt,
     if (cols) cols->n_rows = 0;
     if (n <= 0) { if (paf && paf_cap > 0) paf[0] = 0; g_kept = Kept(); if (opt->out_sam == 2) g_kept.has_sam = true; return 0; }
     WallTimer whole;
-    std::vector<ReadState> rs;
-    std::vector<int32_t> rep_len;
+    std::vector<std::vector<ReadState>> rs_p;
+    std::vector<std::vector<int32_t>> rep_p;
     int n_threads = 1;
     g_need_cigar = paf != nullptr || opt->out_sam != 0;   // columns only: the CIGARs never leave the GPU
-    if (map_batch_core(idx, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
+    if (map_batch_core(&idx, 1, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs_p, rep_p, &n_threads)) return -1;
+    std::vector<ReadState> &rs = rs_p[0];
+    std::vector<int32_t> &rep_len = rep_p[0];
     std::vector<std::vector<Reg>*> regs((size_t)n);
     for (int i = 0; i < n; ++i) regs[(size_t)i] = &rs[(size_t)i].regs;
     const int64_t w = emit_batch(Targets{&idx->names, &idx->lens}, opt, n, names, seqs, quals, seq_off, seq_len, regs, rep_len, n_threads, paf, paf_cap, cols);
@@ -1888,32 +1966,49 @@ extern "C" int32_t mpn_hits_seq_name(const mpn_hits *h, int32_t i, char *buf, in
     return (int32_t)nm.size();
 }
 
+// several RESIDENT parts in one call (288 GB of HBM hold what a CPU host streams through -I): the pipeline's work items are
+// (sub-batch, part) pairs; the hits land in the accumulator part by part, in the order given, as repeated
+// mpn_map_batch_part calls would leave them
+extern "C" int mpn_map_batch_parts(const mpn_index *const *parts, int32_t n_parts, const mpn_map_opt *opt, int32_t n, const char *const *names,
+                                   const char *seqs, const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off,
+                                   const int32_t *r_len, mpn_hits *acc) {
+    if (!acc || n != acc->n_reads) { set_error("mpn_map_batch_parts: the accumulator was created for another batch"); return -1; }
+    if (!parts || n_parts <= 0) { set_error("mpn_map_batch_parts: no index part"); return -1; }
+    for (int p = 0; p < n_parts; ++p)
+        if (!parts[p] || parts[p]->k != parts[0]->k) { set_error("mpn_map_batch_parts: null part or parts built with different k"); return -1; }
+    std::lock_guard<std::mutex> call_guard(g_call_mu);
+    memset(g_stats, 0, sizeof(g_stats));
+    if (n > 0) {
+        std::vector<std::vector<ReadState>> rs;
+        std::vector<std::vector<int32_t>> rep_len;
+        int n_threads = 1;
+        g_need_cigar = true;   // (whether text is wanted is only known at mpn_hits_finish)
+        if (map_batch_core(parts, n_parts, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
+        std::vector<int32_t> rid0((size_t)n_parts);
+        int32_t r0 = (int32_t)acc->lens.size();
+        for (int p = 0; p < n_parts; ++p) { rid0[(size_t)p] = r0; r0 += parts[p]->n_seq; }
+        parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i)
+                for (int p = 0; p < n_parts; ++p) {
+                    for (Reg &r : rs[(size_t)p][(size_t)i].regs) { r.rid += rid0[(size_t)p]; acc->regs[(size_t)i].push_back(std::move(r)); }
+                    acc->rep_len[(size_t)i] = std::max(acc->rep_len[(size_t)i], rep_len[(size_t)p][(size_t)i]);
+                    rs[(size_t)p][(size_t)i] = ReadState();
+                }
+        });
+    }
+    for (int p = 0; p < n_parts; ++p) {
+        acc->names.insert(acc->names.end(), parts[p]->names.begin(), parts[p]->names.end());
+        acc->lens.insert(acc->lens.end(), parts[p]->lens.begin(), parts[p]->lens.end());
+        acc->k = parts[p]->k;
+        ++acc->n_parts;
+    }
+    return 0;
+}
+
 extern "C" int mpn_map_batch_part(const mpn_index *part, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                                   const int64_t *seq_off, const int32_t *seq_len, const void *r_seqs, const int64_t *r_off,
                                   const int32_t *r_len, mpn_hits *acc) {
-    if (!acc || n != acc->n_reads) { set_error("mpn_map_batch_part: the accumulator was created for another batch"); return -1; }
-    std::lock_guard<std::mutex> call_guard(g_call_mu);
-    memset(g_stats, 0, sizeof(g_stats));
-    const int32_t rid0 = (int32_t)acc->lens.size();
-    if (n > 0) {
-        std::vector<ReadState> rs;
-        std::vector<int32_t> rep_len;
-        int n_threads = 1;
-        g_need_cigar = true;   // (whether text is wanted is only known at mpn_hits_finish)
-        if (map_batch_core(part, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
-        parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
-            for (int64_t i = lo; i < hi; ++i) {
-                for (Reg &r : rs[(size_t)i].regs) { r.rid += rid0; acc->regs[(size_t)i].push_back(std::move(r)); }
-                acc->rep_len[(size_t)i] = std::max(acc->rep_len[(size_t)i], rep_len[(size_t)i]);
-                rs[(size_t)i] = ReadState();
-            }
-        });
-    }
-    acc->names.insert(acc->names.end(), part->names.begin(), part->names.end());
-    acc->lens.insert(acc->lens.end(), part->lens.begin(), part->lens.end());
-    acc->k = part->k;
-    ++acc->n_parts;
-    return 0;
+    return mpn_map_batch_parts(&part, 1, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, acc);
 }
 
 // minimap2's merge of the per-part hits of a read (mm_split_merge): the sub-optimal bookkeeping is reset, the hits are

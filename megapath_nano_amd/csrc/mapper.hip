@@ -414,7 +414,10 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
 
 // download the per-read tables and the compact chain pools of a batch (pinned staging owned by the caller): the (score, count)
 // words and the chain records; the chained anchors only for the stage test (with_anchors) -- the mapper leaves them in HBM
-int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, bool with_anchors) {
+// mode 0: the per-read tables only (the hits are made on the GPU: hit_kernels.h); 1: + the (score, count) words and the chain
+// records; 2: + the words and the chained anchors (stage test)
+int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, int mode) {
+    const bool with_anchors = mode == 2;
     h.n_anchor.resize((size_t)n);
     h.n_chain.resize(n); h.n_chained.resize(n); h.rep_len.resize(n); h.u_pos.resize(n); h.b_pos.resize(n);
     unsigned long long used[2 + WORK_SLOTS] = {0};
@@ -432,7 +435,9 @@ int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolB
     }
     for (int k = 0; k < WORK_SLOTS; ++k) g_stats[44] += (int64_t)used[2 + k];
     ++g_stats[32];
-    if (with_anchors) {
+    h.n_pool_chains = (int64_t)used[0];
+    if (mode == 0) { h.u_all = nullptr; h.rec_all = nullptr; h.b_all = nullptr; }
+    else if (with_anchors) {
         if (pin_u.ensure((size_t)used[0] * 8 + 16) || pin_b.ensure((size_t)used[1] * 16 + 16)) return -1;
         if (o.u_compact.download(pin_u.as<uint64_t>(), (size_t)used[0], st) || o.chained.download(pin_b.as<u128>(), (size_t)used[1], st)) return -1;
         h.u_all = pin_u.as<uint64_t>(); h.b_all = pin_b.as<u128>();
@@ -470,6 +475,18 @@ void HostChains::read_chains(int i, uint64_t *uo, u128 *bo) const {
         memcpy(bo + kk, b + start, (size_t)cnt * sizeof(u128));
         kk += cnt;
     }
+}
+
+// the records and (score, count) words of a batch whose tables are already down (the reads the hit kernel left to the host)
+int download_chain_records(SeedChainOut &o, HostChains &h, PoolBuf &pin_u, hipStream_t st) {
+    const size_t nc = (size_t)h.n_pool_chains;
+    const size_t rec_bytes = (nc * sizeof(ChainRec) + 15) & ~(size_t)15;
+    if (pin_u.ensure(rec_bytes + nc * 8 + 16)) return -1;
+    h.rec_all = pin_u.as<ChainRec>();
+    h.u_all = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(pin_u.p) + rec_bytes);
+    if (o.recs.download(const_cast<ChainRec *>(h.rec_all), nc, st) || o.u_compact.download(const_cast<uint64_t *>(h.u_all), nc, st)) return -1;
+    MPN_HIP_CHECK(stream_sync(st));
+    return 0;
 }
 
 void HostChains::chain_order(int i, int32_t *order, int64_t *src) const {
@@ -952,7 +969,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     HostChains h;
     PoolBuf pin_u{nullptr, 0, true}, pin_b{nullptr, 0, true};
     struct Free { PoolBuf &a, &b; ~Free() { a.release(); b.release(); } } free_pins{pin_u, pin_b};
-    if (download_chains(n, o, h, pin_u, pin_b, st, true)) return -1;
+    if (download_chains(n, o, h, pin_u, pin_b, st, 2)) return -1;
     for (int i = 0; i < n; ++i) { n_anchor[i] = h.n_anchor[i]; rep_len[i] = h.rep_len[i]; }
     memcpy(chain_off, h.chain_off.data(), ((size_t)n + 1) * 8);
     memcpy(anchor_off, h.b_off.data(), ((size_t)n + 1) * 8);

@@ -63,6 +63,7 @@ struct HostChains {
     const uint64_t *u_all = nullptr;                    // compact pools as downloaded (caller-owned pinned memory)
     const u128 *b_all = nullptr;                        // (only when the anchors were asked for: the stage test)
     const ChainRec *rec_all = nullptr;
+    int64_t n_pool_chains = 0;                          // chains in the compact pools of the batch
     // chains of read i in ascending order of their first anchor (minimap2 re-sorts them like this so that neighbouring
     // chains can be joined): u_out[n_chain[i]], b_out[n_chained[i]]
     void read_chains(int i, uint64_t *u_out, u128 *b_out) const;

@@ -98,6 +98,8 @@ def _bind():
         lib.mpn_hits_sam_header.restype = ct.c_int64
         lib.mpn_map_batch_part.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P]
         lib.mpn_map_batch_part.restype = ct.c_int
+        lib.mpn_map_batch_parts.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int32, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P]
+        lib.mpn_map_batch_parts.restype = ct.c_int
         lib.mpn_hits_finish.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, ct.c_int64,
                                         ct.POINTER(AlnCols)]
         lib.mpn_hits_finish.restype = ct.c_int64
@@ -456,6 +458,14 @@ class Hits:
         _ffi.check(_bind().mpn_map_batch_part(idx.h, ct.byref(opt), p.n, p.cnames, p.buf.ctypes.data, p.off.ctypes.data, p.lens.ctypes.data,
                                               d[0], d[1], d[2], self.h), 'mpn_map_batch_part')
 
+    def add_parts(self, parts, opt, use_device=True):
+        """Several RESIDENT index parts in one call: reads uploaded once, (sub-batch, part) pairs in one pipeline."""
+        p = self.packed
+        d = _dev_ptrs(p, use_device)
+        arr = (ct.c_void_p * len(parts))(*[i.h for i in parts])
+        _ffi.check(_bind().mpn_map_batch_parts(arr, len(parts), ct.byref(opt), p.n, p.cnames, p.buf.ctypes.data, p.off.ctypes.data,
+                                               p.lens.ctypes.data, d[0], d[1], d[2], self.h), 'mpn_map_batch_parts')
+
     def finish(self, opt, want_paf=False, want_cols=True):
         """-> (text, SAM text or None, columns); column `rid` indexes targets()"""
         lib = _bind()
@@ -535,7 +545,7 @@ STAT_NAMES = {0: 'bases', 1: 'minimizers', 2: 'anchors', 3: 'chains', 4: 'dp_job
               33: 'k_sketch_count_ns', 34: 'k_sketch_fill_ns', 35: 'k_seed_lookup_ns', 36: 'k_seed_fill_ns',
               37: 'k_chain_dp_ns', 38: 'k_strip16_ns', 39: 'k_strip32_ns', 40: 'k_strip64_ns', 41: 'strip16_cells',
               42: 'strip32_cells', 43: 'strip64_cells', 44: 'sort_records_moved', 45: 'anchors_kept', 46: 'k_compact_ns', 47: 'k_sort_msd_ns', 48: 'k_sort_chunk_ns', 49: 'k_sort_radix_ns',
-              50: 'k_seed_filter_ns', 51: 'anchors_emitted', 52: 'k_finish_ns', 53: 'cigar_ops', 54: 'k_stitch_ns', 55: 'k_plan_ns', 56: 'k_layout_ns', 57: 'k_xstrip_ns', 58: 'xstrip_cells', 59: 'anchors_squeezed', 60: 'workers_shed', 61: 'workers'}
+              50: 'k_seed_filter_ns', 51: 'anchors_emitted', 52: 'k_finish_ns', 53: 'cigar_ops', 54: 'k_stitch_ns', 55: 'k_plan_ns', 56: 'k_layout_ns', 57: 'k_xstrip_ns', 58: 'xstrip_cells', 59: 'anchors_squeezed', 60: 'workers_shed', 61: 'workers', 62: 'k_hit_select_ns', 63: 'reads_hits_on_host'}
 
 
 def last_stats():

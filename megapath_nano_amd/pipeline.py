@@ -62,8 +62,7 @@ def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_thre
         # minimap2 --split-prefix merges them (mapper.Hits); column `rid` indexes the concatenated target list
         hits = mapper.Hits(packed)
         try:
-            for part in idx:
-                hits.add_part(part, opt, use_device=use_device)
+            hits.add_parts(list(idx), opt, use_device=use_device)      # all parts are resident: one call, one pipeline
             _, _, c = hits.finish(opt, want_paf=False, want_cols=True)
         finally:
             hits.close()

@@ -241,6 +241,12 @@ def test_split_index_parts_merge_matches_oracle(world, tmp_path):
         for gp in gparts:
             h.add_part(gp, gopt)
         paf, sam, cols = h.finish(gopt, want_paf=True, want_cols=True)
+        # all parts resident, one call (mpn_map_batch_parts: (sub-batch, part) pairs in one pipeline): the same accumulator
+        h2 = mapper.Hits(packed)
+        h2.add_parts(gparts, gopt)
+        paf2, sam2, cols2 = h2.finish(gopt, want_paf=True, want_cols=True)
+        h2.close()
+        assert paf2 == paf and sam2 == sam and all(np.array_equal(cols[k], cols2[k]) for k in cols)
         tnames, tlens = h.targets()
         assert tnames == [g[0] for g in gen] and list(tlens) == [len(g[1]) for g in gen]
         want = [sp.map_read(oopt, n_, s_) for n_, s_ in zip(names, seqs)]
