@@ -166,6 +166,9 @@ int64_t mpn_map_fetch_sam(char *buf, int64_t cap);  /* like mpn_map_fetch_text, 
 typedef struct mpn_hits mpn_hits;
 mpn_hits *mpn_hits_create(int32_t n_reads);
 void mpn_hits_destroy(mpn_hits *h);
+/* want_text = 0: mpn_hits_finish will be asked for the integer columns only (no PAF, no SAM), so the CIGARs of the parts' hits stay in
+ * HBM -- the integer fast path of the species-placement step (bin/megapath_nano.py:1262-1299 reads columns only).  Default 1. */
+void mpn_hits_set_text(mpn_hits *h, int32_t want_text);
 int mpn_map_batch_part(const mpn_index *part, const mpn_map_opt *opt, int32_t n, const char *const *names, const char *seqs,
                        const int64_t *seq_off, const int32_t *seq_len, const void *d_seqs, const int64_t *d_off,
                        const int32_t *d_len, mpn_hits *acc);

@@ -333,8 +333,29 @@ static void hit_sort(std::vector<Reg> &r) {
     for (int i = 0; i < n; ++i)
         if (r[i].inv || r[i].cnt > 0) aux.push_back({(uint64_t)(uint32_t)(r[i].has_p ? r[i].dp_max : r[i].score) << 32 | r[i].hash, i});
     std::sort(aux.begin(), aux.end());
+    const int m = (int)aux.size();
+    if (m == n) {
+        // every hit stays: permute in place along the cycles (a read of a split, strain-rich target set brings a hundred hits
+        // to the merge; a second array of them costs an allocation and a construction + destruction per hit)
+        std::vector<int> &from = tl_hs.idx;   // the hit that belongs at place k
+        from.resize((size_t)n);
+        for (int k = 0; k < n; ++k) from[(size_t)k] = aux[(size_t)(n - 1 - k)].second;
+        for (int s0 = 0; s0 < n; ++s0) {
+            if (from[(size_t)s0] == s0 || from[(size_t)s0] < 0) continue;
+            Reg tmp = std::move(r[(size_t)s0]);
+            int k = s0;
+            for (;;) {
+                const int f = from[(size_t)k];
+                from[(size_t)k] = -1;
+                if (f == s0) { r[(size_t)k] = std::move(tmp); break; }
+                r[(size_t)k] = std::move(r[(size_t)f]);
+                k = f;
+            }
+        }
+        return;
+    }
     std::vector<Reg> t(aux.size());
-    for (int i = (int)aux.size() - 1; i >= 0; --i) t[aux.size() - 1 - i] = std::move(r[(size_t)aux[i].second]);
+    for (int i = m - 1; i >= 0; --i) t[(size_t)(m - 1 - i)] = std::move(r[(size_t)aux[i].second]);
     r.swap(t);
 }
 
@@ -1339,10 +1360,15 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         static const int hit_max = []() { const char *e = getenv("MPN_HIT_MAX_CHAINS"); return e ? std::max(0, std::min(HIT_MAX_CHAINS, atoi(e))) : HIT_MAX_CHAINS; }();
         hp.max_chains = hit_max;
         EvTimer evh(st);
-        hipLaunchKernelGGL(hit_select_kernel, dim3((unsigned)std::max(1, std::min(n, 256 * 8))), dim3(64), 0, st, hp, n, (const int32_t *)o.n_chain.p,
-                           (const int64_t *)o.u_pos.p, (const int64_t *)o.b_pos.p, (const uint64_t *)o.u_compact.p, (const ChainRec *)o.recs.p, d_len.p,
-                           d_name_hash_all + lo, d_hregs.p, d_hsegs.p, reinterpret_cast<unsigned long long *>(d_hreads.p),
-                           reinterpret_cast<HitRead *>(d_hreads.p + 32));
+        // two instantiations: reads with few chains (nearly all reads of a random target set) need little LDS, so many waves per CU
+#define MPN_HIT_LAUNCH(NN, LO, GRID)                                                                                                      \
+        hipLaunchKernelGGL(hit_select_kernel<NN>, dim3((unsigned)std::max(1, std::min(n, GRID))), dim3(64), 0, st, hp, LO, n, (const int32_t *)o.n_chain.p, \
+                           (const int64_t *)o.u_pos.p, (const int64_t *)o.b_pos.p, (const uint64_t *)o.u_compact.p, (const ChainRec *)o.recs.p, d_len.p, \
+                           d_name_hash_all + lo, d_hregs.p, d_hsegs.p, reinterpret_cast<unsigned long long *>(d_hreads.p),                \
+                           reinterpret_cast<HitRead *>(d_hreads.p + 32))
+        MPN_HIT_LAUNCH(HIT_SMALL_CHAINS, 0, 256 * 16);
+        MPN_HIT_LAUNCH(HIT_MAX_CHAINS, HIT_SMALL_CHAINS, 256 * 3);
+#undef MPN_HIT_LAUNCH
         MPN_HIP_CHECK(hipGetLastError());
         evh.mark(62);
         unsigned char *pin = SL.pin_hits.as<unsigned char>();
@@ -1606,6 +1632,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
 // part with target ids shifted to the concatenated target table, and the largest repetitive-seed span.
 struct mpn_hits {
     int32_t n_reads = 0, n_parts = 0, k = 15;
+    int32_t want_text = 1;   // 0: mpn_hits_finish will be asked for columns only: the CIGARs need not leave the GPU (mpn_hits_set_text)
     std::vector<std::vector<Reg>> regs;
     std::vector<int32_t> rep_len;
     std::vector<std::string> names;
@@ -1822,9 +1849,9 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
         fprintf(stderr, "[phase-end]\n");
     }
     if (g_cpu_on) {
-        static const char *const nm[] = {"other", "hits", "plan", "plan-copy", "stitch", "final", "dp-group-A", "strip-sort", "job-copy", "finish-copy"};
+        static const char *const nm[] = {"other", "hits", "plan", "plan-copy", "stitch", "final", "dp-group-A", "strip-sort", "job-copy", "finish-copy", "accumulate", "merge"};
         fprintf(stderr, "[cpu] thread CPU ms in parallel regions:");
-        for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.0f", nm[k], g_cpu_ns[k].load() / 1e6);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, " %s %.0f", nm[k], g_cpu_ns[k].load() / 1e6);
         fprintf(stderr, "\n[cpu] sections: stitch-append %.0f", g_cpu_ns[16].load() / 1e6);
         for (int k = 3; k < 16; ++k) if (g_cpu_ns[16 + k].load() > 500000) fprintf(stderr, " s%d %.0f", k, g_cpu_ns[16 + k].load() / 1e6);
         fprintf(stderr, "\n[cpu] worker-thread CPU ms by phase slot:");
@@ -1954,6 +1981,7 @@ extern "C" mpn_hits *mpn_hits_create(int32_t n_reads) {
     return h;
 }
 extern "C" void mpn_hits_destroy(mpn_hits *h) { delete h; }
+extern "C" void mpn_hits_set_text(mpn_hits *h, int32_t want_text) { if (h) h->want_text = want_text ? 1 : 0; }
 extern "C" int32_t mpn_hits_n_seq(const mpn_hits *h) { return (int32_t)h->lens.size(); }
 extern "C" int32_t mpn_hits_n_parts(const mpn_hits *h) { return h->n_parts; }
 extern "C" int32_t mpn_hits_seq_len(const mpn_hits *h, int32_t i) { return i >= 0 && (size_t)i < h->lens.size() ? h->lens[(size_t)i] : -1; }
@@ -1982,19 +2010,23 @@ extern "C" int mpn_map_batch_parts(const mpn_index *const *parts, int32_t n_part
         std::vector<std::vector<ReadState>> rs;
         std::vector<std::vector<int32_t>> rep_len;
         int n_threads = 1;
-        g_need_cigar = true;   // (whether text is wanted is only known at mpn_hits_finish)
+        g_need_cigar = acc->want_text != 0;   // (text is asked for at mpn_hits_finish: the accumulator says whether it will be)
         if (map_batch_core(parts, n_parts, opt, n, names, seqs, seq_off, seq_len, r_seqs, r_off, r_len, rs, rep_len, &n_threads)) return -1;
         std::vector<int32_t> rid0((size_t)n_parts);
         int32_t r0 = (int32_t)acc->lens.size();
         for (int p = 0; p < n_parts; ++p) { rid0[(size_t)p] = r0; r0 += parts[p]->n_seq; }
         parallel_chunks(n, n_threads, [&](int64_t lo, int64_t hi, int) {
-            for (int64_t i = lo; i < hi; ++i)
+            for (int64_t i = lo; i < hi; ++i) {
+                size_t more = 0;
+                for (int p = 0; p < n_parts; ++p) more += rs[(size_t)p][(size_t)i].regs.size();
+                acc->regs[(size_t)i].reserve(acc->regs[(size_t)i].size() + more);
                 for (int p = 0; p < n_parts; ++p) {
                     for (Reg &r : rs[(size_t)p][(size_t)i].regs) { r.rid += rid0[(size_t)p]; acc->regs[(size_t)i].push_back(std::move(r)); }
                     acc->rep_len[(size_t)i] = std::max(acc->rep_len[(size_t)i], rep_len[(size_t)p][(size_t)i]);
                     rs[(size_t)p][(size_t)i] = ReadState();
                 }
-        });
+            }
+        }, 10);
     }
     for (int p = 0; p < n_parts; ++p) {
         acc->names.insert(acc->names.end(), parts[p]->names.begin(), parts[p]->names.end());
@@ -2033,7 +2065,10 @@ extern "C" int64_t mpn_hits_finish(mpn_hits *acc, const mpn_map_opt *opt, int32_
     const int n_threads = default_host_threads(opt);
     g_pool.ensure(n_threads);
     if (!acc->n_parts) { set_error("mpn_hits_finish: no part was mapped"); return -1; }
-    parallel_for(n, n_threads, [&](int i, int) { merge_regs(opt, acc->k, acc->regs[(size_t)i], acc->rep_len[(size_t)i]); }, 0, 128);
+    if (!acc->want_text && (paf || opt->out_sam != 0)) { set_error("mpn_hits_finish: text asked of an accumulator that was told there would be none (mpn_hits_set_text)"); return -1; }
+    if (g_cpu_on) { g_cpu_ns[11] = 0; g_cpu_ns[0] = 0; }
+    struct Report { ~Report() { if (g_cpu_on) fprintf(stderr, "[cpu] finish: merge %.0f ms, text/other %.0f ms (thread CPU in parallel regions)\n", g_cpu_ns[11].load() / 1e6, g_cpu_ns[0].load() / 1e6); } } report_;
+    parallel_for(n, n_threads, [&](int i, int) { merge_regs(opt, acc->k, acc->regs[(size_t)i], acc->rep_len[(size_t)i]); }, 11, 128);
     std::vector<std::vector<Reg>*> regs((size_t)n);
     for (int i = 0; i < n; ++i) regs[(size_t)i] = &acc->regs[(size_t)i];
     return emit_batch(Targets{&acc->names, &acc->lens}, opt, n, names, seqs, quals, seq_off, seq_len, regs, acc->rep_len, n_threads, paf, paf_cap, cols);

@@ -13,7 +13,8 @@
 
 namespace mpn {
 
-constexpr int HIT_MAX_CHAINS = 384;
+constexpr int HIT_MAX_CHAINS = 384;   // LDS of the large instantiation: 136 bytes per chain
+constexpr int HIT_SMALL_CHAINS = 48;  // the small one (most reads of a random target set): 6.5 KB, so that a CU holds many waves
 
 struct HitSelParams {
     float mask_level, pri_ratio, min_join_flank_ratio;
@@ -44,13 +45,16 @@ __device__ __forceinline__ uint32_t hs_wang32(uint32_t key) {
     return key;
 }
 
-__global__ __launch_bounds__(64) void hit_select_kernel(HitSelParams prm, int n_reads, const int32_t *__restrict__ n_chain,
+// N: chains a read may have in this instantiation; it takes the reads with lo_excl < chains <= min(N, prm.max_chains), and the
+// instantiation with lo_excl == 0 also writes the records of the reads without chains; the one with N == HIT_MAX_CHAINS those
+// of the reads it leaves to the host
+template <int N>
+__global__ __launch_bounds__(64) void hit_select_kernel(HitSelParams prm, int lo_excl, int n_reads, const int32_t *__restrict__ n_chain,
                                                         const int64_t *__restrict__ u_pos, const int64_t *__restrict__ b_pos,
                                                         const uint64_t *__restrict__ Uc, const ChainRec *__restrict__ Rc,
                                                         const int32_t *__restrict__ qlens, const uint32_t *__restrict__ name_hash,
                                                         HitRec *__restrict__ out_regs, SqueezeSeg *__restrict__ out_segs,
                                                         unsigned long long *__restrict__ counters, HitRead *__restrict__ out_reads) {
-    constexpr int N = HIT_MAX_CHAINS;
     // sort keys / scratch
     __shared__ uint64_t k0[N], k1[N];
     __shared__ int32_t ord[N];
@@ -64,8 +68,12 @@ __global__ __launch_bounds__(64) void hit_select_kernel(HitSelParams prm, int n_
     const int lane = threadIdx.x;
     for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
         const int nc = n_chain[read];
-        if (nc == 0) { if (lane == 0) out_reads[read] = HitRead{0, 0, 0, 0, 0}; continue; }
-        if (nc > prm.max_chains) { if (lane == 0) { out_reads[read] = HitRead{0, -1, 0, 0, 0}; atomicAdd(&counters[2], 1ULL); } continue; }
+        if (nc == 0) { if (lane == 0 && lo_excl == 0) out_reads[read] = HitRead{0, 0, 0, 0, 0}; continue; }
+        if (nc > prm.max_chains) {
+            if (lane == 0 && N == HIT_MAX_CHAINS) { out_reads[read] = HitRead{0, -1, 0, 0, 0}; atomicAdd(&counters[2], 1ULL); }
+            continue;
+        }
+        if (nc <= lo_excl || nc > N) continue;
         const int qlen = qlens[read];
         const uint64_t *u = Uc + u_pos[read];
         const ChainRec *rc = Rc + u_pos[read];

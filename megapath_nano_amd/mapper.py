@@ -100,6 +100,8 @@ def _bind():
         lib.mpn_map_batch_part.restype = ct.c_int
         lib.mpn_map_batch_parts.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int32, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, P, P]
         lib.mpn_map_batch_parts.restype = ct.c_int
+        lib.mpn_hits_set_text.argtypes = [P, ct.c_int32]
+        lib.mpn_hits_set_text.restype = None
         lib.mpn_hits_finish.argtypes = [P, ct.POINTER(MapOpt), ct.c_int32, ct.POINTER(ct.c_char_p), P, P, P, P, P, ct.c_int64,
                                         ct.POINTER(AlnCols)]
         lib.mpn_hits_finish.restype = ct.c_int64
@@ -446,11 +448,13 @@ class Hits:
     """Hits of one batch of reads accumulated over the parts of a split index (minimap2 -I), merged by finish()
     the way minimap2 --split-prefix merges its per-part dumps."""
 
-    def __init__(self, packed):
+    def __init__(self, packed, want_text=True):
         self.packed = packed
         self.h = _bind().mpn_hits_create(packed.n)
         if not self.h:
             raise _ffi.MpnError('mpn_hits_create: ' + _ffi.last_error())
+        if not want_text:   # columns only at finish(): the CIGARs of the parts' hits never leave the GPU
+            _bind().mpn_hits_set_text(self.h, 0)
 
     def add_part(self, idx, opt, use_device=True):
         p = self.packed

@@ -60,7 +60,7 @@ def align_and_assign(idx, opt, packed, tax, error_rate=0.05, ratio=0.05, as_thre
     if isinstance(idx, (list, tuple)):
         # a target set held as several index parts (minimap2 -I): every part is mapped, the hits are merged per read like
         # minimap2 --split-prefix merges them (mapper.Hits); column `rid` indexes the concatenated target list
-        hits = mapper.Hits(packed)
+        hits = mapper.Hits(packed, want_text=False)
         try:
             hits.add_parts(list(idx), opt, use_device=use_device)      # all parts are resident: one call, one pipeline
             _, _, c = hits.finish(opt, want_paf=False, want_cols=True)
