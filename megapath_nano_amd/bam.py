@@ -347,13 +347,14 @@ def write_bam(path, header_text, ref_names, ref_lens, records, level=-1, index_p
         bai.write(index_path)
 
 
-def sam_to_sorted_bam(sam_path, bam_path, exclude_flags=0, level=-1, index=True, sort_keys=None):
+def sam_to_sorted_bam(sam_path, bam_path, exclude_flags=0, level=-1, index=True, sort_keys=None, native=True, batch_bytes=64 << 20):
     """`samtools view -F <exclude_flags> -b | samtools sort; samtools index`: keep the records without any of the flags, order them
     by (reference, position, strand) with the unplaced ones last -- a stable sort, like samtools' -- and write BAM + .bai.
 
     The SAM text of a run is tens of GB: only a key (reference, position, strand) and the line's place in the file are kept per
     record; the lines are read back in sorted order and encoded as they are written.  sort_keys(tid, pos, rev) -> order may
-    replace the host sort (megapath_nano_amd.abundance.device_sort_order runs it on the GPU)."""
+    replace the host sort (megapath_nano_amd.abundance.device_sort_order runs it on the GPU).  native: the records are encoded by
+    libmpn.so (mpn_bam_encode, all host cores) instead of encode_record; the two are compared byte for byte in tests/test_bam.py."""
     import numpy as np
     header = []
     tids, poss, revs, offs, lens_ = [], [], [], [], []
@@ -392,13 +393,88 @@ def sam_to_sorted_bam(sam_path, bam_path, exclude_flags=0, level=-1, index=True,
     ref_str = {n_: i for i, n_ in enumerate(names)}
     offs_a, lens_a = np.asarray(offs, dtype=np.int64), np.asarray(lens_, dtype=np.int64)
 
-    def records():
+    def records_python():
         with open(sam_path, 'rb') as f:
             for k in order:
                 f.seek(int(offs_a[k]))
                 yield encode_record(f.read(int(lens_a[k])).decode().rstrip('\n').split('\t'), ref_str)
 
+    def records():
+        # the lines of a batch, in sorted order, through the native encoder (include/mpn_bam.h: the same encoding as
+        # encode_record above, in C, over all host cores): a run has millions of records
+        enc = NativeEncoder(names)
+        try:
+            with open(sam_path, 'rb') as f:
+                k0 = 0
+                while k0 < len(order):
+                    k1, size = k0, 0
+                    while k1 < len(order) and (size < batch_bytes or k1 == k0):
+                        size += int(lens_a[order[k1]])
+                        k1 += 1
+                    lines = []
+                    for k in order[k0:k1]:
+                        f.seek(int(offs_a[k]))
+                        lines.append(f.read(int(lens_a[k])))
+                    yield from enc.encode(lines)
+                    k0 = k1
+        finally:
+            enc.close()
+
     hd = '@HD\tVN:1.6\tSO:coordinate\n'
     body = ''.join(l for l in header if not l.startswith('@HD'))
-    write_bam(bam_path, hd + body, names, lens, records(), level=level, index_path=bam_path + '.bai' if index else None)
+    write_bam(bam_path, hd + body, names, lens, records() if native else records_python(), level=level,
+              index_path=bam_path + '.bai' if index else None)
     return len(order)
+
+
+class NativeEncoder:
+    """SAM lines -> BAM records through libmpn.so (mpn_bam_encode); yields what encode_record yields."""
+
+    def __init__(self, ref_names):
+        import ctypes as ct
+        from . import _ffi
+        self.ct, self._ffi = ct, _ffi
+        lib = _ffi.lib()
+        lib.mpn_bam_encoder_create.argtypes = [ct.POINTER(ct.c_char_p), ct.c_int32]
+        lib.mpn_bam_encoder_create.restype = ct.c_void_p
+        lib.mpn_bam_encoder_destroy.argtypes = [ct.c_void_p]
+        lib.mpn_bam_encoder_destroy.restype = None
+        lib.mpn_bam_encode.argtypes = [ct.c_void_p, ct.c_char_p] + [ct.c_void_p] * 2 + [ct.c_int64, ct.c_void_p, ct.c_int64] + [ct.c_void_p] * 5
+        lib.mpn_bam_encode.restype = ct.c_int64
+        self.lib = lib
+        arr = (ct.c_char_p * max(1, len(ref_names)))(*[n_.encode() for n_ in ref_names])
+        self.h = lib.mpn_bam_encoder_create(arr, len(ref_names))
+        if not self.h:
+            raise _ffi.MpnError('mpn_bam_encoder_create: ' + _ffi.last_error())
+
+    def encode(self, lines):
+        """lines: list of bytes (one SAM line each) -> list of (tid, pos0, end0, flag, record bytes)"""
+        import numpy as np
+        n = len(lines)
+        if n == 0:
+            return []
+        text = b''.join(lines)
+        lens = np.fromiter((len(l) for l in lines), dtype=np.int32, count=n)
+        offs = np.zeros(n, dtype=np.int64)
+        np.cumsum(lens[:-1], out=offs[1:])
+        rec_off = np.zeros(n + 1, dtype=np.int64)
+        tid, pos0, end0, flag = (np.zeros(n, dtype=np.int32) for _ in range(4))
+        cap = len(text) + 64 * n + 1024
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            r = self.lib.mpn_bam_encode(self.h, text, offs.ctypes.data, lens.ctypes.data, n, out.ctypes.data, cap, rec_off.ctypes.data,
+                                        tid.ctypes.data, pos0.ctypes.data, end0.ctypes.data, flag.ctypes.data)
+            if r == -3:
+                cap = int(rec_off[n]) + 1024
+                continue
+            if r < 0:
+                raise ValueError('mpn_bam_encode: ' + self._ffi.last_error())
+            break
+        buf = out.tobytes()
+        ro = rec_off.tolist()
+        return [(int(tid[i]), int(pos0[i]), int(end0[i]), int(flag[i]), buf[ro[i]:ro[i + 1]]) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.lib.mpn_bam_encoder_destroy(self.h)
+            self.h = None

@@ -142,3 +142,37 @@ def test_threaded_bgzf_index_points_at_record_starts_and_long_cigars_use_cg(tmp_
     assert lr['cigar'] == [n_ops << 4 | 4, 35001 << 4 | 3]
     assert lr['aux'][:8] == b'CGBI' + struct.pack('<I', n_ops) and len(lr['aux']) == 8 + 4 * n_ops
     assert struct.unpack_from('<3I', lr['aux'], 8) == (1 << 4 | 0, 1 << 4 | 1, 1 << 4 | 0)
+
+
+def test_native_record_encoder_equals_the_python_one():
+    """mpn_bam_encode (csrc/bam_records.cpp, what Align() uses for a run's millions of records) against bam.encode_record, which
+    htslib's own test data pin above: byte for byte on htslib's index.sam, on every optional-field type and on a CIGAR beyond 65535
+    operations."""
+    lines, names = [], []
+    with open(os.path.join(G, 'index.sam')) as f:
+        for l in f:
+            if l.startswith('@SQ'):
+                names.append(dict(x.split(':', 1) for x in l.rstrip('\n').split('\t')[1:])['SN'])
+            elif not l.startswith('@') and l.strip():
+                lines.append(l)
+    names += ['t1', 't2']
+    n_ops = 70001
+    lines += ['r1\t0\tt2\t10\t60\t5M\t=\t7\t-3\tACGTA\tIIIII\tNM:i:0\tAS:i:10\tde:f:0.0123\ttp:A:P\tXB:B:c,-1,2,3\tXS:B:S,1,65535\tXF:B:f,0.5,1.25\tXH:H:1AE3\n',
+              'r2\t16\tt1\t100\t30\t2S3M\tt2\t1\t0\tacgtn\t*\tNM:i:-3\tSA:Z:t2,1,+,5M,60,0;\tXI:i:-40000\tXJ:i:-3000000\tXK:i:70000\tXL:i:300\n',
+              'r3\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n',
+              'r4\t0\tunknown_ref\t5\t1\t3M1D2M1N4M\t*\t0\t0\tACGTACGTA\t*\n',
+              'long\t0\tt1\t5\t60\t' + '1M1I' * 35000 + '1M' + '\t*\t0\t0\t' + 'A' * n_ops + '\t*\n']
+    ref_id = {n_: i for i, n_ in enumerate(names)}
+    want = [bam.encode_record(l.rstrip('\n').split('\t'), ref_id) for l in lines]
+    enc = bam.NativeEncoder(names)
+    got = enc.encode([l.encode() for l in lines])
+    enc.close()
+    assert len(got) == len(want) >= 10
+    for g, w, l in zip(got, want, lines):
+        assert g == w, l[:60]
+    with pytest.raises(ValueError):
+        e2 = bam.NativeEncoder(names)
+        try:
+            e2.encode([b'bad\t0\tt1\t1\t0\t3M\t*\t0\t0\tACG\tIII\tXX:q:1\n'])
+        finally:
+            e2.close()
