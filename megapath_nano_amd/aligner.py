@@ -210,6 +210,13 @@ class MappedBatch:
         self.target_names, self.target_lens = target_names, target_lens
 
 
+class _ReadTable:
+    """What stays of a batch of reads once its text has been handed over: names and lengths (the sequences leave memory)."""
+
+    def __init__(self, names, lens):
+        self.names, self.lens, self.n = names, lens, len(names)
+
+
 class _Results(list):
     """The MappedBatch list of map_files.  With a sink every batch is handed over as soon as it is final and its text is
     dropped (a run of configs[2]'s size has tens of GB of SAM text); the integer columns stay."""
@@ -227,6 +234,7 @@ class _Results(list):
         if self.on_batch:
             self.on_batch(b)
             b.paf = b.sam = None
+            b.packed = _ReadTable(b.packed.names, b.packed.lens)   # (the table of the batch's rows needs names and lengths only)
         super().append(b)
 
 
@@ -242,95 +250,136 @@ def map_files(target_paths, query_paths, options, want_paf=True, want_sam=False,
     out_opt = mapper.MapOpt.from_buffer_copy(bytes(opt))
     out_opt.out_sam = (2 if want_paf else 1) if want_sam else 0
     text_wanted = want_paf or want_sam
-    batches = list(iter_read_batches(query_paths, read_batch_bases))
     results, header = _Results(on_batch, on_header), None
 
-    def single(idx):
+    def map_single(idx, b, names, lens):
+        text, sam, cols = mapper.map_batch_full(idx, out_opt, b, want_paf=text_wanted, want_cols=want_cols)
+        if want_sam and not want_paf:
+            text, sam = None, text
+        results.append(MappedBatch(b, text, sam, cols, names, lens))
+
+    def stream_one(idx):
+        """The whole target set is this ONE index (the usual case on an accelerator whose memory holds tens of Gbp of targets):
+        read batches are read, mapped, handed over and dropped one at a time -- a run's FASTQ never sits in memory as a whole."""
         nonlocal header
-        if want_sam:
+        names, lens = np.array(idx.names, dtype=object), idx.lens
+        n_batches = 0
+        for b in iter_read_batches(query_paths, read_batch_bases):
+            n_batches += 1
+            if options.split:       # --split-prefix: minimap2 takes its merge path even for one part
+                h = mapper.Hits(b)
+                try:
+                    h.add_part(idx, opt)
+                    if n_batches == 1 and want_sam:
+                        header = h.sam_header()
+                        results.header(header)
+                    _finish_hits([h], out_opt, want_paf, want_sam, want_cols, results)
+                finally:
+                    h.close()
+            else:
+                if n_batches == 1 and want_sam:
+                    header = idx.sam_header()
+                    results.header(header)
+                map_single(idx, b, names, lens)
+        if n_batches == 0 and want_sam:
             header = idx.sam_header()
             results.header(header)
-        names, lens = np.array(idx.names, dtype=object), idx.lens
-        for b in batches:
-            text, sam, cols = mapper.map_batch_full(idx, out_opt, b, want_paf=text_wanted, want_cols=want_cols)
-            if want_sam and not want_paf:
-                text, sam = None, text
-            results.append(MappedBatch(b, text, sam, cols, names, lens))
 
-    if _is_saved_index(target_paths):
-        # a saved index may hold several parts (minimap2 -d dumps every part of a -I split into the one file): they are loaded
-        # one at a time, like the parts of a FASTA target
-        idx = _INDEX_CACHE.get(cache_key) if cache_key else None
-        parts = [idx] if idx is not None else mapper.Index.iter_parts(target_paths[0])
+    def all_parts(parts):
+        """Several index parts that are built (or loaded) one after another and dropped again: every read batch meets every part,
+        so the batches are kept (their hits accumulate per batch: mapper.Hits) while the parts stream by."""
+        nonlocal header
+        batches = list(iter_read_batches(query_paths, read_batch_bases))
         hits = [mapper.Hits(b) for b in batches] if options.split else None
-        n_parts, first_header = 0, None
-        for idx in parts:
-            n_parts += 1
-            if hits is not None:
-                for h in hits:
-                    h.add_part(idx, opt)
-            else:
-                single(idx)
-                first_header = first_header if first_header is not None else header
-            if cache_key and n_parts == 1:
-                _INDEX_CACHE[cache_key] = idx      # (kept only when it turns out to be the only part)
-                kept = idx
-            else:
-                if n_parts == 2 and cache_key:
-                    _INDEX_CACHE.pop(cache_key, None)
-                    kept.close()
+        headers, n_parts = [], 0
+        try:
+            for idx in parts:
+                n_parts += 1
+                if hits is not None:
+                    for h in hits:
+                        h.add_part(idx, opt)
+                else:   # without --split-prefix minimap2 reports every part on its own
+                    if want_sam:
+                        header = idx.sam_header()
+                        results.header(header)
+                        headers.append(header)
+                    names, lens = np.array(idx.names, dtype=object), idx.lens
+                    for b in batches:
+                        map_single(idx, b, names, lens)
                 idx.close()
-        if hits is not None:
-            header = hits[0].sam_header() if (want_sam and hits) else None
-            results.header(header)
-            _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
-            for h in hits:
+            if hits is not None:
+                if want_sam:
+                    header = hits[0].sam_header() if hits else ''
+                    results.header(header)
+                _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
+            elif headers:
+                header = headers[0]
+        finally:
+            for h in hits or []:
                 h.close()
-        else:
-            header = first_header
-        return results, header
-
-    hits = [mapper.Hits(b) for b in batches] if options.split else None
-    headers = []
-
-    def use(idx):
-        if hits is not None:
-            for h in hits:
-                h.add_part(idx, opt)
-        else:
-            single(idx)
-            headers.append(header)
 
     cached = _INDEX_CACHE.get(cache_key) if cache_key else None
     if cached is not None:
-        use(cached)
-    else:
-        prev, n_parts = None, 0
-        for part in iter_target_parts(iter_target_records(target_paths), options.batch_bases):
-            if prev is not None:   # a part's index leaves HBM before the next one is built
-                prev.close()
-            idx = mapper.Index(part, k=options.k, w=options.w)
-            del part
-            n_parts += 1
-            if save_index:
-                # minimap2 -d FILE dumps every part into the one file (bin/megapath_nano.py:1641-1645): so does this
-                idx.save(save_index, append=n_parts > 1)
-            use(idx)
-            prev = idx
-        if prev is not None:
-            if cache_key and n_parts == 1:
-                _INDEX_CACHE[cache_key] = prev
+        stream_one(cached)
+        return results, header
+    if _is_saved_index(target_paths):
+        # a saved index may hold several parts (minimap2 -d dumps every part of a -I split into the one file): they are loaded
+        # one at a time, like the parts of a FASTA target
+        first, nxt = mapper.Index.load_at(target_paths[0], 0)
+        if nxt < 0:
+            stream_one(first)
+            if cache_key:
+                _INDEX_CACHE[cache_key] = first
             else:
-                prev.close()
-    if hits is not None:
-        if want_sam:
-            header = hits[0].sam_header() if hits else ''
-            results.header(header)
-        _finish_hits(hits, out_opt, want_paf, want_sam, want_cols, results)
-        for h in hits:
-            h.close()
-    elif headers:
-        header = headers[0]
+                first.close()
+        else:
+            def rest():
+                off = nxt
+                yield first
+                while off >= 0:
+                    part, off = mapper.Index.load_at(target_paths[0], off)
+                    yield part
+            all_parts(rest())
+        return results, header
+
+    raw_parts = iter_target_parts(iter_target_records(target_paths), options.batch_bases)
+    n_built = 0
+
+    def build(part):
+        nonlocal n_built
+        idx = mapper.Index(part, k=options.k, w=options.w)
+        n_built += 1
+        if save_index:
+            # minimap2 -d FILE dumps every part into the one file (bin/megapath_nano.py:1641-1645): so does this
+            idx.save(save_index, append=n_built > 1)
+        return idx
+
+    first = next(raw_parts, None)
+    if first is None:
+        all_parts(iter(()))
+        return results, header
+    idx = build(first)
+    del first
+    second = next(raw_parts, None)    # (the target stream is read on while the first index is resident: only its raw records are held)
+    if second is None:
+        stream_one(idx)
+        if cache_key:
+            _INDEX_CACHE[cache_key] = idx
+        else:
+            idx.close()
+        return results, header
+
+    def built():
+        nonlocal second
+        yield idx
+        part = second
+        second = None
+        while part is not None:
+            nxt_idx = build(part)
+            del part
+            yield nxt_idx
+            part = next(raw_parts, None)
+    all_parts(built())
     return results, header
 
 
