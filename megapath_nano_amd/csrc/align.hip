@@ -37,7 +37,9 @@ namespace mpn {
 int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32_t *seq_len, DevBuf<uint8_t> &d_seqs,
                 DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_len, int64_t *total_bases, hipStream_t st);
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
-                      const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st);
+                      const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st, const ReadSketch *pre);
+int sketch_reads(int k, int w, int n, const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len, const int32_t *h_len, ReadSketch &sk,
+                 hipStream_t st);
 int download_chains(int n, SeedChainOut &o, HostChains &h, PoolBuf &pin_u, PoolBuf &pin_b, hipStream_t st, int mode);
 int download_chain_records(SeedChainOut &o, HostChains &h, PoolBuf &pin_u, hipStream_t st);
 
@@ -842,7 +844,14 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     struct { int32_t *p; } d_order{SL.pool_order.as<int32_t>()};
     // (bucket counters and the totals block are neighbours in one pool: one fill clears both; the padding of the strip lists
     // is written by the scan kernel)
-    MPN_HIP_CHECK(hipMemsetAsync(d_bcnt, 0, (size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals), st));
+    {   // one launch zeroes the bucket counters + totals and this group's two list counters (the other counters of the round's block
+        // were zeroed with it at the start of the round)
+        ZeroList z{};
+        zero_list_push(z, d_bcnt, (size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals));
+        zero_list_push(z, dv.used + 1, 8);
+        zero_list_push(z, dv.used + 5, 8);
+        MPN_HIP_CHECK(zero_regions(z, st));
+    }
     const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256));   // (a block per CU: every block flushes its counters once)
     EvTimer evl(st);
     hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, prm, g_force_kernel, d_sizes, d_bcnt, d_tot);
@@ -914,8 +923,6 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     unsigned long long *d_used = dv.used;   // [0] operations in the compact pool (the whole round), [1] windows listed for the second pass (this group)
     int32_t *d_redo_ids = SL.pool_redo_ids.as<int32_t>();
     InvProbe *d_probes = SL.pool_probes.as<InvProbe>();
-    MPN_HIP_CHECK(hipMemsetAsync(d_used + 1, 0, 8, st));
-    MPN_HIP_CHECK(hipMemsetAsync(d_used + 5, 0, 8, st));
     // one launch of launch list `l` over ord[0..n)
     auto launch_list = [&](int l, const int32_t *ord, int n, hipStream_t s) -> int {
         if (n == 0) return 0;
@@ -1124,14 +1131,18 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
 // Run the DP windows whose raw job records the caller has put at the start of the worker's job pool (SL.pool_jobs), in groups
 // whose direction scratch stays under the budget (MPN_DP_BUDGET bytes, for tests).  The job records, results and compacted
 // CIGARs of ALL groups stay in the worker's device pools (out); a group only borrows the direction-matrix scratch.
+// block_zeroed: the caller has zeroed the whole counter block of the round (and the planning kernel has counted into [3] since)
 static int run_jobs(const RefView &rv, const mpn_map_opt *opt, int nj_cap, const uint8_t *d_reads, const int64_t *d_read_off,
-                    const int32_t *d_read_len, DevRound &out, const HostSeqs *hs, hipStream_t st) {
+                    const int32_t *d_read_len, DevRound &out, const HostSeqs *hs, hipStream_t st, bool block_zeroed = false) {
     static const int64_t budget = []() { const char *e = getenv("MPN_DP_BUDGET"); return e ? std::max<int64_t>(1 << 20, atoll(e)) : (int64_t)40 << 30; }();
     Slot &SL = *tl_slot;
     if (SL.pool_res.ensure((size_t)nj_cap * sizeof(ExtRes) + 16) || SL.pool_used.ensure(128)) return -1;
     out.jobs = SL.pool_jobs.as<ExtJob>(); out.res = SL.pool_res.as<ExtRes>(); out.compact = nullptr;
     out.used = SL.pool_used.as<unsigned long long>();   // [0] compacted ops, [1] second-pass windows, [2] stitched ops, [3] windows of the round, [4] of a sub-range
-    MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 24, st));
+    if (!block_zeroed) {   // [0..2] and [5..7]; [3], [4] carry the window counts
+        MPN_HIP_CHECK(hipMemsetAsync(out.used, 0, 24, st));
+        MPN_HIP_CHECK(hipMemsetAsync(out.used + 5, 0, 24, st));
+    }
     const int rc = run_job_group(rv, opt, nj_cap, out.used + 3, out, d_reads, d_read_off, d_read_len, budget, hs, st);
     if (rc != 1) return rc;
     // over the budget: cut the range where the direction matrices (their offsets are in the size table) fill it
@@ -1174,7 +1185,7 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     const int n_sr = sr_base[(size_t)n];
     if (n_sr == 0) return 0;
     Slot &SL = *tl_slot;
-    if (SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut) + sizeof(SplitRec)) + 64) ||
+    if (SL.pin_fin_out.ensure((size_t)n_sr * (sizeof(StitchOut) + sizeof(FinOut) + sizeof(SplitRec)) + 128) ||
         SL.pool_souts.ensure((size_t)n_sr * sizeof(StitchOut) + 16) || SL.pool_splits.ensure((size_t)n_sr * sizeof(SplitRec) + 16) ||
         SL.pool_fin_jobs.ensure((size_t)n_sr * sizeof(FinJob) + 16) || SL.pool_fin_out.ensure((size_t)n_sr * sizeof(FinOut) + 16) ||
         SL.pool_fin_cig.ensure((size_t)dv.cig_cap * 4 + 16))
@@ -1186,13 +1197,11 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     unsigned long long *d_out_used = dv.used + 2;
     StitchOut *h_so = SL.pin_fin_out.as<StitchOut>();
     FinOut *h_fo = reinterpret_cast<FinOut *>(h_so + n_sr);
-    unsigned long long *h_out_used = reinterpret_cast<unsigned long long *>(h_fo + n_sr);   // [stitched ops, cut hits]
-    SplitRec *h_splits = reinterpret_cast<SplitRec *>(h_out_used + 2);
+    unsigned long long *h_out_used = reinterpret_cast<unsigned long long *>(h_fo + n_sr);   // the counter block as read back
+    SplitRec *h_splits = reinterpret_cast<SplitRec *>(h_out_used + 8);
     SplitRec *d_splits = SL.pool_splits.as<SplitRec>();
     unsigned long long *d_n_splits = dv.used + 6;
     EvTimer ev(st);
-    MPN_HIP_CHECK(hipMemsetAsync(d_out_used, 0, 8, st));
-    MPN_HIP_CHECK(hipMemsetAsync(d_n_splits, 0, 8, st));
     ev.skip();
     hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)std::min(n_sr, 256 * 32)), dim3(64), 0, st, rd.sregs, n_sr, (const ExtJob *)dv.jobs,
                        (const ExtRes *)dv.res, (const uint32_t *)dv.compact, d_cig, d_out_used, d_so, d_fj, rd.pregs, rd.psum, rd.job_anchor, rd.anchors,
@@ -1200,12 +1209,12 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(54);
     MPN_HIP_CHECK(hipMemcpyAsync(h_so, d_so, (size_t)n_sr * sizeof(StitchOut), hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(h_out_used, d_out_used, 8, hipMemcpyDeviceToHost, st));
-    MPN_HIP_CHECK(hipMemcpyAsync(h_out_used + 1, d_n_splits, 8, hipMemcpyDeviceToHost, st));
+    MPN_HIP_CHECK(hipMemcpyAsync(h_out_used, dv.used, 64, hipMemcpyDeviceToHost, st));   // the round's counter block: [2] stitched ops, [6] cut hits
     MPN_HIP_CHECK(stream_sync(st));
-    const int64_t n_ops = (int64_t)*h_out_used;
-    if (h_out_used[1]) {   // (the cut hits' records: rare)
-        MPN_HIP_CHECK(hipMemcpyAsync(h_splits, d_splits, (size_t)h_out_used[1] * sizeof(SplitRec), hipMemcpyDeviceToHost, st));
+    const int64_t n_ops = (int64_t)h_out_used[2];
+    const unsigned long long n_cut = h_out_used[6];
+    if (n_cut) {   // (the cut hits' records: rare)
+        MPN_HIP_CHECK(hipMemcpyAsync(h_splits, d_splits, (size_t)n_cut * sizeof(SplitRec), hipMemcpyDeviceToHost, st));
         MPN_HIP_CHECK(stream_sync(st));
     }
     // hits: coordinates, score, splits at z-drops
@@ -1298,7 +1307,7 @@ static int stitch_and_finish(const mpn_index *idx, const mpn_map_opt *opt, ReadS
 static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *const *names, const char *seqs,
                      const int64_t *seq_off_all, const int32_t *seq_len_all, const uint8_t *d_seqs_p, const int64_t *d_off_all,
                      const int32_t *d_len_all, const uint32_t *d_name_hash_all, int lo, int hi, int n_threads, hipStream_t st,
-                     std::vector<ReadState> &rs_all, std::vector<int32_t> &rep_len_all) {
+                     std::vector<ReadState> &rs_all, std::vector<int32_t> &rep_len_all, const ReadSketch *sketch) {
     const int n = hi - lo;
     if (n <= 0) return 0;
     const int64_t *seq_off = seq_off_all + lo;
@@ -1323,7 +1332,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
         };
         static StageGate gate;
         struct Hold { StageGate &g; Hold(StageGate &x) : g(x) { g.enter(); } ~Hold() { g.leave(); } } hold(gate);
-        if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
+        if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st, sketch)) return -1;
         wt.stop_into(g_stats[17]);
         // MPN_HOST_HITS=1 (tests): hits from chains on the host for every read, from the downloaded chain records
         static const bool host_hits = []() { const char *e = getenv("MPN_HOST_HITS"); return e && atoi(e) != 0; }();
@@ -1498,7 +1507,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             ExtJob *d_jobs = SL.pool_jobs.as<ExtJob>();
             int32_t *d_janchor = SL.pool_job_anchor.as<int32_t>();
             unsigned long long *d_used = SL.pool_used.as<unsigned long long>();
-            MPN_HIP_CHECK(hipMemsetAsync(d_used + 3, 0, 8, st));
+            MPN_HIP_CHECK(hipMemsetAsync(d_used, 0, 64, st));   // every counter of the round in one fill
             MPN_HIP_CHECK(hipMemcpyAsync(d_pr, h_pr, (size_t)n_sr * sizeof(PlanReg), hipMemcpyHostToDevice, st));
             EvTimer evp(st);
             hipLaunchKernelGGL(plan_kernel, dim3((unsigned)std::min(n_sr, 256 * 4)), dim3(64), 0, st, po, (const PlanReg *)d_pr, n_sr, d_a.p,
@@ -1508,7 +1517,7 @@ static int map_range(const mpn_index *idx, const mpn_map_opt *opt, const char *c
             wt.stop_into(g_stats[20]);
             ++g_stats[7];
             DevRound dv;
-            if (run_jobs(rv, opt, nj_cap, d_seqs.p, d_off.p, d_len.p, dv, &hseqs, st)) return -1;
+            if (run_jobs(rv, opt, nj_cap, d_seqs.p, d_off.p, d_len.p, dv, &hseqs, st, true)) return -1;
             evp.resolve();
             if (!dv.compact) {   // (a round without any window: the stitching kernel still sets the hits' coordinates)
                 if (SL.pool_compact.ensure(64)) return -1;
@@ -1728,7 +1737,7 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
         cut.push_back(n);
     }
     const int n_sub = (int)cut.size() - 1;
-    const int n_items = n_sub * n_parts;   // item k: sub-batch k / n_parts against part k % n_parts
+    const int n_items = n_sub;   // a work item is a sub-batch: its worker maps it against every part in turn, on ONE sketch of its reads
     n_workers = std::max(1, std::min(n_workers, n_items));
     {
         // every worker holds its own scratch (direction matrices above all): about 400 bytes per base of a sub-batch
@@ -1800,8 +1809,23 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
             memcpy(stats_before, g_stats, sizeof(stats_before));
             const double t_in = since();
             struct Out { bool on; int wid, sb; double t_in; decltype(since) &f; ~Out() { if (on) fprintf(stderr, "[worker %d] sub-batch %d: %.1f -> %.1f ms\n", wid, sb, t_in, f()); } } out_{dbg_workers, wid, sb, t_in, since};
-            const int sbi = sb / n_parts, prt = sb % n_parts;
-            if (map_range(parts[prt], opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, d_name_hash.p, cut[sbi], cut[sbi + 1], n_threads, S.st, rs[(size_t)prt], rep_len[(size_t)prt])) {
+            int rc_item = 0;
+            {
+                ReadSketch sk;
+                const int sbi = sb, nr = cut[sbi + 1] - cut[sbi];
+                if (n_parts > 1 && nr > 0) {
+                    WallTimer wts;
+                    rc_item = sketch_reads(parts[0]->k, parts[0]->w, nr, dv.p, dv.po + cut[sbi], dv.pl + cut[sbi], seq_len + cut[sbi], sk, S.st);
+                    wts.stop_into(g_stats[17]);
+                }
+                const Arena::Mark after_sketch = S.arena.mark();
+                for (int prt = 0; prt < n_parts && !rc_item; ++prt) {
+                    S.arena.rewind(after_sketch);   // (what the previous part took is dead; the sketch stays)
+                    rc_item = map_range(parts[prt], opt, names, seqs, seq_off, seq_len, dv.p, dv.po, dv.pl, d_name_hash.p, cut[sbi], cut[sbi + 1], n_threads, S.st,
+                                        rs[(size_t)prt], rep_len[(size_t)prt], sk.valid ? &sk : nullptr);
+                }
+            }
+            if (rc_item) {
                 std::lock_guard<std::mutex> g(mu);
                 // Out of device memory: the workers' scratch grows with what the target set throws at them (a strain-rich index
                 // yields tens of times the anchors of a random one), and the up-front estimate can be too low.  This worker gives

@@ -85,4 +85,22 @@ struct ReadCursor {
     }
 };
 
+// Several small regions zeroed by ONE launch (counters, cursors and flag arrays of a stage: a hipMemsetAsync each is a launch and a
+// completion signal each).  Sizes in 4-byte words; block b works on region b % n.
+struct ZeroList { uint32_t *p[8]; uint32_t words[8]; int n; };
+static __global__ __launch_bounds__(256) void zero_regions_kernel(ZeroList z) {
+    const int r = blockIdx.x % z.n, part = blockIdx.x / z.n, parts = gridDim.x / z.n;
+    for (uint32_t i = part * 256 + threadIdx.x; i < z.words[r]; i += parts * 256) z.p[r][i] = 0;
+}
+inline void zero_list_push(ZeroList &z, void *p, size_t bytes) {
+    if (!p || !bytes) return;
+    z.p[z.n] = (uint32_t *)p; z.words[z.n] = (uint32_t)((bytes + 3) / 4); ++z.n;
+}
+inline hipError_t zero_regions(ZeroList &z, hipStream_t st) {
+    if (z.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_regions_kernel, dim3((unsigned)z.n * 4), dim3(256), 0, st, z);
+    return hipGetLastError();
+}
+
+
 }  // namespace mpn

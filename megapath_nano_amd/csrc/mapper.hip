@@ -200,14 +200,31 @@ int upload_seqs(int32_t n, const char *seqs, const int64_t *seq_off, const int32
     return 0;
 }
 
-// seeds -> sorted anchors -> chains for a batch resident on the device
+// the sketch of a batch of reads on its own (shared by the index parts a sub-batch is mapped against)
+int sketch_reads(int k, int w, int n, const uint8_t *d_seqs, const int64_t *d_off, const int32_t *d_len, const int32_t *h_len, ReadSketch &sk,
+                 hipStream_t st) {
+    EvTimer ev(st);
+    sk.valid = false;
+    if (sketch_device(d_seqs, d_off, d_len, h_len, n, k, w, 0, sk.mz_off, sk.mz, &sk.n_mz, st, &ev)) return -1;
+    MPN_HIP_CHECK(stream_sync(st));
+    ev.resolve();
+    sk.k = k; sk.w = w; sk.valid = true;
+    return 0;
+}
+
+// seeds -> sorted anchors -> chains for a batch resident on the device; pre: the batch's sketch if the caller has it (same k, w)
 int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const uint8_t *d_seqs, const int64_t *d_off,
-                      const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st) {
+                      const int32_t *d_len, const int32_t *h_len, SeedChainOut &o, hipStream_t st, const ReadSketch *pre) {
     int64_t n_mz = 0;
     DevBuf<int64_t> mz_off;
     DevBuf<u128> mz;
     EvTimer ev(st);
-    if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st, &ev)) return -1;
+    if (pre && pre->valid && pre->k == idx->k && pre->w == idx->w) {
+        // (views of the caller's buffers: nothing is copied, nothing is released here)
+        mz_off.p = pre->mz_off.p; mz_off.n = pre->mz_off.n; mz_off.owned = false;
+        mz.p = pre->mz.p; mz.n = pre->mz.n; mz.owned = false;
+        n_mz = pre->n_mz;
+    } else if (sketch_device(d_seqs, d_off, d_len, h_len, n, idx->k, idx->w, 0, mz_off, mz, &n_mz, st, &ev)) return -1;
     g_stats[1] += n_mz;
     int32_t mid_occ = opt->mid_occ > 0 ? opt->mid_occ : mpn_index_mid_occ(idx, opt->mid_occ_frac);
     if (mid_occ > (1 << 25)) {
@@ -251,9 +268,23 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     DevBuf<int64_t> blk_kept, blk_off;
     DevBuf<int32_t> blk_read, order;
     DevBuf<unsigned int> next_read;
-    if (next_read.alloc(4) || next_read.zero(st) || order.alloc(n) || keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
-        blk_read.alloc((size_t)nb_cap + 1) || blk_kept.zero(st))
+    // the counters, cursors and flag arrays of the whole stage are allocated here and zeroed by ONE launch (regions must be sized
+    // in whole 4-byte words: all of them are arrays of 4- or 8-byte items)
+    DevBuf<unsigned int> n_list, seg_counters;
+    DevBuf<unsigned long long> read_kept;
+    if (next_read.alloc(4) || order.alloc(n) || keep.alloc((size_t)(n_full / 64 + nb_cap + 8)) || blk_kept.alloc((size_t)nb_cap + 1) || blk_off.alloc((size_t)nb_cap + 2) ||
+        blk_read.alloc((size_t)nb_cap + 1) || n_list.alloc(4) || seg_counters.alloc(4) || read_kept.alloc(n))
         return -1;
+    {
+        ZeroList z{};
+        zero_list_push(z, next_read.p, 4 * sizeof(unsigned int));
+        zero_list_push(z, blk_kept.p, ((size_t)nb_cap + 1) * 8);
+        zero_list_push(z, o.used.p, o.used.n * sizeof(unsigned long long));
+        zero_list_push(z, n_list.p, 4 * sizeof(unsigned int));
+        zero_list_push(z, seg_counters.p, 4 * sizeof(unsigned int));
+        zero_list_push(z, read_kept.p, (size_t)n * 8);
+        MPN_HIP_CHECK(zero_regions(z, st));
+    }
     if (nb_cap > 0x7fffffff) { set_error("sub-batch too large for the seed filter"); return -1; }
     if (mid_occ > (1 << 25)) { set_error("occurrence cut-off %d too large (a block of 64 minimizers must hold fewer than 2^32 hits)", mid_occ); return -1; }
     if (n_full > 0) {
@@ -289,7 +320,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     o.n_anchors = n_a;
     g_stats[51] += n_a;
     DevBuf<u128> tmp;
-    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n) || o.used.zero(st)) return -1;
+    if (o.anchors.alloc(n_a) || tmp.alloc(n_a) || o.n_ends.alloc(n)) return -1;
     ev.mark(11);
     if (n_a > 0) {
         // kept hits in (minimizer, hit) order -> tmp; partition per read on the top key bits -> o.anchors; small buckets are
@@ -312,11 +343,10 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
         // work lists of the buckets that are not sorted in place by the chunk kernel (more than SMALL_BUCKET anchors each)
         SortLists lists;
         DevBuf<SortSeg> list_mem;
-        DevBuf<unsigned int> n_list;
         {
             const int64_t c0 = n_a / (SMALL_BUCKET + 1) + (int64_t)n + 16, c1 = n_a / (BITONIC_SMALL + 1) + 16, c2 = n_a / (BITONIC_MID + 1) + 16;
             if (c0 > 0x7fffffff) { set_error("sub-batch too large for the anchor sort"); return -1; }
-            if (list_mem.alloc((size_t)(c0 + c1 + c2)) || n_list.alloc(4) || n_list.zero(st)) return -1;
+            if (list_mem.alloc((size_t)(c0 + c1 + c2))) return -1;
             lists.seg[0] = list_mem.p; lists.seg[1] = list_mem.p + c0; lists.seg[2] = list_mem.p + c0 + c1;
             lists.cap[0] = (unsigned int)c0; lists.cap[1] = (unsigned int)c1; lists.cap[2] = (unsigned int)c2;
             lists.count = n_list.p;
@@ -349,10 +379,9 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     // anchors of segments too short to chain are dropped; everything below runs on the compact list (c_off, tmp)
     const int64_t n_pieces = (n_a + COMPACT_PIECE - 1) / COMPACT_PIECE;
     DevBuf<int64_t> kept, piece_kept, piece_off;
-    DevBuf<unsigned long long> read_kept;
     DevBuf<float> avg_qspan;
     if (kept.alloc((size_t)n + 1) || o.c_off.alloc((size_t)n + 1) || avg_qspan.alloc(n) || piece_kept.alloc((size_t)n_pieces + 1) ||
-        piece_off.alloc((size_t)n_pieces + 1) || read_kept.alloc(n) || read_kept.zero(st))
+        piece_off.alloc((size_t)n_pieces + 1))
         return -1;
     const int gp = (int)std::max<int64_t>(1, std::min<int64_t>(n_pieces, 256 * 64));
     if (n_a > 0) {
@@ -383,10 +412,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     ev.mark(46);
     // work items of the chain DP: runs of whole independent segments of each read's anchor list, cut on the device
     DevBuf<ChainSeg> seg_big, seg_small;
-    DevBuf<unsigned int> seg_counters;
-    if (seg_big.alloc((size_t)n_c / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_c / CHAIN_ITEM + (size_t)n + 1) ||
-        seg_counters.alloc(4) || seg_counters.zero(st))
-        return -1;
+    if (seg_big.alloc((size_t)n_c / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_c / CHAIN_ITEM + (size_t)n + 1)) return -1;
     hipLaunchKernelGGL(chain_segments_kernel, dim3(g), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, n, cp, avg_qspan.p, 1, seg_big.p,
                        seg_small.p, seg_counters.p);
     MPN_HIP_CHECK(hipGetLastError());
@@ -965,7 +991,7 @@ int mpn_seed_chain_batch(const mpn_index *idx, const mpn_map_opt *opt, int32_t n
     if (upload_seqs(n, seqs, seq_off, seq_len, d_seqs, d_off, d_len, &bases, st)) return -1;
     g_stats[0] = bases;
     SeedChainOut o;
-    if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st)) return -1;
+    if (seed_chain_device(idx, opt, n, d_seqs.p, d_off.p, d_len.p, seq_len, o, st, nullptr)) return -1;
     HostChains h;
     PoolBuf pin_u{nullptr, 0, true}, pin_b{nullptr, 0, true};
     struct Free { PoolBuf &a, &b; ~Free() { a.release(); b.release(); } } free_pins{pin_u, pin_b};

@@ -56,6 +56,16 @@ struct SeedChainOut {
     DevBuf<unsigned long long> used;
 };
 
+// minimizers of a batch of reads that is resident on the device (mm_sketch of every read): index parts built with the same k, w
+// share it -- a sub-batch is sketched once, not once per part
+struct ReadSketch {
+    DevBuf<int64_t> mz_off;
+    DevBuf<u128> mz;
+    int64_t n_mz = 0;
+    int k = 0, w = 0;
+    bool valid = false;
+};
+
 struct HostChains {
     std::vector<int64_t> n_anchor, chain_off, b_off;    // per read: anchors found; prefix sums of chains and of chained anchors
     std::vector<int64_t> n_chained, u_pos, b_pos;       // per read: chained anchors; start in the compact pools

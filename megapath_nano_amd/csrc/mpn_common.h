@@ -55,6 +55,11 @@ struct Arena {
         }
         cur = 0; off = 0; used = 0;
     }
+    // what has been handed out up to here / back to there: the allocations made after mark() are dead (a worker maps one sub-batch
+    // against several index parts and keeps the sub-batch's sketch, taken before the mark, across them)
+    struct Mark { size_t cur, off, used; };
+    Mark mark() const { return Mark{cur, off, used}; }
+    void rewind(const Mark &m) { cur = m.cur; off = m.off; used = m.used; }
     // give everything back (a worker that leaves, or a slot that idles while the others need the memory)
     void release_all() {
         for (const Chunk &c : chunks) { (void)hipFree(c.p); g_arena_bytes -= (long long)c.cap; }

@@ -3,6 +3,7 @@ usage: python scripts/pmc_summary.py <out.json> <steps_profiled> <csv> [<csv> ..
 import collections
 import csv
 import json
+import os
 import sys
 
 out, steps = sys.argv[1], int(sys.argv[2])
@@ -25,6 +26,6 @@ for k, v in agg.items():
     if 'WRITE_SIZE' in d or 'FETCH_SIZE' in d:
         d['hbm_bytes_per_step'] = (d.get('WRITE_SIZE', 0) + d.get('FETCH_SIZE', 0)) * 1024
     res[k] = d
-json.dump(dict(steps_profiled=steps, note='per bench step (warm-up steps included in the average; set-up dispatches -- before the first seed lookup -- under setup:<kernel>, also divided by the steps); FETCH_SIZE uncorrected',
+json.dump(dict(steps_profiled=steps, config=os.environ.get('MPN_PMC_CONFIG', 'refseq'), note='per bench step (warm-up steps included in the average; set-up dispatches -- before the first seed lookup -- under setup:<kernel>, also divided by the steps); FETCH_SIZE uncorrected',
                kernels=res), open(out, 'w'), indent=1, sort_keys=True)
 print('wrote', out, len(res), 'kernels')
