@@ -423,20 +423,18 @@ __global__ __launch_bounds__(NT) void ext_dp_wg_kernel(const ExtJob *__restrict_
 // z-drop decision for r there (nothing of r+1 is computed before it).  Direction codes are stored by slot
 // ([r][t mod SL], one aligned 32-bit store per four cells); the traceback recomputes the band limits from r, so no
 // band-start/end arrays are written.
-template <int NW, int T>
-__global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                                              ExtParams prm, const uint8_t *__restrict__ reads,
-                                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                              RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
-    static_assert(T % 4 == 0 || T == 2, "T must be 2 or a multiple of 4");
+// APPROX: the bookkeeping of ksw2's approximate maximum (gap fills) or of the exact one (end extensions, exact fills): a workgroup
+// runs one window, so the kernel branches once per window into the instantiation that carries only its own bookkeeping.  A wave
+// none of whose slots lies in the band of an anti-diagonal (the band is at most 752 wide, the slots 1024) skips the cells and
+// only publishes its unchanged boundary: its issue slots go to the other kernels on the CU.
+template <int NW, int T, bool APPROX>
+__device__ __forceinline__ void ext_dp_band_body(const ExtJob &jb, const int jid, const ExtParams &prm, const uint8_t *__restrict__ reads,
+                                                 const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                 const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem,
+                                                 int (*bnd)[NW][4], int (*red)[NW][2], int (*pub)[4]) {
     constexpr int NT = NW * 64, SL = NT * T;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int bnd[2][NW][4];   // last slot of each wave after the anti-diagonal: v, x, x2, H
-    __shared__ int red[2][NW][2];   // per-wave best H and its tie-break key
-    __shared__ int pub[2][4];       // H[en], H[st], v[last_H0_t], u[last_H0_t + 1]
+    constexpr bool approx = APPROX;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int jid = order[blockIdx.x];
-    const ExtJob jb = jobs[jid];
     const int qlen = jb.qlen, tlen = jb.tlen;
     int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
     if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
@@ -449,7 +447,6 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
     if (w < 0) w = tlen > qlen ? tlen : qlen;
     uint8_t *qs_ = smem;
     uint8_t *ts_ = smem + ((qlen + 3) & ~3);
-    const bool approx = (jb.flag & EZ_APPROX_MAX) != 0;
     {
         const int64_t roff = read_off[jb.read];
         const int32_t rlen = read_len[jb.read];
@@ -457,9 +454,9 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
         const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
         for (int i = tid; i < tlen; i += NT) ts_[i] = (uint8_t)ref_code(rv, g0 + (jb.reversed ? tlen - 1 - i : i));
     }
-    int U[T], V[T], X[T], Y[T], X2[T], Y2[T], H[T];
+    int U[T], V[T], X[T], Y[T], X2[T], Y2[T], H[APPROX ? 1 : T];
 #pragma unroll
-    for (int k = 0; k < T; ++k) { U[k] = V[k] = X[k] = Y[k] = -qe; X2[k] = Y2[k] = -qe2; H[k] = NEG_INF; }
+    for (int k = 0; k < T; ++k) { U[k] = V[k] = X[k] = Y[k] = -qe; X2[k] = Y2[k] = -qe2; if constexpr (!APPROX) H[k] = NEG_INF; }
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
@@ -515,8 +512,13 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
         // old state of the slot to the left of this thread's first slot
         const int pw = (wv + NW - 1) % NW;
         int cv = 0, cx = 0, cx2 = 0, ch = 0;
-        if (r > 0 && lane == 0) { cv = bnd[par ^ 1][pw][0]; cx = bnd[par ^ 1][pw][1]; cx2 = bnd[par ^ 1][pw][2]; ch = bnd[par ^ 1][pw][3]; }
-        const int lv = wave_shr1(V[T - 1], cv), lx = wave_shr1(X[T - 1], cx), lx2 = wave_shr1(X2[T - 1], cx2), lh = wave_shr1(H[T - 1], ch);
+        if (r > 0 && lane == 0) { cv = bnd[par ^ 1][pw][0]; cx = bnd[par ^ 1][pw][1]; cx2 = bnd[par ^ 1][pw][2]; if constexpr (!APPROX) ch = bnd[par ^ 1][pw][3]; }
+        const int lv = wave_shr1(V[T - 1], cv), lx = wave_shr1(X[T - 1], cx), lx2 = wave_shr1(X2[T - 1], cx2);
+        int lh = 0;
+        if constexpr (!APPROX) lh = wave_shr1(H[T - 1], ch);
+        // does the band touch this wave's slots at all?  (its slots from the band's first one, modulo SL: [wa, wa + 64 T))
+        const int wa = (wv * 64 * T - st) & (SL - 1);
+        const bool wave_act = wa < en - st + 1 || wa + 64 * T > SL;
         const int en1 = st + (en - st) / 4 * 4;
         int32_t bestH = NEG_INF, bestKey = 0x7fffffff;
         uint32_t dw[(T + 3) / 4];
@@ -526,6 +528,7 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
         int32_t pv_en = 0, pv_st = 0, pv_h0v = 0, pv_h0u = 0;
         bool has_en = false, has_st = false, has_h0v = false, has_h0u = false, any = false;
         const bool first = r == 0, en_pos = en > 0;
+        if (wave_act) {
 #pragma unroll
         for (int k = T - 1; k >= 0; --k) {
             // Cells outside the band compute on clamped operands and their results are never read: a slot that has not
@@ -542,7 +545,8 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
             const int v1 = edge ? bv1 : k > 0 ? V[k > 0 ? k - 1 : 0] : lv;
             const int x1 = edge ? -qe : k > 0 ? X[k > 0 ? k - 1 : 0] : lx;
             const int x21 = edge ? -qe2 : k > 0 ? X2[k > 0 ? k - 1 : 0] : lx2;
-            const int hl = k > 0 ? H[k > 0 ? k - 1 : 0] : lh;
+            int hl = lh;
+            if constexpr (!APPROX) hl = k > 0 ? H[k > 0 ? k - 1 : 0] : lh;
             const int sq = ts_[min(t, tlen - 1)], sr = qs_[min(max(r - t, 0), qlen - 1)];
             const int sc = (sq == 4 || sr == 4) ? prm.sc_n : sq == sr ? prm.sc_mch : prm.sc_mis;
             int z = sc, a = x1 + v1, b = yt + ut, a2 = x21 + v1, b2 = y2t + ut, d;
@@ -567,18 +571,20 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
             X[k] = max(a, 0) - qe; Y[k] = max(b, 0) - qe;
             X2[k] = max(a2, 0) - qe2; Y2[k] = max(b2, 0) - qe2;
             dw[k >> 2] |= (uint32_t)d << (8 * (k & 3));
-            // exact mode: the H row
-            const int32_t h = first ? nv - qe : (is_en && en_pos) ? hl + nu : H[k] + nv;
-            H[k] = act ? h : H[k];  // (H alone can be read stale: H[en-1] of a one-cell band)
-            const int key = (t < en1 ? 1 + ((t - st) & 3) : 5) << 24 | t;
-            const bool better = t < en && (h > bestH || (h == bestH && key < bestKey));
-            bestH = better ? h : bestH; bestKey = better ? key : bestKey;
-            pv_en = is_en ? h : pv_en; has_en |= is_en;
-            pv_st = is_st ? h : pv_st; has_st |= is_st;
-            // approximate mode: the tracked cell
-            const bool is0 = act && t == last_H0_t, is1 = act && t == last_H0_t + 1;
-            pv_h0v = is0 ? nv : pv_h0v; has_h0v |= is0;
-            pv_h0u = is1 ? nu : pv_h0u; has_h0u |= is1;
+            if constexpr (!APPROX) {   // exact mode: the H row
+                const int32_t h = first ? nv - qe : (is_en && en_pos) ? hl + nu : H[k] + nv;
+                H[k] = act ? h : H[k];  // (H alone can be read stale: H[en-1] of a one-cell band)
+                const int key = (t < en1 ? 1 + ((t - st) & 3) : 5) << 24 | t;
+                const bool better = t < en && (h > bestH || (h == bestH && key < bestKey));
+                bestH = better ? h : bestH; bestKey = better ? key : bestKey;
+                pv_en = is_en ? h : pv_en; has_en |= is_en;
+                pv_st = is_st ? h : pv_st; has_st |= is_st;
+            } else {                   // approximate mode: the tracked cell
+                const bool is0 = act && t == last_H0_t, is1 = act && t == last_H0_t + 1;
+                pv_h0v = is0 ? nv : pv_h0v; has_h0v |= is0;
+                pv_h0u = is1 ? nu : pv_h0u; has_h0u |= is1;
+            }
+        }
         }
         if (any) {
             uint8_t *dst = p + (int64_t)r * SL;
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
         if (has_st) pub[par][1] = pv_st;
         if (has_h0v) pub[par][2] = pv_h0v;
         if (has_h0u) pub[par][3] = pv_h0u;
-        if (lane == 63) { bnd[par][wv][0] = V[T - 1]; bnd[par][wv][1] = X[T - 1]; bnd[par][wv][2] = X2[T - 1]; bnd[par][wv][3] = H[T - 1]; }
+        if (lane == 63) { bnd[par][wv][0] = V[T - 1]; bnd[par][wv][1] = X[T - 1]; bnd[par][wv][2] = X2[T - 1]; if constexpr (!APPROX) bnd[par][wv][3] = H[T - 1]; }
         if (!approx && r > 0) {
             const int32_t m = wave_reduce_max(bestH);
             int kk = (bestH == m && m > NEG_INF) ? bestKey : 0x7fffffff;
@@ -608,6 +614,22 @@ __global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__re
     else if (!ez.zdropped && (jb.flag & EZ_EXTZ_ONLY) && mqe + jb.end_bonus > ez.max) { out.reach_end = 1; out.do_bt = 1; out.bt_i = mqe_t; out.bt_j = qlen - 1; }
     else if (ez.max_t >= 0 && ez.max_q >= 0) { out.do_bt = 1; out.bt_i = ez.max_t; out.bt_j = ez.max_q; }
     if (tid == 0) res[jid] = out;
+}
+
+template <int NW, int T>
+__global__ __launch_bounds__(NW * 64) void ext_dp_band_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                              ExtParams prm, const uint8_t *__restrict__ reads,
+                                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                              RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
+    static_assert(T % 4 == 0 || T == 2, "T must be 2 or a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int bnd[2][NW][4];   // last slot of each wave after the anti-diagonal: v, x, x2, H
+    __shared__ int red[2][NW][2];   // per-wave best H and its tie-break key
+    __shared__ int pub[2][4];       // H[en], H[st], v[last_H0_t], u[last_H0_t + 1]
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    if (jb.flag & EZ_APPROX_MAX) ext_dp_band_body<NW, T, true>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem, bnd, red, pub);
+    else ext_dp_band_body<NW, T, false>(jb, jid, prm, reads, read_off, read_len, rv, P, res, smem, bnd, red, pub);
 }
 
 // Systolic strip variant for gap-fill windows whose band never clips (w >= max(qlen, tlen), tlen <= 1024, gaps
