@@ -1718,15 +1718,21 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
     // latency-bound kernels (chain DP, long extensions) of one overlap the throughput-bound ones of another
     int n_workers = 12;
     if (const char *e = getenv("MPN_PIPE_WORKERS")) n_workers = std::max(1, std::min(16, atoi(e)));
-    std::vector<int> cut{0};
-    {
-        int64_t target = 32000000;
-        if (const char *e = getenv("MPN_SUB_BATCH_BP")) target = std::max<int64_t>(1000, atoll(e));
-        // equal-sized sub-batches, their count a multiple of the worker count so that no worker idles in the last round
-        const int W = n_workers;
+    // Sub-batches: equal-sized, their count a multiple of the worker count so that no worker idles in the last round.  Every worker
+    // holds its own scratch (direction matrices above all): ~400 bytes per base of a sub-batch on a random target set, several times
+    // that on a strain-rich one -- what the workers of the previous calls took per sub-batch base is remembered.  When the free HBM
+    // (plus what the slots hold) does not cover all workers at the default size -- several index parts resident -- the sub-batches
+    // shrink (not below 11 Mbp) before workers are given up: 12 workers on 11 Mbp run 3 % faster than 6 on 22 Mbp (profiles/r04).
+    static double obs_bytes_per_bp = 0.0;   // (the mapping calls take turns: g_call_mu)
+    static int64_t obs_sub_bp = 0;
+    const bool env_target = getenv("MPN_SUB_BATCH_BP") != nullptr;
+    const int W_all = n_workers;
+    std::vector<int> cut;
+    auto make_cuts = [&](int64_t target) {
+        cut.assign(1, 0);
         std::vector<int64_t> sizes;
         int64_t n_cut = std::max<int64_t>(1, (bases + target - 1) / target);
-        if (n_cut > W) n_cut = (n_cut + W - 1) / W * W;
+        if (n_cut > W_all) n_cut = (n_cut + W_all - 1) / W_all * W_all;
         for (int64_t i = 0; i < n_cut; ++i) sizes.push_back(std::max<int64_t>(1, (bases + n_cut - 1) / n_cut));
         size_t si = 0;
         int64_t acc = 0;
@@ -1735,27 +1741,40 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
             if (si + 1 < sizes.size() && acc >= sizes[si] && i + 1 < n) { cut.push_back(i + 1); acc = 0; ++si; }
         }
         cut.push_back(n);
-    }
-    const int n_sub = (int)cut.size() - 1;
-    const int n_items = n_sub;   // a work item is a sub-batch: its worker maps it against every part in turn, on ONE sketch of its reads
-    n_workers = std::max(1, std::min(n_workers, n_items));
+    };
+    int64_t target = 32000000;
+    if (env_target) target = std::max<int64_t>(1000, atoll(getenv("MPN_SUB_BATCH_BP")));
+    make_cuts(target);
+    int n_sub = (int)cut.size() - 1;
+    int64_t largest = n_sub > 0 ? (bases + n_sub - 1) / n_sub : bases;
     {
-        // every worker holds its own scratch (direction matrices above all): about 400 bytes per base of a sub-batch
-        // with map-ont settings.  Do not start more workers than the free HBM (plus what the slots already hold) covers.
-        size_t free_b = 0, total_b = 0, held = 0, held_max = 0;
+        size_t free_b = 0, total_b = 0, held = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            for (const Slot &S : g_slots) {
-                const size_t h = S.device_bytes();
-                held += h;
-                held_max = std::max(held_max, h);
+            for (const Slot &S : g_slots) held += S.device_bytes();
+            const double avail = 0.9 * (double)(free_b + held);
+            auto per_worker = [&](int64_t sub_bp) { return std::max(400.0, 1.15 * obs_bytes_per_bp) * (double)std::max<int64_t>(sub_bp, 1) + 2e9; };
+            int fit = (int)std::max(1.0, avail / per_worker(largest));
+            if (fit < std::min(W_all, n_sub) && !env_target && largest > 11000000) {
+                // what fits W_all workers, at least 11 Mbp
+                const double room = avail / W_all - 2e9;
+                const int64_t t2 = std::max<int64_t>(11000000, (int64_t)(room / std::max(400.0, 1.15 * obs_bytes_per_bp)));
+                if (t2 < largest) {
+                    make_cuts(t2);
+                    n_sub = (int)cut.size() - 1;
+                    largest = n_sub > 0 ? (bases + n_sub - 1) / n_sub : bases;
+                    fit = (int)std::max(1.0, avail / per_worker(largest));
+                }
             }
-            const int64_t largest = n_sub > 0 ? (bases + n_sub - 1) / n_sub : bases;
-            // what a worker took in earlier calls (anchor-heavy target sets need far more than the DP scratch) is the better guide
-            const double per_worker = std::max(400.0 * (double)std::max<int64_t>(largest, 1) + 2e9, 1.2 * (double)held_max);
-            const int fit = (int)std::max(1.0, 0.9 * (double)(free_b + held) / per_worker);
+            // pools that were grown for much larger sub-batches would keep the memory the smaller ones free: give them back once
+            if (obs_sub_bp > 0 && largest < obs_sub_bp * 3 / 4) {
+                MPN_HIP_CHECK(hipDeviceSynchronize());
+                for (Slot &S : g_slots) S.release_device();
+            }
             n_workers = std::min(n_workers, fit);
         }
     }
+    const int n_items = n_sub;   // a work item is a sub-batch: its worker maps it against every part in turn, on ONE sketch of its reads
+    n_workers = std::max(1, std::min(n_workers, n_items));
     // slots that idle in this call give their scratch back: the running workers may need it (a call with fewer workers than the
     // last one -- less free memory since another index part became resident, or MPN_PIPE_WORKERS lowered)
     for (int wdx = n_workers; wdx < 16; ++wdx)
@@ -1889,6 +1908,15 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
         g_stats[16] = h2d;
         g_stats[0] = bases;
         g_stats[60] = n_shed; g_stats[61] = n_workers;
+        {   // what a worker took per sub-batch base in this call (the next call sizes its sub-batches and workers by it)
+            size_t held_max = 0;
+            for (const Slot &S : g_slots) held_max = std::max(held_max, S.device_bytes());
+            if (largest > 0 && held_max > 0) {
+                const double r = (double)held_max / (double)largest;
+                obs_bytes_per_bp = obs_sub_bp == largest ? std::max(obs_bytes_per_bp, r) : r;
+                obs_sub_bp = largest;
+            }
+        }
     }
     return 0;
 }
