@@ -1065,12 +1065,38 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     uint32_t cur_op = 0xf, cur_len = 0;
 #define MPN_FLUSH() do { if (cur_len) { if (rev_cigar) cbeg[n] = cur_len << 4 | cur_op; else cend[-1 - n] = cur_len << 4 | cur_op; ++n; } } while (0)
 #define MPN_PUSHOP(OP, LEN) do { if ((uint32_t)(OP) == cur_op) cur_len += (LEN); else { MPN_FLUSH(); cur_op = (OP); cur_len = (LEN); } } while (0)
+    constexpr int BT_AHEAD = 8;   // direction bytes fetched at once down the diagonal
     while (i >= 0 && j >= 0) {
         const int rr = i + j;
         int force_state = -1, tmp;
         if (rowmajor) {  // (the strip kernel stores the winner's rank: 4 - operand, or the operand itself for right-aligned gaps)
-            tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i];
-            if (!rank_is_op) tmp = (tmp & ~7) | (4 - (tmp & 7));
+            if (state == 0) {
+                // The walk is a chain of dependent loads, one HBM round trip per cell, and most cells of an alignment continue the
+                // diagonal: the bytes of the next BT_AHEAD cells down the diagonal are requested together and consumed while they
+                // say "match"; the first one that says otherwise is handled by the general step below (its byte is already here).
+                uint8_t ahead[BT_AHEAD];
+#pragma unroll
+                for (int k = 0; k < BT_AHEAD; ++k) {
+                    const int ii = i - k, jj = j - k;
+                    ahead[k] = (ii >= 0 && jj >= 0) ? p[(int64_t)(jj + ii / jb.strip_s) * jb.qstride + ii] : (uint8_t)0xff;
+                }
+                int k = 0;
+                tmp = 0;
+#pragma unroll
+                for (int q = 0; q < BT_AHEAD; ++q) {
+                    if (k != q) continue;             // (stopped earlier)
+                    if (i - q < 0 || j - q < 0) continue;
+                    int b = ahead[q];
+                    if (!rank_is_op) b = (b & ~7) | (4 - (b & 7));
+                    if ((b & 7) == 0) ++k; else tmp = b;
+                }
+                if (k > 0) { MPN_PUSHOP(0, (uint32_t)k); i -= k; j -= k; }
+                if (k == BT_AHEAD || i < 0 || j < 0) continue;
+                // cell (i, j): a gap wins there (tmp holds its decoded byte)
+            } else {
+                tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i];
+                if (!rank_is_op) tmp = (tmp & ~7) | (4 - (tmp & 7));
+            }
         }
         else if (byslot) {
             int st = 0, en = jb.tlen - 1;
@@ -1141,15 +1167,26 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     };
     const ExtRes r = res[jid];
     const int zmin = prm.zdrop_thres < prm.zdrop_inv ? prm.zdrop_thres : prm.zdrop_inv;
-    // No walk needed when a drop of more than the smaller threshold is impossible: prefix scores satisfy S(i) <= a * (matches up
-    // to i) and S(j) >= F - a * (matches after j), so S(i) - S(j) <= a * min(qlen, tlen) - F for the window's final score F.
-    // (Only for the strip kernel, whose corner score is exact.)
-    if (jb.layout == 1 && r.do_bt && !r.zdropped &&
-        (int64_t)prm.sc_mch * (jb.qlen < jb.tlen ? jb.qlen : jb.tlen) - r.score <= zmin) {
-        report(0);
-        return;
-    }
+    // No walk over the sequences is needed when a drop of more than the smaller threshold is impossible.  A drop is made of the
+    // negative contributions between two points of the path, so it is at most all of them: N = (mismatch and ambiguous columns) +
+    // (the gaps as THIS test prices them, q + e * len each).  The window's DP score F (exact corner score of the strip kernel) is
+    // a * matches - those columns - the gaps as the DP prices them (the cheaper of the two affine costs), hence
+    // N <= a * M - F + sum over the gaps of (q + e * len - DP cost), with M = the columns of the CIGAR's match operations.
+    // One pass over the CIGAR's few dozen operations, no sequence access.
     const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
+    if (jb.layout == 1 && r.do_bt && !r.zdropped) {
+        int64_t m_cols = 0, extra = 0;
+        for (int c = 0; c < r.n_cigar; ++c) {
+            const uint32_t op = cig[c] & 0xf;
+            const int64_t len = cig[c] >> 4;
+            if (op == 0) m_cols += len;
+            else if (op == 1 || op == 2) {
+                const int64_t w1 = prm.q + prm.e * len, w2 = prm.q2 + prm.e2 * len;
+                extra += w1 - (w1 < w2 ? w1 : w2);
+            }
+        }
+        if ((int64_t)prm.sc_mch * m_cols - r.score + extra <= zmin) { report(0); return; }
+    }
     const int64_t roff = read_off[jb.read];
     const int32_t rlen = read_len[jb.read];
     const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
