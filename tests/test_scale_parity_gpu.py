@@ -103,3 +103,76 @@ def test_saturated_seed_space_matches_oracle(libmpn, oracle_built):
     finally:
         gidx.close()
         oidx.close()
+
+
+def test_strain_rich_target_set_matches_oracle(libmpn, oracle_built):
+    """The regime of the bench headline in small: 40 assemblies of each of 3 community genomes at 97-99.9 % identity beside 30
+    unrelated genomes (150 x 600 kb), `-N 50 -p 1`: every read has dozens of loci, i.e. dozens of chain ends (the backtrack runs a
+    lane per end), dozens of chains per read in hit_select_kernel (rank sorts, secondaries within the score window, long joins),
+    many alignments per read.  PAF identical to the oracle for 120 reads incl. long ones; then the same target set as THREE index
+    parts through mpn_map_batch_parts against the oracle's split-index merge."""
+    import torch
+    from megapath_nano_amd import mapper, synth
+    from oracle import mm2_bindings as mb
+    dev = torch.device('cuda', 0)
+    glen, n_fam, copies, n_rand = 600_000, 3, 40, 30
+    n = n_rand + n_fam * copies
+    names, flat, lens = synth.make_genomes_device(4711, n, glen, 0, dev, families=(n_fam, copies, 0.97, 0.999))
+    torch.cuda.synchronize()
+    host = flat.view(n, glen).cpu().numpy()
+    gen = [(names[i], host[i]) for i in range(n)]
+    gidx = mapper.Index.from_device(names, flat.data_ptr(), lens)
+    cut = [0, 50, 100, n]
+    gparts = [mapper.Index.from_device(names[a:b], flat.data_ptr() + a * glen, lens[a:b]) for a, b in zip(cut, cut[1:])]
+    del flat
+    torch.cuda.empty_cache()
+    os.environ.setdefault('OMP_NUM_THREADS', str(min(16, os.cpu_count() or 1)))
+    oidx = mb.Index(gen)
+    oparts = [mb.Index(gen[a:b]) for a, b in zip(cut, cut[1:])]
+    w = np.zeros(n)
+    w[:n_fam] = [3, 2, 1]
+    reads = synth.make_reads(99, gen, 100, mean_len=6000, weights=w) + synth.make_reads(98, gen, 20, mean_len=30000, min_len=20000, weights=w)
+    for i, r in enumerate(reads):
+        r['name'] = f'sr{i:04d}'
+    names_r, seqs = [r['name'] for r in reads], [r['seq'] for r in reads]
+    try:
+        gopt, oopt = mapper.default_opt(best_n=50, pri_ratio=1.0), mb.default_opt(best_n=50, pri_ratio=1.0)
+        got = mapper.map_batch(gidx, gopt, names_r, seqs)
+        stats = mapper.last_stats()
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+            want = list(ex.map(lambda r: mb.map_read(oidx, oopt, r['name'], r['seq'])[2], reads))
+        by = {}
+        for line in got.splitlines(keepends=True):
+            by.setdefault(line.split('\t', 1)[0], []).append(line)
+        for r, w_ in zip(reads, want):
+            assert ''.join(by.get(r['name'], [])) == w_, (r['name'], len(r['seq']))
+        assert stats['chains'] >= 20 * len(reads), stats['chains']            # dozens of chains per read ...
+        assert stats['alignments'] >= 5 * len(reads), stats['alignments']     # ... and many hits kept
+        assert stats['reads_hits_on_host'] == 0
+        # three resident parts in one call, merged like --split-prefix
+        sp = mb.SplitIndex(oparts)
+        packed = mapper.PackedReads(names_r, seqs)
+        h = mapper.Hits(packed)
+        h.add_parts(gparts, gopt)
+        paf, _, cols = h.finish(gopt, want_paf=True, want_cols=True)
+        h.close()
+        want_s = [sp.map_read(oopt, n_, s_) for n_, s_ in zip(names_r, seqs)]
+        by = {}
+        for line in paf.splitlines(keepends=True):
+            by.setdefault(line.split('\t', 1)[0], []).append(line)
+        for r, w_ in zip(reads, want_s):
+            assert ''.join(by.get(r['name'], [])) == w_, ('parts', r['name'], len(r['seq']))
+        # an accumulator that was told there would be no text refuses to make some
+        h2 = mapper.Hits(packed, want_text=False)
+        h2.add_parts(gparts, gopt)
+        _, _, cols2 = h2.finish(gopt, want_paf=False, want_cols=True)
+        assert all(np.array_equal(cols[k], cols2[k]) for k in cols)
+        with pytest.raises(Exception):
+            h2.finish(gopt, want_paf=True, want_cols=False)
+        h2.close()
+        sp.close()
+    finally:
+        gidx.close()
+        oidx.close()
+        for x in gparts + oparts:
+            x.close()
