@@ -138,7 +138,7 @@ struct PoolBuf {
         if (bytes <= cap) return 0;
         if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 4096;
-        const hipError_t e_ = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        const hipError_t e_ = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : guarded_malloc(&p, want);
         if (e_ != hipSuccess) {
             if (e_ == hipErrorOutOfMemory && !pinned_host) tl_oom = true;
             p = nullptr;

@@ -33,6 +33,21 @@ extern thread_local bool tl_oom;
 extern std::atomic<long long> g_arena_bytes;
 long long arena_test_budget();
 
+// hipMalloc that leaves the device a reserve: the workers of the pipelined mapper grow their scratch until an allocation fails and
+// then shed (align.hip) -- but a device that is filled to the last byte cannot serve the runtime's own needs either (kernel scratch,
+// signals), and THAT failure aborts the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Large requests are therefore refused, as
+// out of memory, while they would leave less than the reserve free.
+inline hipError_t guarded_malloc(void **p, size_t bytes) {
+    if (bytes >= ((size_t)32 << 20)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t reserve = std::max<size_t>((size_t)4 << 30, total_b / 40);
+            if (free_b < bytes + reserve) return hipErrorOutOfMemory;
+        }
+    }
+    return hipMalloc(p, bytes);
+}
+
 struct Arena {
     struct Chunk { void *p; size_t cap; };
     std::vector<Chunk> chunks;
@@ -50,7 +65,7 @@ struct Arena {
             const size_t want = std::max(used + used / 4, total / 2) + ((size_t)64 << 20);
             Chunk c{nullptr, want};
             const long long budget = arena_test_budget();
-            if ((budget <= 0 || g_arena_bytes + (long long)want <= budget) && hipMalloc(&c.p, c.cap) == hipSuccess) { chunks.push_back(c); g_arena_bytes += (long long)want; }
+            if ((budget <= 0 || g_arena_bytes + (long long)want <= budget) && guarded_malloc(&c.p, c.cap) == hipSuccess) { chunks.push_back(c); g_arena_bytes += (long long)want; }
             else (void)hipGetLastError();  // take() will report the failure if the memory is really gone
         }
         cur = 0; off = 0; used = 0;
@@ -75,7 +90,7 @@ struct Arena {
         c.cap = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
         const long long budget = arena_test_budget();
         if (budget > 0) c.cap = bytes > ((size_t)16 << 20) ? bytes : ((size_t)16 << 20);   // (small chunks, so that a small budget binds)
-        if ((budget > 0 && g_arena_bytes + (long long)c.cap > budget) || hipMalloc(&c.p, c.cap) != hipSuccess) {
+        if ((budget > 0 && g_arena_bytes + (long long)c.cap > budget) || guarded_malloc(&c.p, c.cap) != hipSuccess) {
             (void)hipGetLastError();
             tl_oom = true;
             mpn::set_error("arena: out of memory (hipMalloc of %zu bytes failed)", c.cap);
