@@ -1016,8 +1016,10 @@ __device__ __forceinline__ void ext_strip_dispatch(const ExtJob *__restrict__ jo
 struct StripSeg { int32_t first_block, n_list, ord_off, lds_stride, nr_stride, glc, right, pad; };
 struct StripSegs { StripSeg s[6]; int32_t n; };
 
+// (the gap-fill instantiation needs 99 VGPRs as the compiler allocates them by default: one register granule over what lets a
+// fifth wave onto a SIMD.  Five waves are asked for -- the dependent chain down a lane's 16 rows needs other waves to issue.)
 template <bool EXACT>
-__global__ __launch_bounds__(64) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, StripSegs segs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXACT ? 3 : 5, EXACT ? 3 : 5))) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, StripSegs segs,
                                                           ExtParams prm, const uint8_t *__restrict__ reads,
                                                           const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                                                           RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
