@@ -854,7 +854,9 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     }
     const int lay_grid = std::max(1, std::min((nj + 255) / 256, 256));   // (a block per CU: every block flushes its counters once)
     EvTimer evl(st);
-    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, prm, g_force_kernel, d_sizes, d_bcnt, d_tot);
+    static const bool tiled_on = []() { const char *e = getenv("MPN_TILED"); return !e || atoi(e) != 0; }();
+    hipLaunchKernelGGL(job_classify_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, strip_scores, prm, g_force_kernel ? g_force_kernel : (tiled_on ? 0 : 7), d_sizes,
+                       d_bcnt, d_tot);
     hipLaunchKernelGGL(job_scan_kernel, dim3(1), dim3(1024), 0, st, d_sizes, d_nj, (const int32_t *)d_bcnt, d_bcur, d_tot, d_order.p);
     hipLaunchKernelGGL(job_layout_kernel, dim3(lay_grid), dim3(256), 0, st, d_jobs.p, d_nj, (const JobSizes *)d_sizes, d_bcur, d_order.p);
     MPN_HIP_CHECK(hipGetLastError());
@@ -969,6 +971,10 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             } while (0)
             if (fam == 0) MPN_STRIP_LAUNCH(false); else MPN_STRIP_LAUNCH(true);
 #undef MPN_STRIP_LAUNCH
+        } else if (l == L_TILE) {
+            const size_t lds = (size_t)std::max(T.tile_lds, 64) + 64;
+            if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ext_dp_tile_kernel, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, gstate.p, d_res.p);
         } else {
             const int bvar = (l - L_BAND) / 4;
             const size_t lds = std::max<size_t>((size_t)T.band_lds[(l - L_BAND) % 4], 64);
@@ -1093,7 +1099,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             const ExtJob &jb = jobs[(size_t)j];
             const int bv = band_of(j);
             pack[k] = j; pack[nr + k] = bv >= 0 ? 2 : 0; pack[2 * nr + k] = 128 << std::max(bv, 0); pack[3 * nr + k] = is_inv[(size_t)j];
-            if (list_of(j) >= L_STRIP && list_of(j) < L_BAND) {
+            if ((list_of(j) >= L_STRIP && list_of(j) < L_BAND) || list_of(j) == L_TILE) {   // (strip and tiled layouts are sized for themselves)
                 const int64_t n_r = (int64_t)jb.qlen + jb.tlen - 1;
                 pack_off[k] = -1 - p2_tot;  // resolved below, once the pool address is known
                 p2_tot += ((bv >= 0 ? n_r * (128 << bv) : n_r * jb.n_col) + 15) & ~(int64_t)15;

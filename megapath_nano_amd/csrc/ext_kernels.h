@@ -31,7 +31,7 @@ struct ExtJob {
     int32_t state_mode;  // 0: state arrays in LDS, 1: in global scratch
     int64_t state_off;
     int32_t layout;      // direction matrix: 0 = [anti-diagonal][t - band start]; 1 = strip kernel: cell (t, j) at [j + t/S][t];
-                         // 2 = band kernel: [anti-diagonal][t mod SL]
+                         // 2 = band kernel: [anti-diagonal][t mod SL]; 3 = tiled strips (tile_geom)
     int32_t qstride;     // layout 1: row width W = n_lanes * S bytes; layout 2: SL
     int32_t strip_s;     // layout 1: S
     int32_t cls;         // launch list | second-pass list << 8 | (band variant + 1) << 16 (job_classify_kernel); -1: placeholder without DP
@@ -1035,6 +1035,222 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXACT ? 3 : 
 #undef MPN_GL
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tiled, banded strips: the gap fills the strip kernel above cannot take -- targets longer than 1024 rows, or a band that clips
+// (the 1.6-kb fills between the sparse anchors of a divergent assembly; w = 750) -- on the SAME cell instead of the band kernel's
+// generic 32-bit one (~33 instead of ~120 instructions per cell).  One wave per window.  The target is cut into tiles of 1024 rows
+// (64 lanes x 16); a tile is a systolic strip over the query columns its rows have in the band, [T0 - w, T0 + rows - 1 + w]; the
+// v / x states and H of a tile's last row go through a 12-byte-per-column boundary in HBM to the next tile's first row.
+// ksw2's band in (t, j) terms: a cell is computed iff t - w <= j <= t + w (st = (r - w + 1) >> 1, en = (r + w) >> 1, r = t + j).
+// What lies outside is never read: the first in-band cell of a row (j == t - w) takes freshly opened gaps on its left, the last
+// one (j == t + w) freshly opened gaps above -- two selects each -- exactly what ksw2's SSE code and the band kernel read there.
+// Cells outside the band are computed on whatever flows in and ignored.  H is carried as a 32-bit number (8 H): from the left,
+// or from above at a row's entry into the band; the corner's H is the score (ksw2's approximate-maximum walk ends there too).
+// Directions: per tile a step-major block like the strip kernel's; layout 3 in the traceback.
+constexpr int TILE_ROWS = 1024, TILE_S = 16;
+struct TileGeom { int T0, rows, n_lanes, W, jlo, jhi; int64_t base; };
+// geometry of tile `tile` of a tlen x qlen window with band w; base = bytes of the tiles before it
+__host__ __device__ inline TileGeom tile_geom(int tile, int qlen, int tlen, int w) {
+    TileGeom g{};
+    int64_t base = 0;
+    for (int k = 0;; ++k) {
+        const int T0 = k * TILE_ROWS, rows = tlen - T0 < TILE_ROWS ? tlen - T0 : TILE_ROWS, nl = (rows + TILE_S - 1) / TILE_S;
+        const int jlo = T0 - w > 0 ? T0 - w : 0, jhi = T0 + rows - 1 + w < qlen - 1 ? T0 + rows - 1 + w : qlen - 1;
+        if (k == tile) { g.T0 = T0; g.rows = rows; g.n_lanes = nl; g.W = nl * TILE_S; g.jlo = jlo; g.jhi = jhi; g.base = base; return g; }
+        base += (int64_t)((jhi >= jlo ? jhi - jlo + 1 : 0) + nl - 1) * (nl * TILE_S);
+    }
+}
+__host__ __device__ inline int64_t tile_matrix_bytes(int qlen, int tlen, int w) {
+    const int nt = (tlen + TILE_ROWS - 1) / TILE_ROWS;
+    const TileGeom g = tile_geom(nt - 1, qlen, tlen, w);
+    return g.base + (int64_t)((g.jhi >= g.jlo ? g.jhi - g.jlo + 1 : 0) + g.n_lanes - 1) * g.W;
+}
+// eligible: a global alignment whose corner the band reaches, on scores the packed cell holds
+__host__ __device__ inline bool ext_tile_ok(int qlen, int tlen, int w) {
+    const int d = qlen > tlen ? qlen - tlen : tlen - qlen;
+    return qlen > 0 && tlen > 0 && w >= 1 && d <= w && tlen <= 32768 && qlen <= 60000;
+}
+
+__global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                         ExtParams prm, const uint8_t *__restrict__ reads,
+                                                         const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                         RefView rv, uint8_t *__restrict__ P, int8_t *__restrict__ gstate, ExtRes *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int S = TILE_S;
+    const int lane = threadIdx.x;
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    const int qlen = jb.qlen, tlen = jb.tlen;
+    int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    int w = jb.w;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    ExtRes out;
+    out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
+    out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
+    if (!ext_tile_ok(qlen, tlen, w) || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
+    // ---- the cell's constants (see ext_strip_pack) ----
+    constexpr int RS = 4, RA = 3, RB = 2, RA2 = 1, RB2 = 0;
+    const uint32_t sb_mch = (uint32_t)(8 * prm.sc_mch + RS + 128) & 0xff, sb_mis = (uint32_t)(8 * prm.sc_mis + RS + 128) & 0xff,
+                   sb_n = (uint32_t)(8 * prm.sc_n + RS + 128) & 0xff;
+    const int q_pad = (qlen + 3) & ~3;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem + q_pad);
+    if (lane < 5) tab[lane] = lane == 4 ? sb_n * 0x01010101u : (sb_mis * 0x01010101u) ^ ((sb_mch ^ sb_mis) << (8 * lane));
+    {
+        const int64_t roff = read_off[jb.read];
+        const int32_t rlen = read_len[jb.read];
+        for (int i = lane; i < qlen; i += 64) smem[i] = (uint8_t)(4 * ext_qbase(reads, roff, rlen, jb.rev, jb.qs + (jb.reversed ? qlen - 1 - i : i)));
+    }
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+#define MPN_BND(R) (8 * ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2))
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto pk = [](int lo, int hi) { return (uint32_t)(hi * 65536 + lo); };
+    constexpr int BETA = 0x2000 + 128;
+    const int cv_lo = -8 * qe + RA + BETA, cv_hi = -8 * qe2 + RA2 + BETA, cu_lo = -8 * qe + RB + BETA, cu_hi = -8 * qe2 + RB2 + BETA;
+    const uint32_t CV = pk(cv_lo, cv_hi), CU = pk(cu_lo, cu_hi);
+    const uint32_t FRESH_U = pk(-8 * qe, -8 * qe) + CU, EDGE_V = pk(-8 * qe, -8 * qe) + CV;
+    const uint32_t KONST = sb_n | 0x2000u;
+    const uint32_t KZZ = pk(-16 * qe + RA + RB + BETA, -16 * qe2 + RA2 + RB2 + BETA);
+    const uint32_t KEA = pk(8 * e - 8 * qe + RA, 8 * e2 - 8 * qe2 + RA2), KEB = pk(8 * e - 8 * qe + RB, 8 * e2 - 8 * qe2 + RB2);
+    const uint32_t EIGHT = 0x00080008u, RANK_CLR = 0xfff8fff8u;
+    const uint32_t MCH7 = (uint32_t)(8 * prm.sc_mch + 7 + BETA) * 0x00010001u;
+    const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
+    // boundary between tiles: two buffers of qlen x 3 words in the window's global scratch (a tile reads what the one before wrote
+    // while it writes for the next)
+    uint32_t *bnd_base = reinterpret_cast<uint32_t *>(gstate + jb.state_off);
+    const int n_tiles = (tlen + TILE_ROWS - 1) / TILE_ROWS;
+    __syncthreads();
+    const bool head = lane == 0;
+    int32_t score8 = 0;
+    int prev_jhi = -1;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const TileGeom G = tile_geom(tile, qlen, tlen, w);
+        const int T0 = G.T0, n_lanes = G.n_lanes, W = G.W, jlo = G.jlo, jhi = G.jhi;
+        if (jhi < jlo) break;   // (cannot happen for an eligible window: |qlen - tlen| <= w)
+        uint32_t *bnd_in = bnd_base + (size_t)(tile & 1) * 3 * (size_t)qlen, *bnd_out = bnd_base + (size_t)((tile + 1) & 1) * 3 * (size_t)qlen;
+        const bool write_bnd = tile + 1 < n_tiles;
+        const int t0 = T0 + lane * S;
+        uint32_t UL[S], YL[S], TSEL[S];
+        int32_t H8[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int t = t0 + k;
+            const int sq = t < tlen ? ref_code(rv, g0 + (jb.reversed ? tlen - 1 - t : t)) : 4;
+            TSEL[k] = 0x0c0c0100u | (sq < 4 ? 4u + (uint32_t)sq : 0u);
+            // rows whose band starts at column 0 take the first-column boundary; the others are overridden at their entry
+            UL[k] = jlo == 0 ? pk(MPN_BND(t), MPN_BND(t)) + CU : FRESH_U;
+            YL[k] = 0;
+            H8[k] = 8 * (t < long_thres ? -(q + e * (t + 1)) : -(q2 + e2 * (t + 1)));
+        }
+        uint8_t *prow = P + jb.p_off + G.base + (int64_t)lane * S;
+        const int n_steps = (jhi - jlo + 1) + n_lanes - 1;
+        int out_v = 0, out_x = 0, out_h = 0;
+        uint32_t qt = 0;
+        auto qcode = [&](int col) -> uint32_t { return col < qlen ? (uint32_t)smem[col] : 16u; };
+        uint32_t qt_next = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + qcode(jlo));
+        uint32_t qc_next = qcode(jlo + 1);
+        // the head lane's boundary words, requested two steps ahead
+        uint32_t bv_n = 0, bx_n = 0, bh_n = 0, bv_n2 = 0, bx_n2 = 0, bh_n2 = 0;
+        auto load_bnd = [&](int col, uint32_t &a, uint32_t &b, uint32_t &c) {
+            if (tile > 0 && head && col <= prev_jhi && col < qlen) { a = bnd_in[3 * (size_t)col]; b = bnd_in[3 * (size_t)col + 1]; c = bnd_in[3 * (size_t)col + 2]; }
+        };
+        load_bnd(jlo, bv_n, bx_n, bh_n);
+        load_bnd(jlo + 1, bv_n2, bx_n2, bh_n2);
+        for (int step = 0; step < n_steps; ++step) {
+            const uint32_t q_in = qt_next;
+            qt_next = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + qc_next);
+            qc_next = qcode(jlo + step + 2);
+            const uint32_t bv = bv_n, bx = bx_n, bh = bh_n;
+            bv_n = bv_n2; bx_n = bx_n2; bh_n = bh_n2;
+            load_bnd(jlo + step + 2, bv_n2, bx_n2, bh_n2);
+            const uint32_t qt_s = (uint32_t)wave_shr1_zero((int)qt);
+            const int v_s = wave_shr1_zero(out_v), x_s = wave_shr1_zero(out_x), h_s = wave_shr1_zero(out_h);
+            const int j = jlo + step - lane;
+            qt = head ? q_in : qt_s;
+            uint32_t Vp, Xp;
+            int32_t Hup;
+            if (head) {
+                if (tile == 0) { const int bj = MPN_BND(j); Vp = pk(bj, bj) + CV; Xp = 0; Hup = 0; }
+                else { Vp = bv; Xp = bx; Hup = (int32_t)bh; }
+            } else { Vp = (uint32_t)v_s; Xp = (uint32_t)x_s; Hup = h_s; }
+            if (j >= jlo && j <= jhi && lane < n_lanes) {
+                uint32_t dw[(S + 3) / 4], ecell[4] = {0, 0, 0, 0};
+                const int d_in = j - t0 + w;    // row k enters the band at this column iff d_in == k
+                const int d_out = j - t0 - w;   // row k is the band's last row of this column iff d_out == k
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const bool enter = d_in == k, edge = d_out == k;
+                    const uint32_t Up = enter ? FRESH_U : UL[k];
+                    const uint32_t Yl = enter ? 0u : YL[k];
+                    Vp = edge ? EDGE_V : Vp;
+                    Xp = edge ? 0u : Xp;
+                    const uint32_t sc16 = __builtin_amdgcn_perm(qt, KONST, TSEL[k]);
+                    const uint32_t A = Xp + Vp, B = Yl + Up;
+                    const uint32_t M = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, A), __builtin_bit_cast(s16x2, B)));
+                    uint32_t m2, z16;
+                    asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m2) : "v"(M));
+                    asm("v_max_i16 %0, %1, %2" : "=v"(z16) : "v"(m2), "v"(sc16));
+                    uint32_t zc;
+                    asm("v_pk_min_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(zc) : "v"(z16), "v"(MCH7));
+                    const uint32_t Zc = zc & RANK_CLR;
+                    const uint32_t ZZ = Zc + KZZ;
+                    const uint32_t nu = ZZ - Vp, nv = ZZ - Up;
+                    const u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
+                    const u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
+                    uint32_t HA, HB;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, An)), "v"(EIGHT));
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, Bn)), "v"(EIGHT));
+                    uint32_t Fw;
+                    asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(Fw) : "v"(HB), "v"(HA));
+                    asm("v_and_or_b32 %0, %1, 7, %2" : "=v"(ecell[k & 3]) : "v"(z16), "v"(Fw));
+                    // H of the cell: from the left, or from above where the row enters the band (8 H; u and v in the low halves)
+                    const int32_t h_left = H8[k] + (int32_t)(nv & 0xffffu) - cv_lo, h_up = Hup + (int32_t)(nu & 0xffffu) - cu_lo;
+                    const int32_t h = enter ? h_up : h_left;
+                    H8[k] = h;
+                    Hup = h;
+                    UL[k] = nu; YL[k] = __builtin_bit_cast(uint32_t, Bn);
+                    Vp = nv; Xp = __builtin_bit_cast(uint32_t, An);
+                    if ((k & 3) == 3) {
+                        uint32_t e01, e23;
+                        asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(e01) : "v"(ecell[1]), "v"(ecell[0]));
+                        asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(e23) : "v"(ecell[3]), "v"(ecell[2]));
+                        const uint32_t lo = __builtin_amdgcn_perm(e23, e01, 0x05040100u), hi = __builtin_amdgcn_perm(e23, e01, 0x07060302u);
+                        asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(dw[k >> 2]) : "v"(hi), "v"(lo));
+                    }
+                }
+                out_v = (int)Vp; out_x = (int)Xp; out_h = Hup;
+                *reinterpret_cast<uint4 *>(prow + (int64_t)step * W) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+                // a full tile's last lane hands its last row to the next tile
+                if (write_bnd && lane == 63) { bnd_out[3 * (size_t)j] = (uint32_t)out_v; bnd_out[3 * (size_t)j + 1] = (uint32_t)out_x; bnd_out[3 * (size_t)j + 2] = (uint32_t)out_h; }
+            }
+        }
+        // the corner: H of row tlen - 1 after its last column (qlen - 1 = jhi of the last tile)
+        if (tile + 1 == n_tiles) {
+            const int lt = tlen - 1 - T0, ll = lt / S, kk = lt % S;
+            int32_t hv = 0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) hv = k == kk ? H8[k] : hv;
+            score8 = __shfl(hv, ll);
+        }
+        prev_jhi = jhi;
+        // the boundary the next tile reads was written by lane 63, its first lane reads it: order them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+#undef MPN_BND
+    if (lane == 0) {
+        out.score = score8 >> 3;
+        out.r_done = qlen + tlen - 2;
+        out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1;
+        res[jid] = out;
+    }
+}
+
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
 __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
                                                     const uint8_t *__restrict__ P, const int32_t *__restrict__ OFF,
@@ -1056,6 +1272,9 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
     const bool rowmajor = jb.layout == 1;  // strip kernel: cell (t, j) at [j + t/S][t], band never clips
     const bool rank_is_op = (jb.flag & EZ_RIGHT) != 0;
     const bool byslot = jb.layout == 2;    // band kernel: cell (t, r) at [r][t mod SL], band limits recomputed here
+    const bool tiled = jb.layout == 3;     // tiled strips: per 1024-row tile a step-major block over the tile's band columns
+    TileGeom tg{};
+    int tg_tile = -1;
     const int bw = jb.w < 0 ? (jb.tlen > jb.qlen ? jb.tlen : jb.qlen) : jb.w;
     const bool rev_cigar = (jb.flag & EZ_REV_CIGAR) != 0;
     // ops are generated last-to-first.  REV_CIGAR keeps that order (write forward from the region start),
@@ -1098,6 +1317,23 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
             } else {
                 tmp = p[(int64_t)(j + i / jb.strip_s) * jb.qstride + i];
                 if (!rank_is_op) tmp = (tmp & ~7) | (4 - (tmp & 7));
+            }
+        }
+        else if (tiled) {
+            int st = 0, en = jb.tlen - 1;
+            if (st < rr - jb.qlen + 1) st = rr - jb.qlen + 1;
+            if (en > rr) en = rr;
+            if (st < (rr - bw + 1) >> 1) st = (rr - bw + 1) >> 1;
+            if (en > (rr + bw) >> 1) en = (rr + bw) >> 1;
+            if (i < st) force_state = 2;
+            if (i > en) force_state = 1;
+            tmp = 0;
+            if (force_state < 0) {
+                const int tile = i / TILE_ROWS;
+                if (tile != tg_tile) { tg = tile_geom(tile, jb.qlen, jb.tlen, bw); tg_tile = tile; }   // (the walk only descends: a few times per window)
+                const int lt = i - tg.T0;
+                tmp = p[tg.base + (int64_t)((j - tg.jlo) + lt / TILE_S) * tg.W + lt];
+                tmp = (tmp & ~7) | (4 - (tmp & 7));
             }
         }
         else if (byslot) {
@@ -1176,7 +1412,7 @@ __global__ __launch_bounds__(64) void ext_ztest_kernel(const ExtJob *__restrict_
     // N <= a * M - F + sum over the gaps of (q + e * len - DP cost), with M = the columns of the CIGAR's match operations.
     // One pass over the CIGAR's few dozen operations, no sequence access.
     const uint32_t *cig = CIG + jb.cig_off - r.n_cigar;  // gap-fill jobs are never REV_CIGAR
-    if (jb.layout == 1 && r.do_bt && !r.zdropped) {
+    if ((jb.layout == 1 || jb.layout == 3) && r.do_bt && !r.zdropped) {
         int64_t m_cols = 0, extra = 0;
         for (int c = 0; c < r.n_cigar; ++c) {
             const uint32_t op = cig[c] & 0xf;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanOpt o, const PlanReg *__re
 // (strip lists: kernel variant (gap fill with approximate maximum / exact / exact with right-aligned gaps) x lane-group class
 // (16/32/64 lanes per window) x strip height 1..16; each is padded to whole waves)
 constexpr int N_STRIP_CLASS = 9;   // variant * 3 + lane-group class
-enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 16 * N_STRIP_CLASS, L_BAND = L_STRIP + N_STRIP, N_LISTS = L_BAND + 16 };
+enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 16 * N_STRIP_CLASS, L_BAND = L_STRIP + N_STRIP, L_TILE = L_BAND + 16, N_LISTS = L_TILE + 1 };
 constexpr int STRIP_QB = 64;                                  // query-length buckets inside a strip list (longest first)
 constexpr int N_BUCKETS = N_LISTS + N_STRIP * (STRIP_QB - 1);  // scatter buckets: a strip list is STRIP_QB consecutive buckets
 __host__ __device__ inline int strip_glc_of_list(int l) { return ((l - L_STRIP) / 16) % 3; }
@@ -294,6 +294,7 @@ __host__ __device__ inline int bucket_of_list(int l) {       // first bucket of 
 struct LayoutTotals {          // read back by the host after job_layout_kernel
     long long p_tot, row_tot, cig_tot, state_tot, cells, strip_cells[3], xstrip_cells;
     int lds_need[5], strip_lds[N_STRIP_CLASS], band_lds[4], strip_nr[N_STRIP_CLASS];   // (strip_nr: anti-diagonals of the longest exact window)
+    int tile_lds, pad_;                                                                  // longest query of the tiled-strip list
     int too_large, tl_q, tl_t, n_jobs;
     int cnt[N_LISTS], base[N_LISTS + 1];   // launch lists in the flat order array (strip lists padded to whole waves)
 };
@@ -304,12 +305,14 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
                                                            ExtParams prm, int force_kernel, JobSizes *__restrict__ sizes, int32_t *__restrict__ bucket_cnt,
                                                            LayoutTotals *__restrict__ tot) {
     const int nj = (int)*nj_p;   // (written by plan_kernel, or by the host for the stage test)
+    const bool no_tile = force_kernel == 7;   // 7: automatic choice without the tiled strips (MPN_TILED=0)
+    if (no_tile) force_kernel = 0;
     const int lds_cap[4] = {8 << 10, 24 << 10, 64 << 10, 150 << 10};
     // counters and maxima are gathered per block in LDS and leave with one atomic per block and slot: a hundred thousand
     // windows adding to ONE global address serialise at the memory side (DESIGN.md lesson 4)
     __shared__ int s_bucket[N_BUCKETS];
-    constexpr int M_STRIP = 5, M_BAND = M_STRIP + N_STRIP_CLASS, M_NR = M_BAND + 4, M_END = M_NR + N_STRIP_CLASS;
-    __shared__ int s_max[M_END];   // lds_need[5] | strip_lds[9] | band_lds[4] | strip_nr[9]
+    constexpr int M_STRIP = 5, M_BAND = M_STRIP + N_STRIP_CLASS, M_NR = M_BAND + 4, M_TILE = M_NR + N_STRIP_CLASS, M_END = M_TILE + 1;
+    __shared__ int s_max[M_END];   // lds_need[5] | strip_lds[9] | band_lds[4] | strip_nr[9] | tile_lds
     for (int k = threadIdx.x; k < N_BUCKETS; k += blockDim.x) s_bucket[k] = 0;
     if (threadIdx.x < M_END) s_max[threadIdx.x] = 0;
     __syncthreads();
@@ -338,6 +341,9 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
                 if (jb.tlen <= (256 << c) && jb.qlen <= (1024 << c)) glc = c;
         }
         const bool strip = glc >= 0;
+        // tiled strips: the gap fills the strip kernel cannot take (target beyond 1024 rows, or a band that clips)
+        const bool tiled = !strip && strip_scores && (jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed &&
+                           ext_tile_ok(jb.qlen, jb.tlen, w) && !no_tile && (force_kernel == 0 || force_kernel == 6);
         const int sclass = variant * 3 + max(glc, 0);
         const int seqb = ((jb.qlen + 3) & ~3) + ((jb.tlen + 3) & ~3);
         // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
@@ -345,15 +351,15 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         if (seqb > lds_cap[3] || !(force_kernel == 0 || force_kernel == 4 || force_kernel == 5)) bv = -1;
         int bc = 3;
         for (int c = 0; c < 4; ++c) if (seqb <= lds_cap[c]) { bc = c; break; }
-        if (bv >= 0) atomicMax(&s_max[M_BAND + bc], seqb);
-        jb.layout = strip ? 1 : bv >= 0 ? 2 : 0;
+        if (bv >= 0) atomicMax(&s_max[M_BAND + bc], seqb);   // (also for strip and tiled windows: their exact second pass runs on the band kernel)
+        jb.layout = strip ? 1 : tiled ? 3 : bv >= 0 ? 2 : 0;
         const int strip_gl = 16 << max(glc, 0);
         jb.strip_s = max(1, min(16, (jb.tlen + strip_gl - 1) / strip_gl));   // strip height: the window's rows over its lane group
         const int strip_lanes = (jb.tlen + jb.strip_s - 1) / jb.strip_s;
         jb.qstride = strip ? strip_lanes * jb.strip_s : 128 << max(bv, 0);   // row width of the direction matrix (layouts 1, 2)
         const long long strip_bytes = (long long)(jb.qlen + strip_lanes - 1) * (strip_lanes * jb.strip_s);
         // (the rare exact second pass of a strip window gets its direction matrix from a pool of its own)
-        sz.p = ((strip ? strip_bytes : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~15LL;
+        sz.p = ((strip ? strip_bytes : tiled ? (long long)tile_matrix_bytes(jb.qlen, jb.tlen, w) : bv >= 0 ? n_r * (128 << bv) : n_r * n_col) + 15) & ~15LL;
         cells += n_r * n_col;
         if (strip) { if (variant == 0) scells[glc] += (long long)jb.qlen * jb.tlen; else xcells += (long long)jb.qlen * jb.tlen; }
         const int stateb = ((6 * jb.tlen + 3) & ~3) + 4 * jb.tlen;
@@ -369,12 +375,17 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
             atomicMax(&s_max[M_STRIP + sclass], (jb.qlen + 15) & ~15);
             if (variant) atomicMax(&s_max[M_NR + sclass], (int)n_r);
         }
+        else if (tiled) {
+            lid = L_TILE;
+            atomicMax(&s_max[M_TILE], (jb.qlen + 3) & ~3);
+            sz.st = ((long long)24 * jb.qlen + 15) & ~15LL;   // the boundary between tiles: two buffers of 12 bytes per query column
+        }
         else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
         else lid = redo_list;
         if (bv < 0) {   // the LDS-state kernels may run this window (now or in the second pass)
             if (cls == 4) {
                 if (seqb > lds_cap[3]) { tot->too_large = 1; tot->tl_q = jb.qlen; tot->tl_t = jb.tlen; }
-                jb.state_mode = 1; sz.st = (stateb + 15) & ~15;
+                jb.state_mode = 1; sz.st = max(sz.st, (long long)((stateb + 15) & ~15));   // (a tiled window keeps its boundary buffers there too)
                 atomicMax(&s_max[4], seqb);
             } else atomicMax(&s_max[cls], seqb + stateb);
             sz.row = n_r;   // band limits are stored only by the LDS-state kernels
@@ -392,8 +403,8 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
     for (int k = threadIdx.x; k < N_BUCKETS; k += blockDim.x) if (s_bucket[k]) atomicAdd(&bucket_cnt[k], s_bucket[k]);
     if (threadIdx.x < M_END && s_max[threadIdx.x]) {
         const int k = threadIdx.x;
-        atomicMax(k < M_STRIP ? &tot->lds_need[k] : k < M_BAND ? &tot->strip_lds[k - M_STRIP] : k < M_NR ? &tot->band_lds[k - M_BAND] : &tot->strip_nr[k - M_NR],
-                  s_max[k]);
+        atomicMax(k < M_STRIP ? &tot->lds_need[k] : k < M_BAND ? &tot->strip_lds[k - M_STRIP] : k < M_NR ? &tot->band_lds[k - M_BAND] :
+                  k < M_TILE ? &tot->strip_nr[k - M_NR] : &tot->tile_lds, s_max[k]);
     }
     // (per-block reduction of the cell counters, one atomic per block)
     __shared__ long long red[5];

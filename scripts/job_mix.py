@@ -24,3 +24,13 @@ for f in range(4):
                 print(f'   list {l} (variant {(l - L_BAND) // 4}, lds class {(l - L_BAND) % 4}): n={ml.sum():8d}  q*t {(qq * tt).sum() / 1e9:7.2f} G  '
                       f'n_r*n_col {((qq + tt - 1) * ncol[ml]).sum() / 1e9:7.2f} G  mean q {qq.mean():7.1f} t {tt.mean():7.1f}  max q {qq.max()} t {tt.max()}  '
                       f'flags {np.unique(flag[ml] & 0xff)[:8]}')
+
+# the band lists by window kind: gap fill (approximate maximum), right extension, left extension (right-aligned gaps), exact fill
+kind = np.where(flag & 0x02, 0, np.where(flag & 0x40, np.where(flag & 0x08, 2, 1), 3))
+knames = ['gap fill (approx)', 'right extension', 'left extension', 'exact fill']
+mb = (fam == 3) & (cls >= 0)
+for k in range(4):
+    m = mb & (kind == k)
+    if m.any():
+        print(f'band windows, {knames[k]:18s}: n={m.sum():8d}  n_r*n_col {((q + t - 1) * ncol)[m].sum() / 1e9:7.2f} G  mean q {q[m].mean():7.1f} t {t[m].mean():7.1f}  '
+              f'max q {q[m].max()} t {t[m].max()}  t>1024: {(t[m] > 1024).sum()}  w<max(q,t): {(w[m] < np.maximum(q[m], t[m])).sum()}')

@@ -185,5 +185,26 @@ def test_lopsided_windows_dispatch(opt):
         q[:n] = np.where(rng.random(n) < 0.88, t[:n], q[:n])   # a homologous prefix, the rest unrelated
         qs.append(q)
         ts.append(t)
-    check(opt, qs, ts, 6000, 400, -1, APPROX, [0, 4, 1])
+    check(opt, qs, ts, 6000, 400, -1, APPROX, [0, 4, 1, 6])
     check(opt, qs, ts, 6000, 400, -1, 0, [0, 5])
+
+
+def test_tiled_banded_strips(opt):
+    """Kernel 6: the gap fills beyond the strip kernel's reach -- targets longer than 1024 rows (several tiles, the boundary between
+    them through HBM), bands that clip (freshly opened gaps at a row's first and last in-band cell), both together; windows whose
+    corner the band does not reach fall back to the other kernels.  Scores and CIGARs against the oracle."""
+    qs, ts = make_pairs(12, [900, 2500, 4100])
+    for w in (63, 127, 255, 400, 600, 751, 1023, 2000, 6000):
+        check(opt, qs, ts, w, 400, -1, APPROX, [6])
+    qs, ts = make_pairs(15, [1000, 1024, 1025, 1100, 2047, 2048, 2049, 3000, 5000])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [6, 0])
+    check(opt, qs, ts, 9000, 400, -1, APPROX, [6])          # no clipping, only tiles
+    qs, ts = make_pairs(14, [1800, 2600], ambig=True, big_indel=True)
+    check(opt, qs, ts, 300, 100, -1, APPROX, [6])
+    qs, ts = make_pairs(16, [30, 200, 700, 790])              # one tile, clipping or not
+    check(opt, qs, ts, 20, 400, -1, APPROX, [6])
+    check(opt, qs, ts, 751, 400, -1, APPROX, [6])
+    # low complexity: ties everywhere
+    qs = [np.array(([0, 1] * 1200)[:n], dtype=np.uint8) for n in (1300, 2200)] + [np.zeros(1500, dtype=np.uint8)]
+    ts = [np.array(([0, 1] * 1300)[:n + 37], dtype=np.uint8) for n in (1300, 2200)] + [np.zeros(1530, dtype=np.uint8)]
+    check(opt, qs, ts, 500, 400, -1, APPROX, [6])
