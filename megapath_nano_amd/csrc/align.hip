@@ -698,7 +698,8 @@ static void write_sam(const Targets mi_, const char *name, int32_t qlen, const c
 struct Slot {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;       // side stream: the few long windows run beside the many short ones
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipStream_t st3 = nullptr;       // third stream: the tiled strips (one wave per long gap fill) beside the band kernels
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     Arena arena;
     PoolBuf pool_jobs, pool_P, pool_P2, pool_OFF, pool_order, pool_state, pool_CIG, pool_res, pool_redo, pool_compact, pool_used;
     PoolBuf pool_redo_ids, pool_sregs, pool_souts, pool_fin_jobs, pool_fin_out, pool_fin_cig;
@@ -997,15 +998,23 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
         MPN_HIP_CHECK(hipStreamCreateWithFlags(&SL.st2, hipStreamNonBlocking));
         MPN_HIP_CHECK(hipEventCreateWithFlags(&SL.ev_a, hipEventDisableTiming));
         MPN_HIP_CHECK(hipEventCreateWithFlags(&SL.ev_b, hipEventDisableTiming));
+        MPN_HIP_CHECK(hipStreamCreateWithFlags(&SL.st3, hipStreamNonBlocking));
+        MPN_HIP_CHECK(hipEventCreateWithFlags(&SL.ev_c, hipEventDisableTiming));
     }
     MPN_HIP_CHECK(hipEventRecord(SL.ev_a, st));
     MPN_HIP_CHECK(hipStreamWaitEvent(SL.st2, SL.ev_a, 0));
-    auto on_side = [](int l) { return (l >= L_WG && l < L_STRIP) || l >= L_BAND + 8; };  // workgroup windows, 512- and 1024-slot bands
-    for (int l = N_LISTS - 1; l >= 0; --l)
+    auto on_side = [](int l) { return (l >= L_WG && l < L_STRIP) || l >= L_BAND + 8; };  // workgroup windows, 512- and 1024-slot bands, tiled strips
+    const bool have_tiles = cnt[L_TILE] > 0;
+    if (have_tiles) {   // (a wave per window for milliseconds: on a stream of its own it overlaps the band kernels instead of preceding them)
+        MPN_HIP_CHECK(hipStreamWaitEvent(SL.st3, SL.ev_a, 0));
+        if (launch_list(L_TILE, d_order.p + base[L_TILE], cnt[L_TILE], SL.st3)) return -1;
+    }
+    for (int l = L_TILE - 1; l >= 0; --l)
         if (on_side(l) && launch_list(l, d_order.p + base[l], cnt[l], SL.st2)) return -1;
     // The long windows are also the long pole of the two lane-per-window kernels (traceback, z-drop test): those of the side
     // lists run on the side stream as soon as their DP is done, beside the strip DP of the main stream.
-    const int side_lo[2] = {base[L_WG], base[L_BAND + 8]}, side_hi[2] = {base[L_STRIP], base[N_LISTS]};
+    const int side_lo[2] = {base[L_WG], base[L_BAND + 8]}, side_hi[2] = {base[L_STRIP], base[L_TILE]};
+    const int tile_lo[2] = {base[L_TILE], 0}, tile_hi[2] = {base[N_LISTS], 0};
     const int main_lo[2] = {0, base[L_STRIP]}, main_hi[2] = {base[L_WG], base[L_BAND + 8]};
     auto bt_ztest = [&](const int *lo, const int *hi, hipStream_t s, bool timed) -> int {
         for (int k = 0; k < 2; ++k) {
@@ -1024,6 +1033,10 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
         if (timed) ev.mark(26);
         return 0;
     };
+    if (have_tiles) {
+        if (bt_ztest(tile_lo, tile_hi, SL.st3, false)) return -1;
+        MPN_HIP_CHECK(hipEventRecord(SL.ev_c, SL.st3));
+    }
     if (bt_ztest(side_lo, side_hi, SL.st2, false)) return -1;
     MPN_HIP_CHECK(hipEventRecord(SL.ev_b, SL.st2));
     for (int l = N_LISTS - 1; l >= 0; --l) {  // wide before narrow, strips (the bulk) in the middle
@@ -1037,6 +1050,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     ev.mark(15);
     if (bt_ztest(main_lo, main_hi, st, true)) return -1;
     MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_b, 0));
+    if (have_tiles) MPN_HIP_CHECK(hipStreamWaitEvent(st, SL.ev_c, 0));
     unsigned long long *h_used = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(SL.pin_res.p) + ((sizeof(LayoutTotals) + 15) & ~(size_t)15));
     MPN_HIP_CHECK(hipMemcpyAsync(h_used, d_used, 48, hipMemcpyDeviceToHost, st));
     wt.stop_into(g_stats[28]);
