@@ -397,6 +397,32 @@ __global__ __launch_bounds__(256) void sketch_chunk_prefix_kernel(const int64_t 
 }
 
 // exclusive scan of n int64 by ONE block (n is the number of reads of a batch: small); out[n] = total
+// two independent scans in one launch (a stage often needs two of them at the same point: a launch each was a third of the
+// seed stage's small commands): block 0 scans the first array, block 1 the second
+__global__ __launch_bounds__(1024) void scan_i64_kernel(const int64_t *__restrict__ in, int64_t *__restrict__ out, int n);
+__global__ __launch_bounds__(1024) void scan_i64x2_kernel(const int64_t *__restrict__ in0, int64_t *__restrict__ out0, int n0,
+                                                          const int64_t *__restrict__ in1, int64_t *__restrict__ out1, int n1) {
+    __shared__ int64_t part[1024];
+    const int64_t *in = blockIdx.x ? in1 : in0;
+    int64_t *out = blockIdx.x ? out1 : out0;
+    const int n = blockIdx.x ? n1 : n0;
+    const int tid = threadIdx.x, per = (n + 1023) / 1024;
+    const int lo = min(n, tid * per), hi = min(n, lo + per);
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int64_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = tid ? part[tid - 1] : 0;
+    for (int i = lo; i < hi; ++i) { int64_t v = in[i]; out[i] = run; run += v; }
+    if (tid == 1023) out[n] = part[1023];
+}
+
 __global__ __launch_bounds__(1024) void scan_i64_kernel(const int64_t *__restrict__ in, int64_t *__restrict__ out, int n) {
     __shared__ int64_t part[1024];
     const int tid = threadIdx.x, per = (n + 1023) / 1024;

@@ -256,8 +256,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     hipLaunchKernelGGL(seed_prefix_kernel, dim3(std::max(1, std::min(n, 256 * 32))), dim3(64), 0, st, mz.p, mz_off.p, n, occ.p, rel_off.p,
                        o.n_anchor.p, o.rep_len.p, span_sum.p, n_blk.p);
     MPN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, o.n_anchor.p, full_off.p, n);
-    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, n_blk.p, blk_base.p, n);
+    hipLaunchKernelGGL(scan_i64x2_kernel, dim3(2), dim3(1024), 0, st, (const int64_t *)o.n_anchor.p, full_off.p, n, (const int64_t *)n_blk.p, blk_base.p, n);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_full = 0;  // hits of the batch's minimizers; only those that pass the stray-hit filter become anchors
     if (read_i64(full_off.p + n, &n_full, st)) return -1;
@@ -391,8 +390,7 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     }
     hipLaunchKernelGGL(anchor_compact_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const int64_t *)o.n_anchor.p, n,
                        (const unsigned long long *)read_kept.p, (const unsigned long long *)span_sum.p, kept.p, avg_qspan.p);
-    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, kept.p, o.c_off.p, n);
-    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, st, piece_kept.p, piece_off.p, (int)n_pieces);
+    hipLaunchKernelGGL(scan_i64x2_kernel, dim3(2), dim3(1024), 0, st, (const int64_t *)kept.p, o.c_off.p, n, (const int64_t *)piece_kept.p, piece_off.p, (int)n_pieces);
     MPN_HIP_CHECK(hipGetLastError());
     int64_t n_c = 0;
     if (read_i64(o.c_off.p + n, &n_c, st)) return -1;
