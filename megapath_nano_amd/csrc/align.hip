@@ -973,7 +973,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             if (fam == 0) MPN_STRIP_LAUNCH(false); else MPN_STRIP_LAUNCH(true);
 #undef MPN_STRIP_LAUNCH
         } else if (l == L_TILE) {
-            const size_t lds = (size_t)std::max(T.tile_lds, 64) + 64;
+            const size_t lds = (size_t)std::max(T.tile_lds, 64) + 64;   // (ext_tile_lds_bytes of the list's largest window)
             if (lds > 64 * 1024) MPN_HIP_CHECK(hipFuncSetAttribute((const void *)ext_dp_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(ext_dp_tile_kernel, dim3(n), dim3(64), lds, s, d_jobs.p, ord, n, prm, d_reads, d_read_off, d_read_len, rv, P.p, gstate.p, d_res.p);
         } else {

@@ -1071,15 +1071,23 @@ __host__ __device__ inline bool ext_tile_ok(int qlen, int tlen, int w) {
     return qlen > 0 && tlen > 0 && w >= 1 && d <= w && tlen <= 32768 && qlen <= 60000;
 }
 
-__global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
-                                                         ExtParams prm, const uint8_t *__restrict__ reads,
-                                                         const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
-                                                         RefView rv, uint8_t *__restrict__ P, int8_t *__restrict__ gstate, ExtRes *__restrict__ res) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// EXACT: an end extension (ksw2's exact maximum per anti-diagonal with its tie order, the z-drop rule, the best cell of the last query
+// column): every in-band cell merges (H, tie key) into its anti-diagonal's slot of an LDS table with one ds_max_u32 -- the slot's
+// band limits come from a second table -- and the rule is applied over the anti-diagonals in order after the last tile, like the
+// exact strip variants do.  RIGHT: right-aligned gaps (the left extension).  LDS: query | score table | BEST[n_r] | (st, en)[n_r].
+__host__ __device__ inline bool ext_tile_exact_ok(int qlen, int tlen, int w) {
+    return qlen > 0 && tlen > 0 && w >= 1 && tlen <= 8191 && qlen <= 16384 && qlen + tlen - 1 <= 14000;
+}
+__host__ __device__ inline int ext_tile_lds_bytes(int qlen, int tlen, bool exact) {
+    return ((qlen + 3) & ~3) + 64 + (exact ? 8 * ((qlen + tlen + 2) & ~3) : 0);
+}
+
+template <bool EXACT, bool RIGHT>
+__device__ __forceinline__ void ext_tile_body(const ExtJob &jb, const int jid, const ExtParams &prm, const uint8_t *__restrict__ reads,
+                                              const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len, const RefView &rv,
+                                              uint8_t *__restrict__ P, int8_t *__restrict__ gstate, ExtRes *__restrict__ res, uint8_t *smem) {
     constexpr int S = TILE_S;
     const int lane = threadIdx.x;
-    const int jid = order[blockIdx.x];
-    const ExtJob jb = jobs[jid];
     const int qlen = jb.qlen, tlen = jb.tlen;
     int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
     if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
@@ -1089,9 +1097,9 @@ __global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restric
     ExtRes out;
     out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = NEG_INF;
     out.reach_end = 0; out.n_cigar = 0; out.r_done = -1; out.bt_i = out.bt_j = -1; out.do_bt = 0; out.zcode = 0; out.cig_pos = 0;
-    if (!ext_tile_ok(qlen, tlen, w) || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
+    if (!(EXACT ? ext_tile_exact_ok(qlen, tlen, w) : ext_tile_ok(qlen, tlen, w)) || -prm.sc_mis > 2 * (q + e)) { if (lane == 0) res[jid] = out; return; }
     // ---- the cell's constants (see ext_strip_pack) ----
-    constexpr int RS = 4, RA = 3, RB = 2, RA2 = 1, RB2 = 0;
+    constexpr int RS = RIGHT ? 0 : 4, RA = RIGHT ? 1 : 3, RB = 2, RA2 = RIGHT ? 3 : 1, RB2 = RIGHT ? 4 : 0;
     const uint32_t sb_mch = (uint32_t)(8 * prm.sc_mch + RS + 128) & 0xff, sb_mis = (uint32_t)(8 * prm.sc_mis + RS + 128) & 0xff,
                    sb_n = (uint32_t)(8 * prm.sc_n + RS + 128) & 0xff;
     const int q_pad = (qlen + 3) & ~3;
@@ -1115,7 +1123,8 @@ __global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restric
     const uint32_t FRESH_U = pk(-8 * qe, -8 * qe) + CU, EDGE_V = pk(-8 * qe, -8 * qe) + CV;
     const uint32_t KONST = sb_n | 0x2000u;
     const uint32_t KZZ = pk(-16 * qe + RA + RB + BETA, -16 * qe2 + RA2 + RB2 + BETA);
-    const uint32_t KEA = pk(8 * e - 8 * qe + RA, 8 * e2 - 8 * qe2 + RA2), KEB = pk(8 * e - 8 * qe + RB, 8 * e2 - 8 * qe2 + RB2);
+    constexpr int RU = RIGHT ? 8 : 0;
+    const uint32_t KEA = pk(8 * e - 8 * qe + RA - RU, 8 * e2 - 8 * qe2 + RA2 - RU), KEB = pk(8 * e - 8 * qe + RB - RU, 8 * e2 - 8 * qe2 + RB2 - RU);
     const uint32_t EIGHT = 0x00080008u, RANK_CLR = 0xfff8fff8u;
     const uint32_t MCH7 = (uint32_t)(8 * prm.sc_mch + 7 + BETA) * 0x00010001u;
     const int64_t g0 = rv.seq_off[jb.rid] + jb.ts;
@@ -1123,6 +1132,26 @@ __global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restric
     // while it writes for the next)
     uint32_t *bnd_base = reinterpret_cast<uint32_t *>(gstate + jb.state_off);
     const int n_tiles = (tlen + TILE_ROWS - 1) / TILE_ROWS;
+    // EXACT: per anti-diagonal the running (H, tie key) maximum and the band limits; per target row H in the last query column
+    const int n_r = qlen + tlen - 1;
+    uint32_t *BEST = reinterpret_cast<uint32_t *>(smem + q_pad + 64), *SE = BEST + ((n_r + 3) & ~3);
+    int32_t *HL = reinterpret_cast<int32_t *>(bnd_base + 6 * (size_t)qlen);
+    int r_lim = n_r;   // first anti-diagonal whose band lies outside the matrix (ksw2 stops there as z-dropped)
+    if constexpr (EXACT) {
+        for (int r = lane; r < n_r; r += 64) {
+            int st = 0, en = tlen - 1;
+            if (st < r - qlen + 1) st = r - qlen + 1;
+            if (en > r) en = r;
+            if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+            if (en > (r + w) >> 1) en = (r + w) >> 1;
+            if (st > en) { r_lim = r_lim < r ? r_lim : r; st = 1; en = 0; }
+            BEST[r] = 0;
+            SE[r] = (uint32_t)st | (uint32_t)en << 16;
+        }
+        for (int t = lane; t < tlen; t += 64) HL[t] = NEG_INF;
+        r_lim = wave_reduce_min(r_lim);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
     __syncthreads();
     const bool head = lane == 0;
     int32_t score8 = 0;
@@ -1199,11 +1228,15 @@ __global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restric
                     const uint32_t Zc = zc & RANK_CLR;
                     const uint32_t ZZ = Zc + KZZ;
                     const uint32_t nu = ZZ - Vp, nv = ZZ - Up;
-                    const u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
-                    const u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
+                    u16x2 An = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A), __builtin_bit_cast(u16x2, Zc + KEA));
+                    u16x2 Bn = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B), __builtin_bit_cast(u16x2, Zc + KEB));
                     uint32_t HA, HB;
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA) : "v"(__builtin_bit_cast(uint32_t, An)), "v"(EIGHT));
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB) : "v"(__builtin_bit_cast(uint32_t, Bn)), "v"(EIGHT));
+                    if constexpr (RIGHT) {   // (right-aligned gaps: the states were one unit high for the >= 0 flags)
+                        An = __builtin_elementwise_sub_sat(An, __builtin_bit_cast(u16x2, EIGHT));
+                        Bn = __builtin_elementwise_sub_sat(Bn, __builtin_bit_cast(u16x2, EIGHT));
+                    }
                     uint32_t Fw;
                     asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(Fw) : "v"(HB), "v"(HA));
                     asm("v_and_or_b32 %0, %1, 7, %2" : "=v"(ecell[k & 3]) : "v"(z16), "v"(Fw));
@@ -1212,6 +1245,17 @@ __global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restric
                     const int32_t h = enter ? h_up : h_left;
                     H8[k] = h;
                     Hup = h;
+                    if constexpr (EXACT) {
+                        const int t = t0 + k, r = t + j;
+                        const uint32_t se = SE[r < n_r ? r : n_r - 1];
+                        const int st_ = (int)(se & 0xffffu), en_ = (int)(se >> 16);
+                        const bool inb = t >= st_ && t <= en_;
+                        const int en1 = st_ + ((en_ - st_) & ~3);
+                        const int cls = t == en_ ? 0 : t < en1 ? 1 + ((t - st_) & 3) : 5;   // ksw2's tie order: the band's last cell, then its 4-lane classes, then the tail
+                        const uint32_t word = (uint32_t)((h >> 3) + 32768) << 16 | (0xffffu - ((uint32_t)cls << 13 | (uint32_t)t));
+                        atomicMax(&BEST[r < n_r ? r : n_r - 1], inb ? word : 0u);
+                        if (inb && j == qlen - 1) HL[t] = h >> 3;
+                    }
                     UL[k] = nu; YL[k] = __builtin_bit_cast(uint32_t, Bn);
                     Vp = nv; Xp = __builtin_bit_cast(uint32_t, An);
                     if ((k & 3) == 3) {
@@ -1243,13 +1287,89 @@ __global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restric
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 #undef MPN_BND
-    if (lane == 0) {
-        out.score = score8 >> 3;
-        out.r_done = qlen + tlen - 2;
-        out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1;
-        res[jid] = out;
+    if constexpr (!EXACT) {
+        if (lane == 0) {
+            out.score = score8 >> 3;
+            out.r_done = qlen + tlen - 2;
+            out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1;
+            res[jid] = out;
+        }
+    } else {
+        // ---- the z-drop rule over the anti-diagonals in order (as in ext_strip_pack's exact variants, 64 lanes wide) ----
+        __syncthreads();
+        const int tlm1 = tlen - 1;
+        struct Best { int m, t, r; };
+        auto scan_first_max = [&](Best x) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const Best o{__shfl_up(x.m, d), __shfl_up(x.t, d), __shfl_up(x.r, d)};
+                if (lane >= d && !(x.m > o.m)) x = o;
+            }
+            return x;
+        };
+        auto diag = [&](int r, int &H, int &mt) {
+            const uint32_t pv = BEST[r];
+            H = pv ? (int)(pv >> 16) - 32768 : NEG_INF;
+            mt = (int)((0xffffu - (pv & 0xffffu)) & 8191u);
+        };
+        const int n_eff = r_lim < n_r ? r_lim : n_r;   // anti-diagonals ksw2 computes
+        const int C = (n_eff + 63) / 64, rlo = min(n_eff, lane * C), rhi = min(n_eff, rlo + C);
+        auto chunk_best = [&](int lim) {
+            Best b{NEG_INF, -1, -1};
+            for (int r = rlo; r < rhi && r <= lim; ++r) { int H, mt; diag(r, H, mt); if (H > b.m) b = Best{H, mt, r}; }
+            return b;
+        };
+        Best incl = scan_first_max(chunk_best(n_eff));
+        Best in{__shfl_up(incl.m, 1), __shfl_up(incl.t, 1), __shfl_up(incl.r, 1)};
+        ExtApply ez; ez.max = 0; ez.max_t = ez.max_q = -1; ez.zdropped = 0;
+        if (lane > 0 && in.m > 0) { ez.max = in.m; ez.max_t = in.t; ez.max_q = in.r - in.t; }
+        int r_break = n_eff;
+        for (int r = rlo; r < rhi; ++r) {
+            int H, mt; diag(r, H, mt);
+            if (ext_apply_zdrop(ez, H, r, mt, jb.zdrop, e2)) { r_break = r; break; }
+        }
+        r_break = wave_reduce_min(r_break);
+        const bool zd = r_break < n_eff;            // the z-drop rule fired
+        const bool dropped = zd || n_eff < n_r;      // ... or the band left the matrix (st > en: ksw2 sets zdropped and stops)
+        const int r_last = zd ? r_break : n_eff - 1; // last anti-diagonal whose cells count
+        Best fin = scan_first_max(chunk_best(r_last));
+        fin = Best{__shfl(fin.m, 63), __shfl(fin.t, 63), __shfl(fin.r, 63)};
+        // best cell of the last query column among the anti-diagonals qlen - 1 .. r_last (target rows 0 .. r_last - qlen + 1)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int t_lim = min(tlm1, r_last - (qlen - 1));
+        const int Ct = (tlen + 63) / 64, tlo = min(tlen, lane * Ct), thi = min(tlen, tlo + Ct);
+        Best me{NEG_INF, -1, -1};
+        for (int t = tlo; t < thi && t <= t_lim; ++t) { const int h = HL[t]; if (h > me.m) me = Best{h, t, t}; }
+        me = scan_first_max(me);
+        me = Best{__shfl(me.m, 63), __shfl(me.t, 63), 0};
+        if (lane == 0) {
+            if (fin.m > 0) { out.max = fin.m; out.max_t = fin.t; out.max_q = fin.r - fin.t; }
+            out.zdropped = dropped ? 1 : 0;
+            if (me.m > NEG_INF) { out.mqe = me.m; out.mqe_t = me.t; }
+            if (!dropped) out.score = HL[tlm1];
+            out.r_done = dropped ? (zd ? r_break : n_eff) : n_r - 1;
+            if (!dropped && !(jb.flag & EZ_EXTZ_ONLY)) { out.do_bt = 1; out.bt_i = tlen - 1; out.bt_j = qlen - 1; }
+            else if (!dropped && (jb.flag & EZ_EXTZ_ONLY) && out.mqe + jb.end_bonus > out.max) { out.reach_end = 1; out.do_bt = 1; out.bt_i = out.mqe_t; out.bt_j = qlen - 1; }
+            else if (out.max_t >= 0 && out.max_q >= 0) { out.do_bt = 1; out.bt_i = out.max_t; out.bt_j = out.max_q; }
+            res[jid] = out;
+        }
     }
 }
+
+__global__ __launch_bounds__(64) void ext_dp_tile_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
+                                                         ExtParams prm, const uint8_t *__restrict__ reads,
+                                                         const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                                         RefView rv, uint8_t *__restrict__ P, int8_t *__restrict__ gstate, ExtRes *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int jid = order[blockIdx.x];
+    const ExtJob jb = jobs[jid];
+    // (a workgroup is one window: one branch per window into the instantiation that carries only its own bookkeeping)
+    if (jb.flag & EZ_APPROX_MAX) ext_tile_body<false, false>(jb, jid, prm, reads, read_off, read_len, rv, P, gstate, res, smem);
+    else if (jb.flag & EZ_RIGHT) ext_tile_body<true, true>(jb, jid, prm, reads, read_off, read_len, rv, P, gstate, res, smem);
+    else ext_tile_body<true, false>(jb, jid, prm, reads, read_off, read_len, rv, P, gstate, res, smem);
+}
+
+
 
 // traceback: one lane per job (serial pointer chase; parallelism across jobs hides the latency)
 __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, int n_jobs,
@@ -1333,7 +1453,7 @@ __global__ __launch_bounds__(64) void ext_bt_kernel(const ExtJob *__restrict__ j
                 if (tile != tg_tile) { tg = tile_geom(tile, jb.qlen, jb.tlen, bw); tg_tile = tile; }   // (the walk only descends: a few times per window)
                 const int lt = i - tg.T0;
                 tmp = p[tg.base + (int64_t)((j - tg.jlo) + lt / TILE_S) * tg.W + lt];
-                tmp = (tmp & ~7) | (4 - (tmp & 7));
+                if (!rank_is_op) tmp = (tmp & ~7) | (4 - (tmp & 7));
             }
         }
         else if (byslot) {

@@ -342,8 +342,11 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         }
         const bool strip = glc >= 0;
         // tiled strips: the gap fills the strip kernel cannot take (target beyond 1024 rows, or a band that clips)
-        const bool tiled = !strip && strip_scores && (jb.flag & EZ_APPROX_MAX) && !(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed &&
-                           ext_tile_ok(jb.qlen, jb.tlen, w) && !no_tile && (force_kernel == 0 || force_kernel == 6);
+        // ... and the end extensions (exact maximum, z-drop) beyond the exact strip variants' reach
+        const bool tile_exact = !(jb.flag & EZ_APPROX_MAX);
+        const bool tiled = !strip && strip_scores && !no_tile && (force_kernel == 0 || force_kernel == 6) &&
+                           (tile_exact ? ext_tile_exact_ok(jb.qlen, jb.tlen, w)
+                                       : (!(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed && ext_tile_ok(jb.qlen, jb.tlen, w)));
         const int sclass = variant * 3 + max(glc, 0);
         const int seqb = ((jb.qlen + 3) & ~3) + ((jb.tlen + 3) & ~3);
         // band kernel: the band (n_col - 1 cells at most) plus the stale left neighbour must fit the slots
@@ -377,8 +380,9 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         }
         else if (tiled) {
             lid = L_TILE;
-            atomicMax(&s_max[M_TILE], (jb.qlen + 3) & ~3);
-            sz.st = ((long long)24 * jb.qlen + 15) & ~15LL;   // the boundary between tiles: two buffers of 12 bytes per query column
+            atomicMax(&s_max[M_TILE], ext_tile_lds_bytes(jb.qlen, jb.tlen, tile_exact));
+            // the boundary between tiles: two buffers of 12 bytes per query column; exact: + H of the last query column per target row
+            sz.st = ((long long)24 * jb.qlen + (tile_exact ? (long long)4 * jb.tlen : 0) + 15) & ~15LL;
         }
         else if (bv >= 0) lid = L_BAND + bv * 4 + bc;
         else lid = redo_list;

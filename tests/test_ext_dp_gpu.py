@@ -208,3 +208,42 @@ def test_tiled_banded_strips(opt):
     qs = [np.array(([0, 1] * 1200)[:n], dtype=np.uint8) for n in (1300, 2200)] + [np.zeros(1500, dtype=np.uint8)]
     ts = [np.array(([0, 1] * 1300)[:n + 37], dtype=np.uint8) for n in (1300, 2200)] + [np.zeros(1530, dtype=np.uint8)]
     check(opt, qs, ts, 500, 400, -1, APPROX, [6])
+
+
+def test_tiled_exact_extensions(opt):
+    """Kernel 6 on end extensions and exact fills beyond the exact strip variants' reach (targets > 1024 rows, clipping bands): the
+    maximum of every anti-diagonal with ksw2's tie order over IN-BAND cells, z-drop in the middle, the band leaving the matrix
+    (st > en), the best cell of the last query column, the end bonus, right-aligned gaps on reversed sequences; low complexity."""
+    qs, ts = make_pairs(13, [700, 2000, 3500], tail=True)
+    for w in (100, 200, 500, 751, 1000):
+        check(opt, qs, ts, w, 400, -1, EXTZ, [6])
+        check(opt, qs, ts, w, 200, 30, EXTZ | RIGHT | REV, [6])
+    qs, ts = make_pairs(9, [3000, 5200], tail=True)
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [6, 0])
+    check(opt, qs, ts, 751, 400, -1, EXTZ | RIGHT | REV, [6, 0])
+    qs, ts = make_pairs(17, [1100, 1500, 2600, 4800])           # no tail: the extension runs to the end (reach_end / mqe)
+    check(opt, qs, ts, 751, 400, 10, EXTZ, [6])
+    check(opt, qs, ts, 751, 400, -1, EXTZ | RIGHT | REV, [6])
+    check(opt, qs, ts, 751, 400, -1, 0, [6])                    # exact global fill
+    check(opt, qs, ts, 300, 100, -1, 0, [6])
+    qs, ts = make_pairs(18, [1200, 2500], ambig=True, big_indel=True)
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [6])
+    check(opt, qs, ts, 751, 100, 5, EXTZ | RIGHT | REV, [6])
+    # lopsided: the band leaves the matrix long before the query ends
+    rng = np.random.default_rng(3)
+    qs, ts = [], []
+    for qlen, tlen in ((5000, 1300), (1300, 5000), (4000, 1100), (600, 1500)):
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        q = rng.integers(0, 4, size=qlen).astype(np.uint8)
+        n = min(qlen, tlen)
+        q[:n] = np.where(rng.random(n) < 0.9, t[:n], q[:n])
+        qs.append(q)
+        ts.append(t)
+    check(opt, qs, ts, 751, 400, -1, EXTZ, [6])
+    check(opt, qs, ts, 200, 400, -1, EXTZ | RIGHT | REV, [6])
+    # low complexity: ties on every anti-diagonal
+    qs = [np.array(([0, 1] * 1200)[:n], dtype=np.uint8) for n in (1300, 2200)] + [np.zeros(1500, dtype=np.uint8)]
+    ts = [np.array(([0, 1] * 1300)[:n + 37], dtype=np.uint8) for n in (1300, 2200)] + [np.zeros(1530, dtype=np.uint8)]
+    for flag in (EXTZ, EXTZ | RIGHT | REV, 0):
+        check(opt, qs, ts, 500, 400, -1, flag, [6])
+        check(opt, qs, ts, 500, 20, 3, flag, [6])
