@@ -277,6 +277,11 @@ __global__ __launch_bounds__(64) void plan_kernel(PlanOpt o, const PlanReg *__re
     }
 }
 
+// An exact tiled window runs on ONE wave at ~50 instructions per cell: 4 ms for 3000 anti-diagonals, 26 ms for a 5000 x 5000
+// extension -- twice the band kernel's eight waves.  The pipeline is sensitive to that pole (-17 % on the strain-rich headline with
+// every extension tiled), so the longest extensions stay on the band kernel.
+constexpr int TILE_EXACT_MAX_NR = 4096;
+
 // ---- kernel choice and direction-matrix layout of every window --------------------------------------------------------------
 // launch lists: every DP window belongs to exactly one
 // (strip lists: kernel variant (gap fill with approximate maximum / exact / exact with right-aligned gaps) x lane-group class
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) void job_classify_kernel(ExtJob *__restrict__ 
         // ... and the end extensions (exact maximum, z-drop) beyond the exact strip variants' reach
         const bool tile_exact = !(jb.flag & EZ_APPROX_MAX);
         const bool tiled = !strip && strip_scores && !no_tile && (force_kernel == 0 || force_kernel == 6) &&
-                           (tile_exact ? ext_tile_exact_ok(jb.qlen, jb.tlen, w)
+                           (tile_exact ? (ext_tile_exact_ok(jb.qlen, jb.tlen, w) && (force_kernel == 6 || jb.qlen + jb.tlen <= TILE_EXACT_MAX_NR))
                                        : (!(jb.flag & (EZ_EXTZ_ONLY | EZ_RIGHT)) && !jb.reversed && ext_tile_ok(jb.qlen, jb.tlen, w)));
         const int sclass = variant * 3 + max(glc, 0);
         const int seqb = ((jb.qlen + 3) & ~3) + ((jb.tlen + 3) & ~3);
