@@ -674,21 +674,27 @@ def main():
     #   chain DP                     : 16 B per kept anchor in + 16 B (f, p, t, v) out
     #   strip DP (gap fill / exact)  : 1 direction byte out per DP cell (qlen x tlen per window)
     #   alignment finishing          : 4 B per CIGAR op in + 4 B out, ~1 B per aligned query base + 0.25 B per target base in
-    strip_cells = st['strip16_cells'] + st['strip32_cells'] + st['strip64_cells']
-    cand = {
-        'sketch_fast_kernel + sketch_fill_kernel': (('k_sketch_count_ns', 'k_sketch_fill_ns'), ('sub', 2), 2 * st['bases'] + 16 * st['minimizers'], 0),
-        'seed_lookup_kernel': (('k_seed_lookup_ns',), ('sub', 1), 28 * st['minimizers'], 0),
-        'seed_filter_kernel': (('k_seed_filter_ns',), ('sub', 1), 16 * st['anchors'] + st['anchors'] / 8, 0),
-        'seed_emit_kernel': (('k_seed_fill_ns',), ('sub', 1), 24 * st['anchors_emitted'], 0),
-        'anchor_msd_kernel': (('k_sort_msd_ns',), ('sub', 1), 40 * st['anchors_emitted'], 0),
-        'anchor_window_sort_kernel': (('k_sort_chunk_ns',), ('sub', 1), 32 * st['anchors_emitted'], 0),
-        'anchor_compact_kernel<count|write>': (('k_compact_ns',), ('sub', 2), 32 * st['anchors_emitted'] + 16 * st['anchors_kept'], 0),
-        'chain_dp_kernel': (('k_chain_dp_ns',), ('sub', 1), 32 * st['anchors_kept'], 0),
-        # (one launch per round: 16-, 32- and 64-lane groups are segments of its grid)
-        'ext_dp_strip_kernel<false> (gap fills)': (('k_strip16_ns', 'k_strip32_ns', 'k_strip64_ns'), ('round', 1), strip_cells, strip_cells),
-        'ext_dp_strip_kernel<true> (end extensions, exact fills)': (('k_xstrip_ns',), ('round', 1), st['xstrip_cells'], st['xstrip_cells']),
-        'aln_finish_wave_kernel': (('k_finish_ns',), ('round', 4), 8 * st['cigar_ops'] + 2 * st['bases'], 0),
-    }
+    def candidates(s):
+        strip_cells = s['strip16_cells'] + s['strip32_cells'] + s['strip64_cells']
+        return {
+            'sketch_fast_kernel + sketch_fill_kernel': (('k_sketch_count_ns', 'k_sketch_fill_ns'), ('sub', 2), 2 * s['bases'] + 16 * s['minimizers'], 0),
+            'seed_lookup_kernel': (('k_seed_lookup_ns',), ('sub', 1), 28 * s['minimizers'], 0),
+            'seed_filter_kernel': (('k_seed_filter_ns',), ('sub', 1), 16 * s['anchors'] + s['anchors'] / 8, 0),
+            'seed_emit_kernel': (('k_seed_fill_ns',), ('sub', 1), 24 * s['anchors_emitted'], 0),
+            'anchor_msd_kernel': (('k_sort_msd_ns',), ('sub', 1), 40 * s['anchors_emitted'], 0),
+            'anchor_window_sort_kernel': (('k_sort_chunk_ns',), ('sub', 1), 32 * s['anchors_emitted'], 0),
+            'anchor_compact_kernel<count|write>': (('k_compact_ns',), ('sub', 2), 32 * s['anchors_emitted'] + 16 * s['anchors_kept'], 0),
+            'chain_dp_kernel': (('k_chain_dp_ns',), ('sub', 1), 32 * s['anchors_kept'], 0),
+            # (one launch per round: 16-, 32- and 64-lane groups are segments of its grid)
+            'ext_dp_strip_kernel<false> (gap fills)': (('k_strip16_ns', 'k_strip32_ns', 'k_strip64_ns'), ('round', 1), strip_cells, strip_cells),
+            'ext_dp_strip_kernel<true> (end extensions, exact fills)': (('k_xstrip_ns',), ('round', 1), s['xstrip_cells'], s['xstrip_cells']),
+            'aln_finish_wave_kernel': (('k_finish_ns',), ('round', 4), 8 * s['cigar_ops'] + 2 * s['bases'], 0),
+        }
+    cand = candidates(st)
+    # The single-worker pass maps a slice of a batch part by part: its launches are not the timed region's launches (the sub-batches
+    # of one worker with the whole scratch are larger), so its fractions are formed from ITS OWN algorithmic bytes and cells, and
+    # its time is scaled to a step by the kernel's algorithmic bytes (a slice maps the same reads against every part, like a step).
+    cand_alone = candidates(alone) if alone is not None else None
     VALU_PEAK = 1024 * 2.4e9 / 2.0    # MI355X_MICROARCH.md: 1024 SIMDs, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
     wi_per_cell = STRIP_INSTR_PER_CELL / 64.0
     rows = {}
@@ -699,11 +705,12 @@ def main():
         row = {'launches_per_step': round(launches, 1), 'alg_GB_per_step': round(abytes / 1e9, 3),
                'in_pipeline_ms': round(ns_pipe / 1e6 / max(launches, 1), 3), 'in_pipeline_ms_per_step': round(ns_pipe / 1e6, 2)}
         if alone is not None:
-            # the single-worker pass ran a fraction of a step: scale by the work unit the kernel's time follows (read bases)
             ns_alone = sum(alone[k] for k in keys)
             launches_a = n_launch(unit, alone)
+            abytes_a = cand_alone[name][2]
             row['alone_ms'] = round(ns_alone / 1e6 / max(launches_a, 1), 3)
-            row['alone_ms_per_step'] = round(ns_alone / 1e6 * st['bases'] / max(alone['bases'], 1), 2)
+            row['alone_alg_GB_per_launch'] = round(abytes_a / 1e9 / max(launches_a, 1), 4)
+            row['alone_ms_per_step'] = round(ns_alone / 1e6 * abytes / max(abytes_a, 1), 2)
         rows[name] = row
     # the dominant kernel: largest EXCLUSIVE device time per step (alone), else largest in-pipeline span
     keyf = (lambda k: rows[k].get('alone_ms_per_step', 0.0)) if alone is not None else (lambda k: rows[k]['in_pipeline_ms_per_step'])
@@ -722,8 +729,10 @@ def main():
         'chosen_by': 'largest exclusive device time per step (single-worker pass)' if alone is not None else 'largest in-pipeline HIP-event span (no single-worker pass)',
     }
     if alone is not None:
+        ns_alone_dom = max(sum(alone[k] for k in keys), 1)
         roof['alone_ms'] = rows[dom]['alone_ms']
-        roof['frac_alone'] = round(abytes / max(launches, 1) / max(rows[dom]['alone_ms'] * 1e6, 1) / HBM_PEAK_GBS, 5)
+        roof['alone_algorithmic_bytes_per_launch'] = int(cand_alone[dom][2] / max(n_launch(unit, alone), 1))
+        roof['frac_alone'] = round(cand_alone[dom][2] / ns_alone_dom / HBM_PEAK_GBS, 5)
     if cells:
         wi_launch = cells * wi_per_cell / max(launches, 1)
         roof['valu'] = {
@@ -731,7 +740,7 @@ def main():
             'peak_wave_instr_per_s': VALU_PEAK,
             'achieved_wave_instr_per_s': round(wi_launch / max(ns / max(launches, 1), 1) * 1e9, 0),
             'frac': round(wi_launch / max(ns / max(launches, 1), 1) * 1e9 / VALU_PEAK, 4),
-            'frac_alone': round(wi_launch / max(rows[dom]['alone_ms'] * 1e6, 1) * 1e9 / VALU_PEAK, 4) if alone is not None else None,
+            'frac_alone': round(cand_alone[dom][3] * wi_per_cell / ns_alone_dom * 1e9 / VALU_PEAK, 4) if alone is not None else None,
             'mix_ceiling_wave_instr_per_s': VALU_CEIL_WAVE_INSTR,
             'gcups_whole_step': round(st['dp_cells'] / (dt / K * 1e9), 2),
             'note': 'the DP kernels are bound by VALU issue, not by HBM. wave-instructions = cells x 21.5 (ISA count of the loop body per cell and lane) / 64: '
@@ -740,8 +749,9 @@ def main():
                     'at 2.7 cycles + 12 packed / three-operand ones at 4.4 per cell).',
         }
     roof['note'] = ('in_pipeline_ms / frac: HIP-event span per launch on its own stream over the timed region, while the other pipeline workers share the GPU '
-                    '(the rocprofv3 average of the same command, profiles/, is the figure to compare). alone_ms / frac_alone: the same launch with nothing else on '
-                    'the GPU (single-worker pass after the timed region). traffic: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from committed PMC passes of the '
+                    '(the rocprofv3 average of the same command, profiles/, is the figure to compare). alone_ms / frac_alone: the kernel with nothing else on '
+                    'the GPU (single-worker pass over a slice of a batch after the timed region; its launches are larger than the pipeline\'s, so the fractions use the '
+                    'slice\'s own bytes and cells: alone_algorithmic_bytes_per_launch). traffic: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from committed PMC passes of the '
                     'same workload (separate rocprofv3 runs), null when none is committed for this --config.')
     roof['candidates'] = rows
     roof['whole_path_alg_bytes_per_bp'] = round(9.73 + 13.1 * hits_per_mz + 1.75 * st['alignments'] / max(args.reads_per_step, 1), 2)

@@ -1367,17 +1367,25 @@ __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restri
     }
 }
 
+// An anchor in the LDS ring: one ds_read_b128.  x is NOT the reference coordinate but its running sum with every step between
+// consecutive anchors clamped to max_dist_x + 1 (mod 2^32): inside a segment -- where every step is at most max_dist_x -- differences
+// are the true ones, across a segment boundary (another target, another strand) they exceed max_dist_x like the true ones; the
+// predecessors an anchor can see are at most max_iter anchors back, so a difference never wraps.  The DP then runs on 32-bit numbers.
+struct ChainSlot { uint32_t x; int32_t y, f, p; };
+
 __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
                                                       const float *__restrict__ avg_qspan_r, const ChainSeg *__restrict__ seg_big,
                                                       const ChainSeg *__restrict__ seg_small, unsigned int *__restrict__ counters,
                                                       ChainParams cp, int32_t *__restrict__ F, int32_t *__restrict__ P,
                                                       int32_t *__restrict__ T, int32_t *__restrict__ V) {
     __shared__ int mark[64];
-    __shared__ uint64_t wx[CHAIN_CW], wy[CHAIN_CW];
-    __shared__ int32_t wf[CHAIN_CW], wp[CHAIN_CW], wt[CHAIN_CW], wv[CHAIN_CW];
-    constexpr int64_t M = CHAIN_CW - 1;
+    __shared__ __attribute__((aligned(16))) ChainSlot ring[CHAIN_CW];
+    __shared__ int32_t wt[CHAIN_CW], wv[CHAIN_CW];
+    constexpr int M = CHAIN_CW - 1;
     const int lane = threadIdx.x;
     const unsigned int n_big = counters[0], n_seg = n_big + counters[1];
+    const uint32_t clamp_x = (uint32_t)cp.max_dist_x + 1u;
+    const int32_t max_dq = cp.max_dist_y < cp.max_dist_x ? cp.max_dist_y : cp.max_dist_x;
     for (;;) {
         unsigned int sidx = 0;
         if (lane == 0) sidx = atomicAdd(&counters[2], 1u);  // shared queue: big segments first
@@ -1386,31 +1394,39 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
         const ChainSeg sg = sidx < n_big ? seg_big[sidx] : seg_small[sidx - n_big];
         // the segment is chained like a read of its own; predecessor indices are stored relative to the read
         const int64_t base = anchor_off[sg.read] + sg.start;
-        const int64_t n = sg.end - sg.start;
+        const int32_t n = sg.end - sg.start;
         const int32_t rel = sg.start;
         const u128 *a = anchors + base;
         int32_t *f = F + base, *p = P + base, *t = T + base, *v = V + base;
-        for (int64_t i = lane; i < n; i += 64) t[i] = 0;
+        for (int32_t i = lane; i < n; i += 64) t[i] = 0;
         const float avg_qspan = avg_qspan_r[sg.read];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // chunk registers: lane l holds anchor c0 + l of the current chunk and of the next one; results of the chunk
-        uint64_t cx = lane < n ? a[lane].x : 0, cy = lane < n ? a[lane].y : 0, nx = 0, ny = 0;
+        // (cx: the clamped running coordinate, cx64 the true one for predecessors that have left the ring)
+        auto step_of = [&](int32_t k, uint64_t x) -> uint32_t {   // clamped step from anchor k - 1 to anchor k
+            if (k == 0) return 0u;
+            const uint64_t d = x - a[k - 1].x;
+            return d > (uint64_t)clamp_x ? clamp_x : (uint32_t)d;
+        };
+        uint64_t cx64 = 0, nx64 = 0;
+        uint32_t cx = 0, cyl = 0, cyh = 0, nstep = 0, nyl = 0, nyh = 0;
+        if (lane < n) { const u128 r = a[lane]; cx64 = r.x; cyl = (uint32_t)r.y; cyh = (uint32_t)(r.y >> 32); cx = step_of(lane, r.x); }
+        cx = (uint32_t)wave_scan_add((int)cx);
         int32_t rf = 0, rp = -1, rv = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            const int li = (int)(i & 63);
+        for (int32_t i = 0; i < n; ++i) {
+            const int li = i & 63;
             if (li == 0) {  // prefetch the next chunk
-                const int64_t k = i + 64 + lane;
-                if (k < n) { nx = a[k].x; ny = a[k].y; }
+                const int32_t k = i + 64 + lane;
+                nstep = 0;
+                if (k < n) { const u128 r = a[k]; nx64 = r.x; nyl = (uint32_t)r.y; nyh = (uint32_t)(r.y >> 32); nstep = step_of(k, r.x); }
             }
-            const uint64_t ri = readlane_u64(cx, li), yi = readlane_u64(cy, li);
-            const int32_t qi = (int32_t)yi, q_span = yi >> 32 & 0xff;
-            int32_t max_f = q_span, n_skip = 0;
-            int64_t max_j = -1;
-            const int64_t win_lo = i - CHAIN_CW;  // anchors j >= win_lo (and < i) are in the LDS ring
+            const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)cx, li);
+            const int32_t qi = __builtin_amdgcn_readlane((int)cyl, li), q_span = __builtin_amdgcn_readlane((int)cyh, li) & 0xff;
+            int32_t max_f = q_span, n_skip = 0, max_j = -1;
+            const int32_t win_lo = i - CHAIN_CW;  // anchors j >= win_lo (and < i) are in the LDS ring
             bool done = false;
-            for (int64_t j0 = i - 1; j0 >= 0 && !done; j0 -= 64) {
-                const int64_t j = j0 - lane;
-                const bool inw = j >= win_lo;
+            for (int32_t j0 = i - 1; j0 >= 0 && !done; j0 -= 64) {
+                const int32_t j = j0 - lane;
                 // A tile that lies in the LDS ring as a whole takes the short way with the marks below: every predecessor that
                 // passes the filters marks its own predecessor in the ring BEFORE the marks are read.  A mark goes to a LATER
                 // lane (an earlier anchor) only, so a lane still sees exactly the marks of the lanes before it; the marks of
@@ -1418,29 +1434,37 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                 // nothing to the anchors after i.  Two LDS round trips per tile instead of four.
                 const bool tile_in_ring = j0 - 63 >= win_lo;   // (uniform)
                 bool in = j >= 0 && i - j <= cp.max_iter;
-                bool cont = true;
-                int32_t sc = NEG_INF, pj = -1, tj = 0;
-                if (in) {
-                    uint64_t ax, ay;
-                    int32_t fj;
-                    if (inw) { const int sl = (int)(j & M); ax = wx[sl]; ay = wy[sl]; pj = wp[sl]; if (!tile_in_ring) tj = wt[sl]; fj = wf[sl]; }
-                    else { ax = a[j].x; ay = a[j].y; pj = p[j]; pj = pj >= 0 ? pj - rel : pj; tj = t[j]; fj = f[j]; }
-                    if (ri > ax + (uint64_t)cp.max_dist_x) in = false;  // out of range: so is everything before it
-                    else {
-                        const int64_t dr = (int64_t)(ri - ax);
-                        const int32_t dq = qi - (int32_t)ay;
-                        if (!(dr == 0 || dq <= 0) && !(dq > cp.max_dist_y || dq > cp.max_dist_x)) {
-                            const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-                            if (dd <= cp.bw) {
-                                const int32_t min_d = dq < dr ? dq : (int32_t)dr;
-                                int32_t s = min_d > q_span ? q_span : min_d;
-                                const int32_t log_dd = dd ? ilog2_32((uint32_t)dd) : 0;
-                                const int32_t gap_cost = (int)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);
-                                sc = s - gap_cost + fj;
-                                cont = false;
-                            }
+                int32_t pj, tj = 0, fj, dq;
+                uint32_t dr;
+                if (tile_in_ring) {
+                    // (a lane with j < 0 reads a slot of the ring too: whatever it holds is discarded with `in`)
+                    const uint4 sl = *reinterpret_cast<const uint4 *>(&ring[j & M]);
+                    dr = ri - sl.x; dq = qi - (int32_t)sl.y; fj = (int32_t)sl.z; pj = (int32_t)sl.w;
+                } else {
+                    dr = ~0u; dq = 0; fj = 0; pj = -1;
+                    const uint64_t ri64 = readlane_u64(cx64, li);
+                    if (in) {
+                        if (j >= win_lo) {
+                            const uint4 sl = *reinterpret_cast<const uint4 *>(&ring[j & M]);
+                            dr = ri - sl.x; dq = qi - (int32_t)sl.y; fj = (int32_t)sl.z; pj = (int32_t)sl.w; tj = wt[j & M];
+                        } else {
+                            const u128 r = a[j];
+                            const uint64_t d64 = ri64 - r.x;   // (sorted: never negative)
+                            dr = d64 > (uint64_t)clamp_x ? clamp_x : (uint32_t)d64;
+                            dq = qi - (int32_t)r.y; pj = p[j]; pj = pj >= 0 ? pj - rel : pj; tj = t[j]; fj = f[j];
                         }
                     }
+                }
+                in = in && dr <= (uint32_t)cp.max_dist_x;   // out of range: so is everything before it
+                const int32_t dd = (int32_t)dr > dq ? (int32_t)dr - dq : dq - (int32_t)dr;
+                const bool cont = !(in && dr != 0u && dq > 0 && dq <= max_dq && dd <= cp.bw);
+                int32_t sc;
+                {
+                    const int32_t min_d = dq < (int32_t)dr ? dq : (int32_t)dr;
+                    const int32_t s = min_d > q_span ? q_span : min_d;
+                    const int32_t log_dd = dd ? ilog2_32((uint32_t)dd) : 0;
+                    const int32_t gap_cost = (int)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);
+                    sc = cont ? NEG_INF : s - gap_cost + fj;
                 }
                 if (!in) pj = -1;
                 // the range ends inside (or right after) this tile if any lane fell out of it
@@ -1449,20 +1473,20 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                 bool tmark, gmark = false;
                 if (tile_in_ring) {
                     if (!cont && pj >= 0) {
-                        if (pj >= win_lo) wt[(int)(pj & M)] = (int32_t)i;
-                        else { t[pj] = (int32_t)i; gmark = true; }
+                        if (pj >= win_lo) wt[pj & M] = i;
+                        else { t[pj] = i; gmark = true; }
                     }
                     MPN_LDS_FENCE();
-                    tmark = j >= 0 && wt[(int)(j & M)] == (int32_t)i;
+                    tmark = wt[j & M] == i && j >= 0;
                 } else {
                     mark[lane] = 0;
                     MPN_LDS_FENCE();
-                    if (!cont && pj >= 0 && j0 - pj < 64 && j0 - pj >= 0) mark[(int)(j0 - pj)] = 1;
+                    if (!cont && pj >= 0 && j0 - pj < 64 && j0 - pj >= 0) mark[j0 - pj] = 1;
                     MPN_LDS_FENCE();
-                    tmark = (tj == (int32_t)i) || mark[lane];
+                    tmark = (tj == i) || mark[lane];
                 }
                 // running maximum before each lane (sequential order = lane order)
-                const int incl = wave_scan_max(cont ? NEG_INF : sc);
+                const int incl = wave_scan_max(sc);
                 const int excl_raw = wave_shr1(incl, NEG_INF);
                 const int before = max(max_f, excl_raw);
                 const bool newmax = !cont && sc > before;
@@ -1487,8 +1511,8 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                     max_j = j0 - wl;
                 }
                 if (!tile_in_ring && elig && pj >= 0) {
-                    if (pj >= win_lo) wt[(int)(pj & M)] = (int32_t)i;
-                    else { t[pj] = (int32_t)i; gmark = true; }
+                    if (pj >= win_lo) wt[pj & M] = i;
+                    else { t[pj] = i; gmark = true; }
                 }
                 if (brk < 64) done = true;
                 // a mark that went to global memory must be visible to the later tiles of this anchor
@@ -1496,18 +1520,20 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(const u128 *__restrict__ a
                 MPN_LDS_FENCE();
             }
             int32_t vprev = 0;
-            if (max_j >= 0) vprev = max_j >= win_lo ? wv[(int)(max_j & M)] : v[max_j];
+            if (max_j >= 0) vprev = max_j >= win_lo ? wv[max_j & M] : v[max_j];
             const int32_t vi = (max_j >= 0 && vprev > max_f) ? vprev : max_f;
-            if (lane == li) { rf = max_f; rp = max_j >= 0 ? (int32_t)max_j + rel : -1; rv = vi; }
+            if (lane == li) { rf = max_f; rp = max_j >= 0 ? max_j + rel : -1; rv = vi; }
             if (lane == 0) {
-                const int sl = (int)(i & M);
-                wx[sl] = ri; wy[sl] = yi; wf[sl] = max_f; wp[sl] = (int32_t)max_j; wv[sl] = vi; wt[sl] = 0;
+                const int sl = i & M;
+                *reinterpret_cast<uint4 *>(&ring[sl]) = make_uint4(ri, (uint32_t)qi, (uint32_t)max_f, (uint32_t)max_j);
+                wv[sl] = vi; wt[sl] = 0;
             }
             MPN_LDS_FENCE();
             if (li == 63 || i == n - 1) {  // write the chunk back, coalesced; move to the prefetched chunk
-                const int64_t k = (i & ~(int64_t)63) + lane;
+                const int32_t k = (i & ~63) + lane;
                 if (k <= i) { f[k] = rf; p[k] = rp; v[k] = rv; }
-                cx = nx; cy = ny;
+                const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)cx, 63);
+                cx = (uint32_t)wave_scan_add((int)nstep) + carry; cx64 = nx64; cyl = nyl; cyh = nyh;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

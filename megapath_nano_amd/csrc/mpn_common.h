@@ -163,14 +163,17 @@ __device__ __forceinline__ int wave_shr1(int v, int fill) { return dpp_mov<0x138
 // the same with lane 0 receiving 0: bound_ctrl supplies the zero, so no register has to be set up with the fill value
 __device__ __forceinline__ int wave_shr1_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 
-// inclusive prefix max over the 64 lanes: row_shr 1,2,4,8 then row_bcast15 / row_bcast31
+// inclusive prefix max over the 64 lanes: row_shr 1,2,4,8 then row_bcast15 / row_bcast31.  The lanes a shift does not reach
+// take INT_MIN, the identity of the signed max: the compiler then folds each move into the max (one v_max_i32_dpp per step
+// instead of a constant, a v_mov_dpp and a max).
 __device__ __forceinline__ int wave_scan_max(int v) {
-    v = max(v, dpp_mov<0x111, 0xf>(NEG_INF, v));
-    v = max(v, dpp_mov<0x112, 0xf>(NEG_INF, v));
-    v = max(v, dpp_mov<0x114, 0xf>(NEG_INF, v));
-    v = max(v, dpp_mov<0x118, 0xf>(NEG_INF, v));
-    v = max(v, dpp_mov<0x142, 0xa>(NEG_INF, v));
-    v = max(v, dpp_mov<0x143, 0xc>(NEG_INF, v));
+    constexpr int ID = -2147483647 - 1;
+    v = max(v, dpp_mov<0x111, 0xf>(ID, v));
+    v = max(v, dpp_mov<0x112, 0xf>(ID, v));
+    v = max(v, dpp_mov<0x114, 0xf>(ID, v));
+    v = max(v, dpp_mov<0x118, 0xf>(ID, v));
+    v = max(v, dpp_mov<0x142, 0xa>(ID, v));
+    v = max(v, dpp_mov<0x143, 0xc>(ID, v));
     return v;
 }
 // inclusive prefix sum over the 64 lanes (the same DPP ladder; lanes a shift does not reach add 0)
