@@ -1209,7 +1209,7 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
 // short read) and computes the read-wide average seed length the gap cost uses; the DP kernel takes items, not reads,
 // from a shared queue -- the long pole of a batch becomes its longest locus instead of its longest read.  Items of at
 // least CHAIN_BIG anchors are queued first.
-constexpr int CHAIN_ITEM = 1024, CHAIN_BIG = 4096;
+constexpr int CHAIN_ITEM = 256, CHAIN_BIG = 4096;
 struct ChainSeg { int32_t read, start, end; };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256) void anchor_compact_finish_kernel(const int64_
 __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restrict__ anchors, const int64_t *__restrict__ anchor_off,
                                                             int n_reads, ChainParams cp, float *__restrict__ avg_qspan, int have_avg,
                                                             ChainSeg *__restrict__ seg_big, ChainSeg *__restrict__ seg_small,
-                                                            unsigned int *__restrict__ counters) {
+                                                            unsigned int *__restrict__ counters, int item_min) {
     const int lane = threadIdx.x;
     for (int read = blockIdx.x; read < n_reads; read += gridDim.x) {
         const int64_t base = anchor_off[read];
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(64) void chain_segments_kernel(const u128 *__restri
             if (lane == 0) {
                 while (m) {
                     const int32_t s_new = (int32_t)i0 + __builtin_ctzll(m);
-                    if (s_new - open >= CHAIN_ITEM) {
+                    if (s_new - open >= item_min) {
                         const bool big = s_new - open >= CHAIN_BIG;
                         const unsigned int pos = atomicAdd(&counters[big ? 0 : 1], 1u);
                         (big ? seg_big : seg_small)[pos] = ChainSeg{read, open, s_new};

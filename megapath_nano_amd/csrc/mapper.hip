@@ -410,9 +410,10 @@ int seed_chain_device(const mpn_index *idx, const mpn_map_opt *opt, int n, const
     ev.mark(46);
     // work items of the chain DP: runs of whole independent segments of each read's anchor list, cut on the device
     DevBuf<ChainSeg> seg_big, seg_small;
-    if (seg_big.alloc((size_t)n_c / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_c / CHAIN_ITEM + (size_t)n + 1)) return -1;
+    static const int chain_item = []() { const char *e = getenv("MPN_CHAIN_ITEM"); return e ? std::min(CHAIN_BIG, std::max(16, atoi(e))) : CHAIN_ITEM; }();
+    if (seg_big.alloc((size_t)n_c / CHAIN_BIG + (size_t)n + 1) || seg_small.alloc((size_t)n_c / chain_item + (size_t)n + 1)) return -1;
     hipLaunchKernelGGL(chain_segments_kernel, dim3(g), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, n, cp, avg_qspan.p, 1, seg_big.p,
-                       seg_small.p, seg_counters.p);
+                       seg_small.p, seg_counters.p, chain_item);
     MPN_HIP_CHECK(hipGetLastError());
     ev.mark(13);
     hipLaunchKernelGGL(chain_dp_kernel, dim3(256 * 32), dim3(64), 0, st, (const u128 *)ca, (const int64_t *)o.c_off.p, (const float *)avg_qspan.p,
