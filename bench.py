@@ -583,6 +583,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'scripts'))
         import thread_cpu
         thr0 = thread_cpu.snapshot()
+        det0 = dict(thread_cpu.DETAIL)
     stats_acc = {}
     counts = None
     sampled = np.zeros(n, dtype=np.int64)   # what this rank's generator sampled in the timed steps, per genome
@@ -605,7 +606,11 @@ def main():
         for name, (cnt, sec) in thread_cpu.diff(thr0, thr1)[:12]:
             log(f'threads {name!r} x{cnt}: {sec / max(1, args.steps):.3f} CPU-s per step')
         for tid, name, sec, is_main in thread_cpu.top_threads(thr0, thr1):
-            log(f'  thread {tid} {name!r}{" (main)" if is_main else ""}: {sec / max(1, args.steps):.3f} CPU-s per step')
+            u1, s1, (v1, n1) = thread_cpu.DETAIL.get(tid, (0, 0, (0, 0)))
+            u0, s0, (v0, n0) = det0.get(tid, (0, 0, (0, 0)))
+            log(f'  thread {tid} {name!r}{" (main)" if is_main else ""}: {sec / max(1, args.steps):.3f} CPU-s per step '
+                f'(user {(u1 - u0) / max(1, args.steps):.3f}, system {(s1 - s0) / max(1, args.steps):.3f}; context switches per step: '
+                f'{(v1 - v0) / max(1, args.steps):.0f} voluntary, {(n1 - n0) / max(1, args.steps):.0f} involuntary)')
     if args.config != 'c2':
         for s in range(args.steps):
             sampled += np.bincount(batches[(args.warmup + s) % n_distinct].truth['genome'], minlength=n)

@@ -2,6 +2,22 @@
 import os
 
 
+DETAIL = {}   # tid -> (user s, system s, (voluntary, involuntary) context switches) at the last snapshot
+
+
+def ctx_switches(tid):
+    v = n = 0
+    try:
+        for line in open(f'/proc/self/task/{tid}/status'):
+            if line.startswith('voluntary_ctxt_switches'):
+                v = int(line.split()[1])
+            elif line.startswith('nonvoluntary_ctxt_switches'):
+                n = int(line.split()[1])
+    except OSError:
+        pass
+    return v, n
+
+
 def snapshot():
     out = {}
     tck = os.sysconf('SC_CLK_TCK')
@@ -13,6 +29,7 @@ def snapshot():
         name = s[s.index('(') + 1:s.rindex(')')]
         f = s[s.rindex(')') + 2:].split()
         out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tck)
+        DETAIL[int(tid)] = (int(f[11]) / tck, int(f[12]) / tck, ctx_switches(tid))
     return out
 
 
