@@ -181,3 +181,43 @@ def test_seed_chain_with_saturated_filter(libmpn, oracle_built):
     finally:
         gidx.close()
         oidx.close()
+
+
+def test_seed_chain_through_a_tandem_repeat(libmpn, oracle_built):
+    """A 37-bp unit repeated 220 times inside one target, no occurrence cut-off: a read minimizer of the repeat hits every copy
+    on the SAME target, hundreds of off-diagonal anchors lie within max_dist_x of each other, and the predecessor scan of an
+    anchor runs far beyond the 128 anchors the chain DP keeps in LDS (its tiles from global memory, marks in both places)."""
+    from megapath_nano_amd import mapper, synth
+    from oracle import mm2_bindings as mb
+    rng = np.random.default_rng(11)
+    unit = synth.ALPHA[rng.integers(0, 4, size=37)]
+    left, right = synth.ALPHA[rng.integers(0, 4, size=6000)], synth.ALPHA[rng.integers(0, 4, size=6000)]
+    rep = np.tile(unit, 220)
+    pos = rng.integers(0, len(rep), size=120)          # a few substitutions so that the copies are not all identical
+    rep[pos] = synth.ALPHA[rng.integers(0, 4, size=120)]
+    gen = [('flank_only', np.concatenate([left, right])), ('with_repeat', np.concatenate([left, rep, right])),
+           ('other', synth.ALPHA[rng.integers(0, 4, size=9000)])]
+    target = gen[1][1]
+    reads = []
+    for k in range(8):
+        st = int(rng.integers(3000, 5500))
+        q = target[st:st + int(rng.integers(6000, 11000))].copy()
+        p = rng.integers(0, len(q), size=len(q) // 25)
+        q[p] = synth.ALPHA[rng.integers(0, 4, size=len(p))]
+        reads.append(q if k % 2 == 0 else synth.COMP[q[::-1]])
+    gidx, oidx = mapper.Index(gen), mb.Index(gen)
+    try:
+        gopt, oopt = mapper.default_opt(mid_occ=100000), mb.default_opt(mid_occ=100000)
+        got = mapper.seed_chain_batch(gidx, gopt, reads)
+        tot = 0
+        for q, g in zip(reads, got):
+            mv = mb.sketch(q, 10, 15, 0)
+            a, rl = mb.collect_anchors(oidx, 100000, mv, len(q))
+            u, b = mb.chain(oopt, a)
+            assert g['n_anchor'] == len(a) and g['rep_len'] == rl
+            assert np.array_equal(g['u'], u) and np.array_equal(g['b'], b)
+            tot += len(a)
+        assert tot > 8 * 20000   # the repeat multiplies the hits
+    finally:
+        gidx.close()
+        oidx.close()
