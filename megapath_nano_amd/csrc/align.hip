@@ -833,7 +833,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
     prm.sc_mch = (int8_t)opt->a; prm.sc_mis = (int8_t)-opt->b; prm.sc_n = (int8_t)-opt->sc_ambi;
     prm.q = (int8_t)opt->q; prm.e = (int8_t)opt->e; prm.q2 = (int8_t)opt->q2; prm.e2 = (int8_t)opt->e2; prm.zdrop_thres = opt->zdrop;
     prm.zdrop_inv = opt->zdrop_inv; prm.max_gap = opt->max_gap;
-    const size_t order_cap = (size_t)nj + (size_t)N_STRIP * 4 + 16;
+    const size_t order_cap = (size_t)nj + (size_t)N_STRIP * 8 + 16;   // (a strip list is padded to whole waves: at most 7 entries)
     if (SL.pool_sizes.ensure((size_t)nj * sizeof(JobSizes) + 16) || SL.pool_buckets.ensure((size_t)2 * N_BUCKETS * 4 + sizeof(LayoutTotals) + 16) ||
         SL.pool_order.ensure(order_cap * 4) || SL.pin_res.ensure(sizeof(LayoutTotals) + 64) ||
         SL.pool_redo_ids.ensure((size_t)nj * 4 + 16) || SL.pool_probes.ensure((size_t)nj * sizeof(InvProbe) + 16))
@@ -952,15 +952,17 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             int blocks = 0;
             size_t lds = 0;
             const int c_lo = fam == 0 ? 0 : 3, c_hi = fam == 0 ? 3 : N_STRIP_CLASS;
+            static const int strip_pair = []() { const char *e = getenv("MPN_STRIP_PAIR"); return e ? atoi(e) : 1; }();   // (0: one gap fill per lane group)
+            const int pair = fam == 0 && strip_pair ? 1 : 0;
             for (int glc = 2; glc >= 0; --glc)   // wide lane groups (the long windows) first
                 for (int sclass = c_lo + glc; sclass < c_hi; sclass += 3) {
-                    const int l0 = L_STRIP + 16 * sclass, nl = base[l0 + 16] - base[l0], per = 4 >> glc;
+                    const int l0 = L_STRIP + 16 * sclass, nl = base[l0 + 16] - base[l0], per = (pair ? 8 : 4) >> glc;
                     if (nl == 0) continue;
                     const int stride = (std::max(T.strip_lds[sclass], 16) + 3) & ~3;
                     // exact variants: a slot per anti-diagonal and the E4 table per window (+ 16: the rows that pad the last strip)
                     const int nr_stride = fam ? T.strip_nr[sclass] + 16 : 0;
                     lds = std::max(lds, (size_t)stride * per + STRIP_TAB_BYTES + (size_t)per * 8 * nr_stride);
-                    segs.s[segs.n++] = StripSeg{blocks, nl, base[l0], stride, nr_stride, glc, sclass >= 6 ? 1 : 0, 0};
+                    segs.s[segs.n++] = StripSeg{blocks, nl, base[l0], stride, nr_stride, glc, sclass >= 6 ? 1 : 0, pair};
                     blocks += nl / per;
                 }
             if (blocks == 0) return 0;

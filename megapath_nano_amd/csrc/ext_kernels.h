@@ -990,6 +990,213 @@ __device__ __forceinline__ void ext_strip_pack(const ExtJob *__restrict__ jobs, 
     }
 }
 
+// TWO gap-fill windows per lane group (round 4): the 16-bit halves of a register hold the same state of window A (low) and window B
+// (high) instead of the two gap types of one window, so every packed instruction -- and the score / maximum / clamp / difference
+// chain, which is scalar in the one-window cell -- works on two cells: 16.5 instead of 21.5 instructions per cell.  The two gap
+// types live in registers of their own (X1, X2 from above; Y1, Y2 per row); u and v carry the constants of type 1 and the type-2
+// candidates come out too large by the constant D = 8 (qe2 - qe) + 2 (rank a - rank a2 = rank b - rank b2 = 2), which is taken off
+// their maximum once and folded into the constants of their saturating subtractions.  The windows of a pair are neighbours in
+// the launch list (same strip height, queries within one length bucket); each keeps its own matrix, stride and result.  A half
+// whose window is shorter keeps computing (its query continues with ambiguous bases, its target with ambiguous rows: a valid DP of
+// bounded differences, so nothing carries into the other half); what a window needs from its last column and row 0 is taken when
+// the lane is there.  Gap fills only (approximate maximum, left-aligned gaps).
+template <int S, int GL>
+__device__ __forceinline__ void ext_strip_pair(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, const int first,
+                                               const int n_list, const ExtParams &prm, const uint8_t *__restrict__ reads,
+                                               const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+                                               const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem,
+                                               const int lds_stride) {
+    constexpr int NG = 64 / GL;  // pairs per wave
+    const int lane = threadIdx.x, g = lane / GL, gl = lane % GL;
+    int q = prm.q, e = prm.e, q2 = prm.q2, e2 = prm.e2;
+    if (q2 + e2 < q + e) { int t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e, qe2 = q2 + e2;
+    // the pair's windows, one copy per lane ([0] = A, [1] = B)
+    int jid[2], qlen[2], tlen[2], W[2], rd[2], rid[2], rev[2], qs[2], ts[2], back[2];
+    int64_t p_off[2];
+    bool ok[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int slot = first + 2 * g + w;
+        jid[w] = slot < n_list ? order[slot] : -1;  // -1: padding at the end of a launch list
+        qlen[w] = tlen[w] = W[w] = rd[w] = rid[w] = rev[w] = qs[w] = ts[w] = back[w] = 0; p_off[w] = 0;
+        if (jid[w] >= 0) {
+            const ExtJob &jb = jobs[jid[w]];
+            qlen[w] = jb.qlen; tlen[w] = jb.tlen; W[w] = jb.qstride; rd[w] = jb.read; rid[w] = jb.rid; rev[w] = jb.rev; qs[w] = jb.qs; ts[w] = jb.ts;
+            p_off[w] = jb.p_off; back[w] = jb.reversed;
+        }
+        ok[w] = jid[w] >= 0 && qlen[w] > 0 && tlen[w] > 0 && !(-prm.sc_mis > 2 * (q + e));
+        if (!ok[w]) { qlen[w] = 0; tlen[w] = 0; }
+    }
+    constexpr int RS = 4, RA = 3, RB = 2, RA2 = 1, RB2 = 0;
+    const uint32_t sb_mch = (uint32_t)(8 * prm.sc_mch + RS + 128) & 0xff, sb_mis = (uint32_t)(8 * prm.sc_mis + RS + 128) & 0xff,
+                   sb_n = (uint32_t)(8 * prm.sc_n + RS + 128) & 0xff;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem + 2 * NG * lds_stride);   // (lds_stride is a multiple of 4)
+    if (lane < 5) tab[lane] = lane == 4 ? sb_n * 0x01010101u : (sb_mis * 0x01010101u) ^ ((sb_mch ^ sb_mis) << (8 * lane));
+    // queries -> LDS as 4 * base code, one region per window, staged by the whole wave
+#pragma unroll
+    for (int g2 = 0; g2 < NG; ++g2)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int ql = __builtin_amdgcn_readlane(qlen[w], g2 * GL);
+            if (ql > 0) {
+                const int r2 = __builtin_amdgcn_readlane(rd[w], g2 * GL), rv2 = __builtin_amdgcn_readlane(rev[w], g2 * GL),
+                          qs2 = __builtin_amdgcn_readlane(qs[w], g2 * GL), bk2 = __builtin_amdgcn_readlane(back[w], g2 * GL);
+                const int64_t roff = read_off[r2];
+                const int32_t rlen = read_len[r2];
+                for (int i = lane; i < ql; i += 64)
+                    smem[(2 * g2 + w) * lds_stride + i] = (uint8_t)(4 * ext_qbase(reads, roff, rlen, rv2, qs2 + (bk2 ? ql - 1 - i : i)));
+            }
+        }
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+#define MPN_BND(R) (8 * ((R) == 0 ? -qe : (R) < long_thres ? -e : (R) == long_thres ? long_diff : -e2))
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    constexpr int BETA = 0x2000 + 128;
+    const int cv1 = -8 * qe + RA + BETA, cu1 = -8 * qe + RB + BETA;
+    const uint32_t both = 0x00010001u;
+    const uint32_t CV = (uint32_t)cv1 * both, CU = (uint32_t)cu1 * both;
+    const int Dk = 8 * (qe2 - qe) + (RA - RA2);    // (RB - RB2 is the same 2)
+    const uint32_t DD = (uint32_t)Dk * both;
+    const uint32_t KZZ = (uint32_t)(-16 * qe + RA + RB + BETA) * both;
+    const uint32_t KEA1 = (uint32_t)(8 * e - 8 * qe + RA) * both, KEB1 = (uint32_t)(8 * e - 8 * qe + RB) * both;
+    const uint32_t KEA2 = (uint32_t)(8 * e2 - 8 * qe2 + RA2 + Dk) * both, KEB2 = (uint32_t)(8 * e2 - 8 * qe2 + RB2 + Dk) * both;
+    const uint32_t EIGHT = 0x00080008u, RANK_CLR = 0xfff8fff8u, SEVEN = 0x00070007u;
+    const uint32_t MCH7 = (uint32_t)(8 * prm.sc_mch + 7 + BETA) * both;
+    uint32_t U[S], Y1[S], Y2[S], T1[S], T2[S];
+    const int t0 = gl * S;
+    const uint32_t KONST = sb_n | 0x2000u;   // byte 0: the score against an ambiguous target base; byte 1: the high byte of every score
+    {
+        const int64_t ga = ok[0] ? rv.seq_off[rid[0]] + ts[0] : 0, gb = ok[1] ? rv.seq_off[rid[1]] + ts[1] : 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int t = t0 + k;
+            const int sa = t < tlen[0] ? ref_code(rv, ga + (back[0] ? tlen[0] - 1 - t : t)) : 4;
+            const int sb_ = t < tlen[1] ? ref_code(rv, gb + (back[1] ? tlen[1] - 1 - t : t)) : 4;
+            T1[k] = 0x0c0c0100u | (sa < 4 ? 4u + (uint32_t)sa : 0u);                 // -> low half: byte 0 the score, byte 1 its high byte
+            T2[k] = 0x01000c0cu | (sb_ < 4 ? 4u + (uint32_t)sb_ : 0u) << 16;         // -> high half
+            U[k] = (uint32_t)MPN_BND(t) * both + CU;   // left of column 0: the first-column boundary (the same for both windows)
+            Y1[k] = 0; Y2[k] = 0;
+        }
+    }
+    __syncthreads();
+    const int nl0 = (tlen[0] + S - 1) / S, nl1 = (tlen[1] + S - 1) / S;
+    const int qmax = max(qlen[0], qlen[1]), nlmax = max(nl0, nl1);
+    const int max_steps = wave_reduce_max(qmax > 0 ? qmax + nlmax - 1 : 0);
+    const uint8_t *qrow0 = smem + (2 * g) * lds_stride, *qrow1 = qrow0 + lds_stride;
+    uint8_t *prow0 = P + p_off[0] + t0, *prow1 = P + p_off[1] + t0;
+    int out_v = 0, out_x1 = 0, out_x2 = 0;
+    uint32_t qta = 0, qtb = 0;       // the score words of the query bases this lane works on
+    int32_t row0a = 0, row0b = 0;    // first lane of a group: sums of the horizontal differences of row 0
+    int32_t tota = 0, totb = 0;      // sum of the vertical differences of the lane's rows in the window's last column
+    const bool head = gl == 0;
+    const int qa1 = qlen[0] - 1, qb1 = qlen[1] - 1;
+    auto code0 = [&](int s_) -> uint32_t { return s_ < qlen[0] ? (uint32_t)qrow0[s_] : 16u; };
+    auto code1 = [&](int s_) -> uint32_t { return s_ < qlen[1] ? (uint32_t)qrow1[s_] : 16u; };
+    auto word = [&](uint32_t c) -> uint32_t { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + c); };
+    uint32_t qa_next = word(code0(0)), qb_next = word(code1(0));
+    uint32_t ca_next = code0(1), cb_next = code1(1);
+    for (int step = 0; step < max_steps; ++step) {
+        const uint32_t qa_in = qa_next, qb_in = qb_next;
+        qa_next = word(ca_next); qb_next = word(cb_next);
+        ca_next = code0(step + 2); cb_next = code1(step + 2);
+        const uint32_t qa_s = (uint32_t)wave_shr1_zero((int)qta), qb_s = (uint32_t)wave_shr1_zero((int)qtb);
+        const int v_s = wave_shr1_zero(out_v), x1_s = wave_shr1_zero(out_x1), x2_s = wave_shr1_zero(out_x2);
+        const int j = step - gl;
+        const int bj = MPN_BND(step);  // first lane: j = step
+        qta = head ? qa_in : qa_s; qtb = head ? qb_in : qb_s;
+        uint32_t Vp = head ? (uint32_t)bj * both + CV : (uint32_t)v_s, X1 = head ? 0u : (uint32_t)x1_s, X2 = head ? 0u : (uint32_t)x2_s;
+        if (j >= 0 && j < qmax && gl < nlmax) {
+            uint32_t dwa[(S + 3) / 4], dwb[(S + 3) / 4], ecell[4] = {0, 0, 0, 0};
+            uint32_t nv0 = 0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const uint32_t sc = __builtin_amdgcn_perm(qta, KONST, T1[k]) | __builtin_amdgcn_perm(qtb, KONST, T2[k]);   // 8 s + rank + BETA per half
+                const uint32_t Up = U[k];
+                const uint32_t A1 = X1 + Vp, A2 = X2 + Vp, B1 = Y1[k] + Up, B2 = Y2[k] + Up;   // A2, B2: D too large
+                const uint32_t M1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, A1), __builtin_bit_cast(s16x2, B1)));
+                const uint32_t M2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, A2), __builtin_bit_cast(s16x2, B2))) - DD;
+                const uint32_t M = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, M1), __builtin_bit_cast(s16x2, M2)));
+                const uint32_t z = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, M), __builtin_bit_cast(s16x2, sc)));
+                const uint32_t zc = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, z), __builtin_bit_cast(s16x2, MCH7)));
+                const uint32_t Zc = zc & RANK_CLR;               // 8 z + BETA
+                const uint32_t ZZ = Zc + KZZ;
+                uint32_t nu = Up, nv;
+                asm("v_sub_u32 %1, %2, %0\n\tv_sub_u32 %0, %2, %3" : "+v"(nu), "=&v"(nv) : "v"(ZZ), "v"(Vp));
+                const u16x2 An1 = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A1), __builtin_bit_cast(u16x2, Zc + KEA1));
+                const u16x2 An2 = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, A2), __builtin_bit_cast(u16x2, Zc + KEA2));
+                const u16x2 Bn1 = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B1), __builtin_bit_cast(u16x2, Zc + KEB1));
+                const u16x2 Bn2 = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, B2), __builtin_bit_cast(u16x2, Zc + KEB2));
+                // continuation flags: min(state, 8) leaves bit 3 of each half; a -> bit 3, b -> 4, a2 -> 5, b2 -> 6; rank in bits 0..2
+                uint32_t HA1, HB1, HA2, HB2, F;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA1) : "v"(__builtin_bit_cast(uint32_t, An1)), "v"(EIGHT));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB1) : "v"(__builtin_bit_cast(uint32_t, Bn1)), "v"(EIGHT));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HA2) : "v"(__builtin_bit_cast(uint32_t, An2)), "v"(EIGHT));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(HB2) : "v"(__builtin_bit_cast(uint32_t, Bn2)), "v"(EIGHT));
+                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(F) : "v"(HB1), "v"(HA1));
+                asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(F) : "v"(HA2), "v"(F));
+                asm("v_lshl_or_b32 %0, %1, 3, %2" : "=v"(F) : "v"(HB2), "v"(F));
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ecell[k & 3]) : "v"(z), "v"(SEVEN), "v"(F));
+                U[k] = nu; Y1[k] = __builtin_bit_cast(uint32_t, Bn1); Y2[k] = __builtin_bit_cast(uint32_t, Bn2);
+                Vp = nv; X1 = __builtin_bit_cast(uint32_t, An1); X2 = __builtin_bit_cast(uint32_t, An2);
+                if ((k & 3) == 3 || k == S - 1) {
+                    // a cell word holds window A's byte in byte 0 and window B's in byte 2: four rows -> one word per window
+                    const uint32_t p01 = (k & 3) >= 1 ? __builtin_amdgcn_perm(ecell[1], ecell[0], 0x06020400u) : __builtin_amdgcn_perm(0u, ecell[0], 0x0c020c00u);
+                    const uint32_t p23 = (k & 3) == 3 ? __builtin_amdgcn_perm(ecell[3], ecell[2], 0x06020400u)
+                                       : (k & 3) == 2 ? __builtin_amdgcn_perm(0u, ecell[2], 0x0c020c00u) : 0u;
+                    dwa[k >> 2] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    dwb[k >> 2] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+                }
+                if (k == 0) nv0 = nv;
+            }
+            out_v = (int)Vp; out_x1 = (int)X1; out_x2 = (int)X2;
+            if (j <= qa1) row0a += (int)(nv0 & 0xffffu) - cv1;
+            if (j <= qb1) row0b += (int)(nv0 >> 16) - cv1;
+            // the window's last column: the vertical differences of the lane's rows (pre-scaled, exact multiples of 8)
+            if (j == qa1) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) tota += (t0 + k > 0 && t0 + k < tlen[0]) ? (int)(U[k] & 0xffffu) - cu1 : 0;
+            }
+            if (j == qb1) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) totb += (t0 + k > 0 && t0 + k < tlen[1]) ? (int)(U[k] >> 16) - cu1 : 0;
+            }
+            auto store = [&](uint8_t *dst, const uint32_t *dw) {   // p_off is 16-aligned, W and t0 are multiples of S
+                if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
+                else if constexpr (S == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(dw[0], dw[1]);
+                else if constexpr (S == 16) *reinterpret_cast<uint4 *>(dst) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+                else {
+#pragma unroll
+                    for (int c = 0; c < S / 4; ++c) __builtin_memcpy(dst + 4 * c, &dw[c], 4);
+                    if constexpr ((S & 2) != 0) { const uint16_t h = (uint16_t)dw[S / 4]; __builtin_memcpy(dst + (S & ~3), &h, 2); }
+                    if constexpr ((S & 1) != 0) dst[S - 1] = (uint8_t)(dw[S / 4] >> ((S & 2) ? 16 : 0));
+                }
+            };
+            if (j <= qa1 && gl < nl0) store(prow0 + (int64_t)step * W[0], dwa);
+            if (j <= qb1 && gl < nl1) store(prow1 + (int64_t)step * W[1], dwb);
+        }
+    }
+#undef MPN_BND
+    // H(tlen-1, qlen-1) = H(0,-1) + sum_j v(0,j) + sum_{t>0} u(t, qlen-1)
+    int32_t ta = tota + (head ? row0a - 8 * qe : 0), tb = totb + (head ? row0b - 8 * qe : 0);
+#pragma unroll
+    for (int dlt = GL / 2; dlt; dlt >>= 1) { ta += __shfl_xor(ta, dlt); tb += __shfl_xor(tb, dlt); }
+    ta >>= 3; tb >>= 3;
+    if (head) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            if (jid[w] < 0) continue;
+            ExtRes out;
+            out.max = 0; out.zdropped = 0; out.max_q = out.max_t = out.mqe_t = -1; out.mqe = NEG_INF; out.score = ok[w] ? (w ? tb : ta) : NEG_INF;
+            out.reach_end = 0; out.n_cigar = 0; out.r_done = ok[w] ? qlen[w] + tlen[w] - 2 : -1; out.zcode = 0; out.cig_pos = 0;
+            out.do_bt = ok[w] ? 1 : 0; out.bt_i = ok[w] ? tlen[w] - 1 : -1; out.bt_j = ok[w] ? qlen[w] - 1 : -1;
+            res[jid[w]] = out;
+        }
+    }
+}
+
 // One launch per lane-group width.  GL = 16 / 32 / 64 lanes per window (4 / 2 / 1 windows per wave) for targets up to
 // 256 / 512 / 1024 rows: the ramp of the systolic array costs n_lanes - 1 steps per window, so a window should use as few
 // lanes -- as tall a strip, S <= 16 -- as it can.  The launch list is grouped by S and every group is padded to whole
@@ -1013,13 +1220,13 @@ __device__ __forceinline__ void ext_strip_dispatch(const ExtJob *__restrict__ jo
 // ONE launch for all the lane-group classes of a variant family (every launch ends in a tail of half-empty CUs: three launches
 // per round had three).  Segments are ordered from the widest lane group to the narrowest and, inside a class, from the tallest
 // strips and the longest queries down, so the waves with the most cells start first.
-struct StripSeg { int32_t first_block, n_list, ord_off, lds_stride, nr_stride, glc, right, pad; };
+struct StripSeg { int32_t first_block, n_list, ord_off, lds_stride, nr_stride, glc, right, pair; };   // pair: two windows per lane group (gap fills)
 struct StripSegs { StripSeg s[6]; int32_t n; };
 
-// (the gap-fill instantiation needs 99 VGPRs as the compiler allocates them by default: one register granule over what lets a
-// fifth wave onto a SIMD.  Five waves are asked for -- the dependent chain down a lane's 16 rows needs other waves to issue.)
+// (the paired gap-fill cell keeps five registers per row -- u, y, y2 and the two windows' target selectors -- ~120 VGPRs at 16 rows:
+// four waves per SIMD.  The kernel issues as fast with three as with five: it is bound by issue, not by latency hiding.)
 template <bool EXACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXACT ? 3 : 5, EXACT ? 3 : 5))) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, StripSegs segs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void ext_dp_strip_kernel(const ExtJob *__restrict__ jobs, const int32_t *__restrict__ order, StripSegs segs,
                                                           ExtParams prm, const uint8_t *__restrict__ reads,
                                                           const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                                                           RefView rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res) {
@@ -1028,6 +1235,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXACT ? 3 : 
     while (k + 1 < segs.n && (int)blockIdx.x >= segs.s[k + 1].first_block) ++k;
     const StripSeg sg = segs.s[k];
     const int32_t *ord = order + sg.ord_off;
+    if constexpr (!EXACT) {
+        if (sg.pair) {
+            const int first2 = ((int)blockIdx.x - sg.first_block) * (8 >> sg.glc);
+            int S = 16;   // (uniform per wave: the lists are grouped by strip height and padded to whole waves)
+            for (int k = 0; k < (8 >> sg.glc); ++k) { const int slot = first2 + k; if (slot < sg.n_list && ord[slot] >= 0) { S = jobs[ord[slot]].strip_s; break; } }
+#define MPN_PAIR(SS, GLN) ext_strip_pair<SS, GLN>(jobs, ord, first2, sg.n_list, prm, reads, read_off, read_len, rv, P, res, smem, sg.lds_stride)
+#define MPN_PAIR_S(GLN) switch (S) { case 1: MPN_PAIR(1, GLN); break; case 2: MPN_PAIR(2, GLN); break; case 3: MPN_PAIR(3, GLN); break; case 4: MPN_PAIR(4, GLN); break; \
+            case 5: MPN_PAIR(5, GLN); break; case 6: MPN_PAIR(6, GLN); break; case 7: MPN_PAIR(7, GLN); break; case 8: MPN_PAIR(8, GLN); break; \
+            case 9: MPN_PAIR(9, GLN); break; case 10: MPN_PAIR(10, GLN); break; case 11: MPN_PAIR(11, GLN); break; case 12: MPN_PAIR(12, GLN); break; \
+            case 13: MPN_PAIR(13, GLN); break; case 14: MPN_PAIR(14, GLN); break; case 15: MPN_PAIR(15, GLN); break; default: MPN_PAIR(16, GLN); break; }
+            if (sg.glc == 0) MPN_PAIR_S(16) else if (sg.glc == 1) MPN_PAIR_S(32) else MPN_PAIR_S(64)
+#undef MPN_PAIR_S
+#undef MPN_PAIR
+            return;
+        }
+    }
     const int first = ((int)blockIdx.x - sg.first_block) * (4 >> sg.glc);
 #define MPN_GL(GLN, RT) ext_strip_dispatch<GLN, EXACT, RT>(jobs, ord, first, sg.n_list, prm, reads, read_off, read_len, rv, P, res, smem, sg.lds_stride, sg.nr_stride)
     if (EXACT && sg.right) { if (sg.glc == 0) MPN_GL(16, true); else if (sg.glc == 1) MPN_GL(32, true); else MPN_GL(64, true); }

@@ -291,7 +291,8 @@ enum { L_LDS = 0, L_WG = 5, L_STRIP = 20, N_STRIP = 16 * N_STRIP_CLASS, L_BAND =
 constexpr int STRIP_QB = 64;                                  // query-length buckets inside a strip list (longest first)
 constexpr int N_BUCKETS = N_LISTS + N_STRIP * (STRIP_QB - 1);  // scatter buckets: a strip list is STRIP_QB consecutive buckets
 __host__ __device__ inline int strip_glc_of_list(int l) { return ((l - L_STRIP) / 16) % 3; }
-__host__ __device__ inline int strip_windows_per_wave(int l) { return 4 >> strip_glc_of_list(l); }
+// (the gap-fill lists -- variant 0 -- are padded to whole waves of PAIRED windows: two per lane group, ext_strip_pair)
+__host__ __device__ inline int strip_windows_per_wave(int l) { return (l < L_STRIP + 48 ? 8 : 4) >> strip_glc_of_list(l); }
 __host__ __device__ inline int bucket_of_list(int l) {       // first bucket of list l
     return l < L_STRIP ? l : l < L_BAND ? L_STRIP + (l - L_STRIP) * STRIP_QB : L_STRIP + N_STRIP * STRIP_QB + (l - L_BAND);
 }
