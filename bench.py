@@ -47,10 +47,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 # Issue rates of the strip cell's instruction types on gfx950 (profiles/r03/valu_microbench2.txt, 4 waves per SIMD): two-operand 32-bit
 # add / sub / and / or / mov and the 16-bit two-operand max take ~2.7 cycles per wave-instruction per SIMD, packed 16-bit, three-operand,
-# permute, DPP ones ~4.4.  The S = 16 loop body of the strip kernel is 344 VALU instructions per 16-row step (21.5 per cell and lane),
-# of which 9.5 per cell are of the fast kind: ~3.65 cycles per instruction on average -> the ceiling of THIS mix for the chip.
-STRIP_INSTR_PER_CELL = 21.5
-STRIP_FAST_PER_CELL = 9.5
+# permute, DPP ones ~4.4.  The S = 16 loop body of the strip kernel (two windows per lane group since round 4) is 599 VALU instructions
+# per step of 16 rows x 2 windows, ~60 of them per-step overhead: 16.8 per cell and lane (21.5 with one window per group), of which 7
+# per cell are of the fast kind: ~3.7 cycles per instruction on average -> the ceiling of THIS mix for the chip.
+STRIP_INSTR_PER_CELL = 16.8
+STRIP_FAST_PER_CELL = 7.0
 STRIP_CYCLES_PER_INSTR = (STRIP_FAST_PER_CELL * 2.7 + (STRIP_INSTR_PER_CELL - STRIP_FAST_PER_CELL) * 4.4) / STRIP_INSTR_PER_CELL
 VALU_CEIL_WAVE_INSTR = 1024 * 2.4e9 / STRIP_CYCLES_PER_INSTR   # 1024 SIMDs at 2.4 GHz
 T00 = time.time()
@@ -748,10 +749,10 @@ def main():
             'frac_alone': round(cand_alone[dom][3] * wi_per_cell / ns_alone_dom * 1e9 / VALU_PEAK, 4) if alone is not None else None,
             'mix_ceiling_wave_instr_per_s': VALU_CEIL_WAVE_INSTR,
             'gcups_whole_step': round(st['dp_cells'] / (dt / K * 1e9), 2),
-            'note': 'the DP kernels are bound by VALU issue, not by HBM. wave-instructions = cells x 21.5 (ISA count of the loop body per cell and lane) / 64: '
-                    'the ALGORITHMIC count -- ramps of the systolic array, padding rows and per-step overhead are not in it (PMC: 25.7 per cell). peak = 1024 SIMDs x '
-                    '2.4 GHz / 2 cycles (the guide); mix_ceiling = what the cell\'s own instruction mix can issue (profiles/r03/valu_microbench2.txt: 9.5 instructions '
-                    'at 2.7 cycles + 12 packed / three-operand ones at 4.4 per cell).',
+            'note': 'the DP kernels are bound by VALU issue, not by HBM. wave-instructions = cells x 16.8 (ISA count of the loop body per cell and lane, two windows '
+                    'per lane group) / 64: the ALGORITHMIC count -- ramps of the systolic array, padding rows, unequal pairs and per-step overhead are not in it (PMC: '
+                    '22.2 per cell). peak = 1024 SIMDs x 2.4 GHz / 2 cycles (the guide); mix_ceiling = what the cell\'s own instruction mix can issue '
+                    '(profiles/r03/valu_microbench2.txt: 7 instructions at 2.7 cycles + 9.8 packed / three-operand ones at 4.4 per cell).',
         }
     roof['note'] = ('in_pipeline_ms / frac: HIP-event span per launch on its own stream over the timed region, while the other pipeline workers share the GPU '
                     '(the rocprofv3 average of the same command, profiles/, is the figure to compare). alone_ms / frac_alone: the kernel with nothing else on '
