@@ -1155,13 +1155,27 @@ __device__ __forceinline__ void ext_strip_pair(const ExtJob *__restrict__ jobs, 
             if (j <= qa1) row0a += (int)(nv0 & 0xffffu) - cv1;
             if (j <= qb1) row0b += (int)(nv0 >> 16) - cv1;
             // the window's last column: the vertical differences of the lane's rows (pre-scaled, exact multiples of 8)
-            if (j == qa1) {
+            // (one lane of a group is there per step, so the wave runs this at most steps of a drain: a lane whose S rows are all inside
+            // the window -- every lane but the first and the last -- adds them up as packed halves modulo 2^16, S - 1 instructions)
+            auto packed_sum = [&]() -> uint32_t {
+                u16x2 acc = __builtin_bit_cast(u16x2, U[0]);
 #pragma unroll
-                for (int k = 0; k < S; ++k) tota += (t0 + k > 0 && t0 + k < tlen[0]) ? (int)(U[k] & 0xffffu) - cu1 : 0;
+                for (int k = 1; k < S; ++k) acc += __builtin_bit_cast(u16x2, U[k]);
+                return __builtin_bit_cast(uint32_t, acc);
+            };
+            if (j == qa1) {
+                if (!head && t0 + S <= tlen[0]) tota += (int)(short)(uint16_t)((packed_sum() & 0xffffu) - (uint32_t)(S * cu1));
+                else {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) tota += (t0 + k > 0 && t0 + k < tlen[0]) ? (int)(U[k] & 0xffffu) - cu1 : 0;
+                }
             }
             if (j == qb1) {
+                if (!head && t0 + S <= tlen[1]) totb += (int)(short)(uint16_t)((packed_sum() >> 16) - (uint32_t)(S * cu1));
+                else {
 #pragma unroll
-                for (int k = 0; k < S; ++k) totb += (t0 + k > 0 && t0 + k < tlen[1]) ? (int)(U[k] >> 16) - cu1 : 0;
+                    for (int k = 0; k < S; ++k) totb += (t0 + k > 0 && t0 + k < tlen[1]) ? (int)(U[k] >> 16) - cu1 : 0;
+                }
             }
             auto store = [&](uint8_t *dst, const uint32_t *dw) {   // p_off is 16-aligned, W and t0 are multiples of S
                 if constexpr (S == 4) *reinterpret_cast<uint32_t *>(dst) = dw[0];
