@@ -1033,6 +1033,7 @@ __device__ __forceinline__ void ext_strip_pair(const ExtJob *__restrict__ jobs, 
                    sb_n = (uint32_t)(8 * prm.sc_n + RS + 128) & 0xff;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem + 2 * NG * lds_stride);   // (lds_stride is a multiple of 4)
     if (lane < 5) tab[lane] = lane == 4 ? sb_n * 0x01010101u : (sb_mis * 0x01010101u) ^ ((sb_mch ^ sb_mis) << (8 * lane));
+    if (lane == 5) tab[5] = 0;   // what the lanes that are not the first of their group read (code 20): see the query words below
     // queries -> LDS as 4 * base code, one region per window, staged by the whole wave
 #pragma unroll
     for (int g2 = 0; g2 < NG; ++g2)
@@ -1093,8 +1094,14 @@ __device__ __forceinline__ void ext_strip_pair(const ExtJob *__restrict__ jobs, 
     int32_t tota = 0, totb = 0;      // sum of the vertical differences of the lane's rows in the window's last column
     const bool head = gl == 0;
     const int qa1 = qlen[0] - 1, qb1 = qlen[1] - 1;
-    auto code0 = [&](int s_) -> uint32_t { return s_ < qlen[0] ? (uint32_t)qrow0[s_] : 16u; };
-    auto code1 = [&](int s_) -> uint32_t { return s_ < qlen[1] ? (uint32_t)qrow1[s_] : 16u; };
+    // The first lane of a group takes the query words from LDS and the boundary states, the others what the lane before them hands
+    // on: as masks instead of selects (v_cndmask issues in ~17 cycles on gfx950, profiles/r03/valu_microbench2.txt) -- the other lanes
+    // read a zero word where the first reads its query word, and the shifted states are and-ed with the not-first mask.
+    const uint32_t nh = head ? 0u : 0xffffffffu;
+    const int qh0 = head ? qlen[0] : 0, qh1 = head ? qlen[1] : 0;
+    const uint32_t past = head ? 16u : 20u;
+    auto code0 = [&](int s_) -> uint32_t { return s_ < qh0 ? (uint32_t)qrow0[s_] : past; };
+    auto code1 = [&](int s_) -> uint32_t { return s_ < qh1 ? (uint32_t)qrow1[s_] : past; };
     auto word = [&](uint32_t c) -> uint32_t { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + c); };
     uint32_t qa_next = word(code0(0)), qb_next = word(code1(0));
     uint32_t ca_next = code0(1), cb_next = code1(1);
@@ -1106,8 +1113,8 @@ __device__ __forceinline__ void ext_strip_pair(const ExtJob *__restrict__ jobs, 
         const int v_s = wave_shr1_zero(out_v), x1_s = wave_shr1_zero(out_x1), x2_s = wave_shr1_zero(out_x2);
         const int j = step - gl;
         const int bj = MPN_BND(step);  // first lane: j = step
-        qta = head ? qa_in : qa_s; qtb = head ? qb_in : qb_s;
-        uint32_t Vp = head ? (uint32_t)bj * both + CV : (uint32_t)v_s, X1 = head ? 0u : (uint32_t)x1_s, X2 = head ? 0u : (uint32_t)x2_s;
+        qta = (qa_s & nh) | qa_in; qtb = (qb_s & nh) | qb_in;
+        uint32_t Vp = ((uint32_t)v_s & nh) | (((uint32_t)bj * both + CV) & ~nh), X1 = (uint32_t)x1_s & nh, X2 = (uint32_t)x2_s & nh;
         if (j >= 0 && j < qmax && gl < nlmax) {
             uint32_t dwa[(S + 3) / 4], dwb[(S + 3) / 4], ecell[4] = {0, 0, 0, 0};
             uint32_t nv0 = 0;
