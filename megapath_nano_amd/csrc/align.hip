@@ -952,8 +952,7 @@ static int run_job_group(const RefView &rv, const mpn_map_opt *opt, int nj_cap, 
             int blocks = 0;
             size_t lds = 0;
             const int c_lo = fam == 0 ? 0 : 3, c_hi = fam == 0 ? 3 : N_STRIP_CLASS;
-            static const int strip_pair = []() { const char *e = getenv("MPN_STRIP_PAIR"); return e ? atoi(e) : 1; }();   // (0: one gap fill per lane group)
-            const int pair = fam == 0 && strip_pair ? 1 : 0;
+            const int pair = fam == 0 ? 1 : 0;   // gap fills: two windows per lane group (ext_strip_pair)
             for (int glc = 2; glc >= 0; --glc)   // wide lane groups (the long windows) first
                 for (int sclass = c_lo + glc; sclass < c_hi; sclass += 3) {
                     const int l0 = L_STRIP + 16 * sclass, nl = base[l0 + 16] - base[l0], per = (pair ? 8 : 4) >> glc;

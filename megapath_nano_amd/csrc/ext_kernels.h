@@ -1228,7 +1228,9 @@ __device__ __forceinline__ void ext_strip_dispatch(const ExtJob *__restrict__ jo
                                                    const int64_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                                                    const RefView &rv, uint8_t *__restrict__ P, ExtRes *__restrict__ res, uint8_t *smem,
                                                    const int lds_stride, const int nr_stride) {
-    const int S = jobs[order[first]].strip_s;
+    const int j0 = first < n_list ? order[first] : -1;
+    if (j0 < 0) return;   // (a wave of padding only: the lists are padded to whole waves at their ends)
+    const int S = jobs[j0].strip_s;
 #define MPN_CASE(SS) case SS: ext_strip_pack<SS, GL, EXACT, RIGHT>(jobs, order, first, n_list, prm, reads, read_off, read_len, rv, P, res, smem, lds_stride, nr_stride); break
     switch (S) {
         MPN_CASE(1); MPN_CASE(2); MPN_CASE(3); MPN_CASE(4); MPN_CASE(5); MPN_CASE(6); MPN_CASE(7); MPN_CASE(8);
@@ -1256,8 +1258,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     while (k + 1 < segs.n && (int)blockIdx.x >= segs.s[k + 1].first_block) ++k;
     const StripSeg sg = segs.s[k];
     const int32_t *ord = order + sg.ord_off;
-    if constexpr (!EXACT) {
-        if (sg.pair) {
+    if constexpr (!EXACT) {   // the gap fills: always two windows per lane group
+        {
             const int first2 = ((int)blockIdx.x - sg.first_block) * (8 >> sg.glc);
             int S = 16;   // (uniform per wave: the lists are grouped by strip height and padded to whole waves)
             for (int k = 0; k < (8 >> sg.glc); ++k) { const int slot = first2 + k; if (slot < sg.n_list && ord[slot] >= 0) { S = jobs[ord[slot]].strip_s; break; } }
@@ -1269,14 +1271,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (sg.glc == 0) MPN_PAIR_S(16) else if (sg.glc == 1) MPN_PAIR_S(32) else MPN_PAIR_S(64)
 #undef MPN_PAIR_S
 #undef MPN_PAIR
-            return;
         }
-    }
-    const int first = ((int)blockIdx.x - sg.first_block) * (4 >> sg.glc);
+    } else {
+        const int first = ((int)blockIdx.x - sg.first_block) * (4 >> sg.glc);
 #define MPN_GL(GLN, RT) ext_strip_dispatch<GLN, EXACT, RT>(jobs, ord, first, sg.n_list, prm, reads, read_off, read_len, rv, P, res, smem, sg.lds_stride, sg.nr_stride)
-    if (EXACT && sg.right) { if (sg.glc == 0) MPN_GL(16, true); else if (sg.glc == 1) MPN_GL(32, true); else MPN_GL(64, true); }
-    else { if (sg.glc == 0) MPN_GL(16, false); else if (sg.glc == 1) MPN_GL(32, false); else MPN_GL(64, false); }
+        if (sg.right) { if (sg.glc == 0) MPN_GL(16, true); else if (sg.glc == 1) MPN_GL(32, true); else MPN_GL(64, true); }
+        else { if (sg.glc == 0) MPN_GL(16, false); else if (sg.glc == 1) MPN_GL(32, false); else MPN_GL(64, false); }
 #undef MPN_GL
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
