@@ -1693,7 +1693,8 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                 const int e = e0 + lane;
                 if (e < n_u) {
                     int32_t j = (int32_t)u[e];
-                    while (j >= 0) { if (atomicMin(&t[j], e) < e) break; j = p[j]; }
+                    // (the predecessor is fetched beside the atomic, not after it: one memory round trip per step of the walk)
+                    while (j >= 0) { const int32_t nj = p[j]; if (atomicMin(&t[j], e) < e) break; j = nj; }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
@@ -1707,7 +1708,7 @@ __global__ __launch_bounds__(64) void chain_backtrack_kernel(const u128 *__restr
                     const uint64_t ui = u[e];
                     int32_t j = p[(int32_t)ui];
                     cnt = 1;   // (the ordered walk visits its start even when a better end has taken it)
-                    while (j >= 0 && t[j] == e) { ++cnt; j = p[j]; }
+                    while (j >= 0) { const int32_t tj = t[j], nj = p[j]; if (tj != e) break; ++cnt; j = nj; }
                     const bool keep = cnt >= cp.min_cnt && (j < 0 || (int32_t)(ui >> 32) - f[j] >= cp.min_sc);
                     if (!keep) cnt = 0;
                     v[e] = cnt;
