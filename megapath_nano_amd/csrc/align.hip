@@ -1773,12 +1773,15 @@ static int map_batch_core(const mpn_index *const *parts, int n_parts, const mpn_
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             for (const Slot &S : g_slots) held += S.device_bytes();
             const double avail = 0.9 * (double)(free_b + held);
-            auto per_worker = [&](int64_t sub_bp) { return std::max(400.0, 1.15 * obs_bytes_per_bp) * (double)std::max<int64_t>(sub_bp, 1) + 2e9; };
+            // (no call has been observed yet: the need of a strain-rich multi-part target set, 850 bytes per base, is assumed -- a first call
+            // sized for a random target set ran out of memory on it, shed workers and took five times a steady-state call)
+            const double bytes_per_bp = obs_bytes_per_bp > 0 ? std::max(400.0, 1.15 * obs_bytes_per_bp) : 900.0;
+            auto per_worker = [&](int64_t sub_bp) { return bytes_per_bp * (double)std::max<int64_t>(sub_bp, 1) + 2e9; };
             int fit = (int)std::max(1.0, avail / per_worker(largest));
             if (fit < std::min(W_all, n_sub) && !env_target && largest > 11000000) {
                 // what fits W_all workers, at least 11 Mbp
                 const double room = avail / W_all - 2e9;
-                const int64_t t2 = std::max<int64_t>(11000000, (int64_t)(room / std::max(400.0, 1.15 * obs_bytes_per_bp)));
+                const int64_t t2 = std::max<int64_t>(11000000, (int64_t)(room / bytes_per_bp));
                 if (t2 < largest) {
                     make_cuts(t2);
                     n_sub = (int)cut.size() - 1;
